@@ -1,0 +1,33 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: CPU test that takes tens of seconds")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle as O  # oracle/oracle.py (test infrastructure)
+    O.lib()
+    return O
+
+
+@pytest.fixture(scope="session")
+def golden_cases():
+    with open(os.path.join(ROOT, "tests", "golden", "cases.json")) as f:
+        return json.load(f)["cases"]
+
+
+def text_bytes(s: str) -> np.ndarray:
+    return np.frombuffer(s.encode("latin-1"), dtype=np.uint8)
