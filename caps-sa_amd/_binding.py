@@ -1,0 +1,189 @@
+"""ctypes binding of the C ABI declared in include/caps_sa_hip.h.
+
+``CapsLib(path, prefix)`` binds one shared library.  The product package binds
+libcaps_sa_hip.so (prefix ``caps_sa_hip_``); tests bind the host emulation of the same
+sources (tests/emul/libcaps_sa_emul.so, prefix ``caps_sa_emul_``) through this class too.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+_u64, _vp, _ci = ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int
+
+
+class Stats(ctypes.Structure):
+    """caps_sa_stats (include/caps_sa_hip.h)."""
+    _fields_ = [
+        ("n", ctypes.c_uint64),
+        ("idx_bytes", ctypes.c_uint32),
+        ("p_eff", ctypes.c_uint32),
+        ("ppp", ctypes.c_uint32),
+        ("bits_per_char", ctypes.c_uint32),
+        ("merge_passes_phase1", ctypes.c_uint32),
+        ("merge_passes_phase2", ctypes.c_uint32),
+        ("merge_passes_samples", ctypes.c_uint32),
+        ("reserved0", ctypes.c_uint32),
+        ("max_partition", ctypes.c_uint64),
+        ("workspace_bytes", ctypes.c_uint64),
+        ("ms_total", ctypes.c_double),
+        ("ms_pack", ctypes.c_double),
+        ("ms_sort_subarrays", ctypes.c_double),
+        ("ms_select_pivots", ctypes.c_double),
+        ("ms_locate_pivots", ctypes.c_double),
+        ("ms_partition", ctypes.c_double),
+        ("ms_merge_partitions", ctypes.c_double),
+        ("ms_boundary_lcp", ctypes.c_double),
+        ("ms_output", ctypes.c_double),
+        ("ms_h2d", ctypes.c_double),
+        ("ms_d2h", ctypes.c_double),
+        ("merge_pass_ms", ctypes.c_double),
+        ("merge_pass_launches", ctypes.c_uint64),
+        ("merge_pass_elems", ctypes.c_uint64),
+        ("tile_sort_ms", ctypes.c_double),
+        ("tile_sort_launches", ctypes.c_uint64),
+        ("tile_sort_elems", ctypes.c_uint64),
+    ]
+
+    def as_dict(self) -> dict:
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved0"}
+
+
+EXPORTS = ["device_count", "last_error", "version", "workspace_bytes"] + [
+    f"{name}_{sfx}"
+    for sfx in ("u32", "u64")
+    for name in ("build", "build_device", "verify_device", "sort_suffixes", "merge", "upper_bound", "lcp")
+]
+
+
+class CapsSaError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"caps_sa error {code}: {msg}")
+        self.code = code
+
+
+def _sfx(idx_bits: int):
+    return {32: ("u32", np.uint32), 64: ("u64", np.uint64)}[idx_bits]
+
+
+class CapsLib:
+    def __init__(self, path: str, prefix: str = "caps_sa_hip_"):
+        self.path = path
+        self.prefix = prefix
+        self.dll = ctypes.CDLL(path)
+        f = self._f
+        f("device_count").restype = _ci
+        f("device_count").argtypes = []
+        f("last_error").restype = ctypes.c_char_p
+        f("version").restype = ctypes.c_char_p
+        f("workspace_bytes").restype = _ci
+        f("workspace_bytes").argtypes = [_u64, _u64, _ci, ctypes.POINTER(_u64)]
+        for sfx in ("u32", "u64"):
+            f(f"build_{sfx}").restype = _ci
+            f(f"build_{sfx}").argtypes = [_vp, _u64, _u64, _u64, _vp, _vp, _ci, ctypes.POINTER(Stats)]
+            f(f"build_device_{sfx}").restype = _ci
+            f(f"build_device_{sfx}").argtypes = [_vp, _u64, _u64, _u64, _vp, _vp, _vp, _u64, _vp, ctypes.POINTER(Stats)]
+            f(f"verify_device_{sfx}").restype = _ci
+            f(f"verify_device_{sfx}").argtypes = [_vp, _u64, _vp, _vp, _vp, ctypes.POINTER(_u64)]
+            f(f"sort_suffixes_{sfx}").restype = _ci
+            f(f"sort_suffixes_{sfx}").argtypes = [_vp, _u64, _vp, _u64, _vp, _vp, _ci]
+            f(f"merge_{sfx}").restype = _ci
+            f(f"merge_{sfx}").argtypes = [_vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp, _vp, _vp, _ci]
+            f(f"upper_bound_{sfx}").restype = _ci
+            f(f"upper_bound_{sfx}").argtypes = [_vp, _u64, _vp, _u64, _vp, _u64, _vp, _ci]
+            f(f"lcp_{sfx}").restype = _ci
+            f(f"lcp_{sfx}").argtypes = [_vp, _u64, _vp, _vp, _u64, _vp, _ci]
+
+    def _f(self, name: str):
+        return getattr(self.dll, self.prefix + name)
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise CapsSaError(rc, self._f("last_error")().decode(errors="replace"))
+
+    # ------------------------------------------------------------------ queries
+    def device_count(self) -> int:
+        return self._f("device_count")()
+
+    def version(self) -> str:
+        return self._f("version")().decode()
+
+    def workspace_bytes(self, n: int, p: int = 0, idx_bits: int = 32) -> int:
+        out = _u64(0)
+        self._check(self._f("workspace_bytes")(n, p, idx_bits // 8, ctypes.byref(out)))
+        return out.value
+
+    # ------------------------------------------------------------------ host-buffer build
+    @staticmethod
+    def _text(T) -> np.ndarray:
+        if isinstance(T, (bytes, bytearray)):
+            T = np.frombuffer(bytes(T), dtype=np.uint8)
+        return np.ascontiguousarray(T, dtype=np.uint8)
+
+    def build(self, T, p: int = 0, max_context: int = 0, idx_bits: int = 32, device: int = 0):
+        """construct() on host buffers -> (SA, LCP, stats dict)."""
+        T = self._text(T)
+        sfx, dt = _sfx(idx_bits)
+        SA = np.empty(T.size, dtype=dt)
+        LCP = np.empty(T.size, dtype=dt)
+        st = Stats()
+        self._check(self._f(f"build_{sfx}")(T.ctypes.data, T.size, p, max_context, SA.ctypes.data, LCP.ctypes.data,
+                                            device, ctypes.byref(st)))
+        return SA, LCP, st.as_dict()
+
+    # ------------------------------------------------------------------ device-resident build
+    def build_device(self, dT_ptr: int, n: int, dSA_ptr: int, dLCP_ptr: int, p: int = 0, max_context: int = 0,
+                     idx_bits: int = 32, workspace_ptr: int = 0, workspace_bytes: int = 0, stream: int = 0) -> dict:
+        sfx, _ = _sfx(idx_bits)
+        st = Stats()
+        self._check(self._f(f"build_device_{sfx}")(dT_ptr, n, p, max_context, dSA_ptr, dLCP_ptr, workspace_ptr or None,
+                                                   workspace_bytes, stream or None, ctypes.byref(st)))
+        return st.as_dict()
+
+    def verify_device(self, dT_ptr: int, n: int, dSA_ptr: int, dLCP_ptr: int, idx_bits: int = 32, stream: int = 0) -> int:
+        sfx, _ = _sfx(idx_bits)
+        err = _u64(0)
+        self._check(self._f(f"verify_device_{sfx}")(dT_ptr, n, dSA_ptr, dLCP_ptr, stream or None, ctypes.byref(err)))
+        return err.value
+
+    # ------------------------------------------------------------------ kernel-level entry points
+    def sort_suffixes(self, T, idx, idx_bits: int = 32, device: int = 0):
+        T = self._text(T)
+        sfx, dt = _sfx(idx_bits)
+        idx = np.ascontiguousarray(idx, dtype=dt)
+        out_sa = np.empty_like(idx)
+        out_lcp = np.empty_like(idx)
+        self._check(self._f(f"sort_suffixes_{sfx}")(T.ctypes.data, T.size, idx.ctypes.data, idx.size,
+                                                    out_sa.ctypes.data, out_lcp.ctypes.data, device))
+        return out_sa, out_lcp
+
+    def merge(self, T, X, Y, LX, LY, idx_bits: int = 32, device: int = 0):
+        T = self._text(T)
+        sfx, dt = _sfx(idx_bits)
+        X, Y, LX, LY = (np.ascontiguousarray(v, dtype=dt) for v in (X, Y, LX, LY))
+        Z = np.empty(X.size + Y.size, dtype=dt)
+        LZ = np.empty_like(Z)
+        self._check(self._f(f"merge_{sfx}")(T.ctypes.data, T.size, X.ctypes.data, X.size, Y.ctypes.data, Y.size,
+                                            LX.ctypes.data, LY.ctypes.data, Z.ctypes.data, LZ.ctypes.data, device))
+        return Z, LZ
+
+    def upper_bound(self, T, X, pivots, idx_bits: int = 32, device: int = 0):
+        T = self._text(T)
+        sfx, dt = _sfx(idx_bits)
+        X = np.ascontiguousarray(X, dtype=dt)
+        pivots = np.ascontiguousarray(pivots, dtype=dt)
+        out = np.empty_like(pivots)
+        self._check(self._f(f"upper_bound_{sfx}")(T.ctypes.data, T.size, X.ctypes.data, X.size, pivots.ctypes.data,
+                                                  pivots.size, out.ctypes.data, device))
+        return out
+
+    def lcp(self, T, a, b, idx_bits: int = 32, device: int = 0):
+        T = self._text(T)
+        sfx, dt = _sfx(idx_bits)
+        a = np.ascontiguousarray(a, dtype=dt)
+        b = np.ascontiguousarray(b, dtype=dt)
+        out = np.empty_like(a)
+        self._check(self._f(f"lcp_{sfx}")(T.ctypes.data, T.size, a.ctypes.data, b.ctypes.data, a.size,
+                                          out.ctypes.data, device))
+        return out

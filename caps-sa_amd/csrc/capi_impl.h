@@ -1,0 +1,390 @@
+// caps-sa_amd/csrc/capi_impl.h
+//
+// Bodies of the C ABI declared in include/caps_sa_hip.h.  Included exactly once by
+// caps_sa_hip.hip (product: symbols caps_sa_hip_*) and, for the host emulation used by
+// CPU-side logic tests, by tests/emul/emul_lib.cpp (symbols caps_sa_emul_*).
+#pragma once
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "pipeline.h"
+
+#ifndef CAPS_API
+#error "define CAPS_API(name) before including capi_impl.h"
+#endif
+
+namespace caps {
+
+inline std::string& last_error_ref()
+{
+    static thread_local std::string s;
+    return s;
+}
+
+// Runs f(); maps exceptions to the ABI's error codes.
+template <typename F> int guarded(F&& f)
+{
+    try {
+        last_error_ref().clear();
+        return f();
+    } catch (const OomError& e) {
+        last_error_ref() = e.what();
+        return CAPS_SA_ENOMEM;
+    } catch (const HipError& e) {
+        last_error_ref() = e.what();
+        return CAPS_SA_EHIP;
+    } catch (const std::bad_alloc&) {
+        last_error_ref() = "host allocation failed";
+        return CAPS_SA_ENOMEM;
+    } catch (const std::exception& e) {
+        last_error_ref() = e.what();
+        return CAPS_SA_EINVAL;
+    }
+}
+
+inline int fail(int code, const char* msg)
+{
+    last_error_ref() = msg;
+    return code;
+}
+
+// RAII device allocations of one call.
+struct DevAllocs {
+    Backend& be;
+    std::vector<void*> ptrs;
+    explicit DevAllocs(Backend& b) : be(b) {}
+    ~DevAllocs() { for (void* p : ptrs) be.free(p); }
+    template <typename T> T* get(size_t count)
+    {
+        T* p = static_cast<T*>(be.alloc(count * sizeof(T)));
+        ptrs.push_back(p);
+        return p;
+    }
+};
+
+template <typename idx_t> int check_common(const void* T, uint64_t n, uint64_t max_context)
+{
+    if (n && !T) return fail(CAPS_SA_EINVAL, "null text");
+    if (n > (uint64_t)std::numeric_limits<idx_t>::max())
+        return fail(CAPS_SA_EINVAL, "n does not fit the index type (use the _u64 entry point, src/main.cpp:76)");
+    if (max_context != 0 && max_context < n)
+        return fail(CAPS_SA_EUNSUPPORTED,
+                    "bounded max_context is not supported: its output depends on the merge history "
+                    "(src/Suffix_Array.cpp:72,76-77) and is unpinned by any reference test");
+    return CAPS_SA_OK;
+}
+
+int set_device(int device);   // defined by the including translation unit
+
+template <typename idx_t>
+int build_device(const void* dT, uint64_t n, uint64_t p_arg, uint64_t max_context, void* dSA, void* dLCP, void* workspace,
+                 uint64_t workspace_bytes, void* stream, caps_sa_stats* stats)
+{
+    if (int rc = check_common<idx_t>(dT, n, max_context)) return rc;
+    if (n && (!dSA || !dLCP)) return fail(CAPS_SA_EINVAL, "null output");
+    return guarded([&]() -> int {
+        Backend be(static_cast<decltype(Backend::stream)>(stream));
+        DevAllocs da(be);
+        Plan<idx_t> need = make_plan<idx_t>(n, p_arg, nullptr);
+        char* base = static_cast<char*>(workspace);
+        if (!base) base = da.get<char>(need.bytes);
+        else if (workspace_bytes < need.bytes) return fail(CAPS_SA_EINVAL, "workspace too small");
+        // carve from a 256-byte aligned base
+        char* aligned = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(base) + 255) & ~uintptr_t(255));
+        Plan<idx_t> pl = make_plan<idx_t>(n, p_arg, aligned);
+        Builder<idx_t> b(be, pl);
+        b.build(static_cast<const uint8_t*>(dT), static_cast<idx_t*>(dSA), static_cast<idx_t*>(dLCP), stats);
+        return CAPS_SA_OK;
+    });
+}
+
+template <typename idx_t>
+int build_host(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context, idx_t* SA, idx_t* LCP, int device,
+               caps_sa_stats* stats)
+{
+    if (int rc = check_common<idx_t>(T, n, max_context)) return rc;
+    if (n && (!SA || !LCP)) return fail(CAPS_SA_EINVAL, "null output");
+    if (int rc = set_device(device)) return rc;
+    return guarded([&]() -> int {
+        Backend be(nullptr);
+        DevAllocs da(be);
+        uint8_t* dT = da.get<uint8_t>(n);
+        idx_t* dSA = da.get<idx_t>(n);
+        idx_t* dLCP = da.get<idx_t>(n);
+        BackendEvent h0 = be.record();
+        be.h2d(dT, T, n);
+        BackendEvent h1 = be.record();
+        be.sync();
+        caps_sa_stats local;
+        int rc = build_device<idx_t>(dT, n, p_arg, max_context, dSA, dLCP, nullptr, 0, nullptr, &local);
+        if (rc) return rc;
+        BackendEvent d0 = be.record();
+        be.d2h(SA, dSA, n * sizeof(idx_t));
+        be.d2h(LCP, dLCP, n * sizeof(idx_t));
+        BackendEvent d1 = be.record();
+        be.sync();
+        local.ms_h2d = be.elapsed_ms(h0, h1);
+        local.ms_d2h = be.elapsed_ms(d0, d1);
+        if (stats) *stats = local;
+        return CAPS_SA_OK;
+    });
+}
+
+template <typename idx_t>
+int verify_device(const void* dT, uint64_t n, const void* dSA, const void* dLCP, void* stream, uint64_t* n_errors)
+{
+    if (!n_errors) return fail(CAPS_SA_EINVAL, "null n_errors");
+    *n_errors = 0;
+    if (n == 0) return CAPS_SA_OK;
+    if (!dT || !dSA || !dLCP) return fail(CAPS_SA_EINVAL, "null pointer");
+    return guarded([&]() -> int {
+        Backend be(static_cast<decltype(Backend::stream)>(stream));
+        DevAllocs da(be);
+        const size_t words = (n + 31) / 32;
+        uint32_t* seen = da.get<uint32_t>(words);
+        uint64_t* err = da.get<uint64_t>(1);
+        be.memset(seen, 0, words * sizeof(uint32_t));
+        be.memset(err, 0, sizeof(uint64_t));
+        const uint64_t want = (n + 255) / 256;
+        CAPS_LAUNCH((verify_kernel<idx_t>), want < 16384 ? want : 16384, 256, be, static_cast<const int8_t*>(dT), n,
+                    static_cast<const idx_t*>(dSA), static_cast<const idx_t*>(dLCP), seen, err);
+        be.d2h(n_errors, err, sizeof(uint64_t));
+        be.sync();
+        return CAPS_SA_OK;
+    });
+}
+
+// Text on the device for the kernel-level entry points.
+struct DevText {
+    uint8_t* raw = nullptr;
+    uint32_t* P = nullptr;
+    int bits = 0;
+};
+
+inline DevText upload_text(Backend& be, DevAllocs& da, const char* T, uint64_t n)
+{
+    DevText t;
+    t.raw = da.get<uint8_t>(n ? n : 1);
+    t.P = da.get<uint32_t>(packed_words(n ? n : 1, 8));
+    uint32_t* present = da.get<uint32_t>(8);
+    uint8_t* lut = da.get<uint8_t>(256);
+    be.h2d(t.raw, T, n);
+    t.bits = prepare_text(be, t.raw, n, t.P, present, lut);
+    return t;
+}
+
+template <typename idx_t> SegBufs one_segment(Backend& be, DevAllocs& da, uint64_t cnt)
+{
+    SegBufs s;
+    s.G = 1;
+    s.seg_start = da.get<uint64_t>(2);
+    s.tile_off = da.get<uint32_t>(2);
+    s.tile_seg = da.get<uint32_t>(tiles_of(cnt) + 2);
+    s.out2 = da.get<uint64_t>(2);
+    CAPS_LAUNCH(uniform_segments_kernel, 1, 256, be, s.seg_start, 1u, cnt, cnt);
+    prepare_segments(be, s, tiles_of(cnt));
+    return s;
+}
+
+template <typename idx_t> ElemBuf<idx_t> elem_buf(DevAllocs& da, uint64_t cnt)
+{
+    ElemBuf<idx_t> b;
+    b.key = da.get<uint64_t>(cnt ? cnt : 1);
+    b.sa = da.get<idx_t>(cnt ? cnt : 1);
+    b.lcp = da.get<idx_t>(cnt ? cnt : 1);
+    return b;
+}
+
+template <typename idx_t> int check_positions(const idx_t* v, uint64_t cnt, uint64_t n, const char* what)
+{
+    for (uint64_t i = 0; i < cnt; ++i)
+        if ((uint64_t)v[i] >= n) return fail(CAPS_SA_EINVAL, what);
+    return CAPS_SA_OK;
+}
+
+template <typename idx_t>
+int sort_suffixes(const char* T, uint64_t n, const idx_t* idx, uint64_t cnt, idx_t* out_sa, idx_t* out_lcp, int device)
+{
+    if (int rc = check_common<idx_t>(T, n, 0)) return rc;
+    if (cnt == 0) return CAPS_SA_OK;
+    if (!idx || !out_sa || !out_lcp) return fail(CAPS_SA_EINVAL, "null pointer");
+    if (int rc = check_positions(idx, cnt, n, "suffix position out of range")) return rc;
+    if (int rc = set_device(device)) return rc;
+    return guarded([&]() -> int {
+        Backend be(nullptr);
+        DevAllocs da(be);
+        DevText t = upload_text(be, da, T, n);
+        ElemBuf<idx_t> a = elem_buf<idx_t>(da, cnt), b = elem_buf<idx_t>(da, cnt);
+        uint64_t* splits = da.get<uint64_t>(tiles_of(cnt) + 2);
+        be.h2d(a.sa, idx, cnt * sizeof(idx_t));
+        SegBufs s = one_segment<idx_t>(be, da, cnt);
+        ElemBuf<idx_t> r;
+        const uint32_t g = (uint32_t)((cnt + 255) / 256);
+        if (t.bits == 2) {
+            CAPS_LAUNCH((make_keys_kernel<idx_t, 2>), g, 256, be, (const uint32_t*)t.P, (const idx_t*)a.sa, cnt, a.key);
+            r = segmented_sort<idx_t, 2>(be, t.P, n, splits, s, tiles_of(cnt), cnt, false, a, b, cnt, nullptr, nullptr, nullptr);
+        } else {
+            CAPS_LAUNCH((make_keys_kernel<idx_t, 8>), g, 256, be, (const uint32_t*)t.P, (const idx_t*)a.sa, cnt, a.key);
+            r = segmented_sort<idx_t, 8>(be, t.P, n, splits, s, tiles_of(cnt), cnt, false, a, b, cnt, nullptr, nullptr, nullptr);
+        }
+        be.d2h(out_sa, r.sa, cnt * sizeof(idx_t));
+        be.d2h(out_lcp, r.lcp, cnt * sizeof(idx_t));
+        be.sync();
+        return CAPS_SA_OK;
+    });
+}
+
+template <typename idx_t>
+int merge_runs(const char* T, uint64_t n, const idx_t* X, uint64_t len_x, const idx_t* Y, uint64_t len_y, const idx_t* LX,
+               const idx_t* LY, idx_t* Z, idx_t* LZ, int device)
+{
+    if (int rc = check_common<idx_t>(T, n, 0)) return rc;
+    const uint64_t cnt = len_x + len_y;
+    if (cnt == 0) return CAPS_SA_OK;
+    if ((len_x && (!X || !LX)) || (len_y && (!Y || !LY)) || !Z || !LZ) return fail(CAPS_SA_EINVAL, "null pointer");
+    if (int rc = check_positions(X, len_x, n, "suffix position out of range")) return rc;
+    if (int rc = check_positions(Y, len_y, n, "suffix position out of range")) return rc;
+    if (int rc = set_device(device)) return rc;
+    return guarded([&]() -> int {
+        Backend be(nullptr);
+        DevAllocs da(be);
+        DevText t = upload_text(be, da, T, n);
+        ElemBuf<idx_t> a = elem_buf<idx_t>(da, cnt), b = elem_buf<idx_t>(da, cnt);
+        uint64_t* splits = da.get<uint64_t>(tiles_of(cnt) + 2);
+        be.h2d(a.sa, X, len_x * sizeof(idx_t));
+        be.h2d(a.sa + len_x, Y, len_y * sizeof(idx_t));
+        be.h2d(a.lcp, LX, len_x * sizeof(idx_t));
+        be.h2d(a.lcp + len_x, LY, len_y * sizeof(idx_t));
+        SegBufs s = one_segment<idx_t>(be, da, cnt);
+        const SegDesc sd = s.desc();
+        const uint32_t nt = tiles_of(cnt), g = (uint32_t)((cnt + 255) / 256);
+        if (t.bits == 2) {
+            CAPS_LAUNCH((make_keys_kernel<idx_t, 2>), g, 256, be, (const uint32_t*)t.P, (const idx_t*)a.sa, cnt, a.key);
+            CAPS_LAUNCH((merge_partition_kernel<idx_t, 2>), (nt + 255) / 256, 256, be, sd, (const uint32_t*)t.P, n, (uint64_t)TILE_E,
+                        len_x, (const uint64_t*)a.key, (const idx_t*)a.sa, splits);
+            CAPS_LAUNCH((merge_pass_kernel<idx_t, 2>), nt, TILE_NT, be, sd, (const uint32_t*)t.P, n, (uint64_t)TILE_E, len_x,
+                        (const uint64_t*)splits, (const uint64_t*)a.key, (const idx_t*)a.sa, (const idx_t*)a.lcp, b.key, b.sa, b.lcp);
+        } else {
+            CAPS_LAUNCH((make_keys_kernel<idx_t, 8>), g, 256, be, (const uint32_t*)t.P, (const idx_t*)a.sa, cnt, a.key);
+            CAPS_LAUNCH((merge_partition_kernel<idx_t, 8>), (nt + 255) / 256, 256, be, sd, (const uint32_t*)t.P, n, (uint64_t)TILE_E,
+                        len_x, (const uint64_t*)a.key, (const idx_t*)a.sa, splits);
+            CAPS_LAUNCH((merge_pass_kernel<idx_t, 8>), nt, TILE_NT, be, sd, (const uint32_t*)t.P, n, (uint64_t)TILE_E, len_x,
+                        (const uint64_t*)splits, (const uint64_t*)a.key, (const idx_t*)a.sa, (const idx_t*)a.lcp, b.key, b.sa, b.lcp);
+        }
+        be.d2h(Z, b.sa, cnt * sizeof(idx_t));
+        be.d2h(LZ, b.lcp, cnt * sizeof(idx_t));
+        be.sync();
+        return CAPS_SA_OK;
+    });
+}
+
+template <typename idx_t>
+int upper_bounds(const char* T, uint64_t n, const idx_t* X, uint64_t cnt, const idx_t* piv, uint64_t npiv, idx_t* out, int device)
+{
+    if (int rc = check_common<idx_t>(T, n, 0)) return rc;
+    if (npiv == 0) return CAPS_SA_OK;
+    if ((cnt && !X) || !piv || !out) return fail(CAPS_SA_EINVAL, "null pointer");
+    if (npiv > 0x7fffffffull) return fail(CAPS_SA_EINVAL, "too many pivots");
+    if (int rc = check_positions(X, cnt, n, "suffix position out of range")) return rc;
+    if (int rc = check_positions(piv, npiv, n, "pivot position out of range")) return rc;
+    if (int rc = set_device(device)) return rc;
+    return guarded([&]() -> int {
+        Backend be(nullptr);
+        DevAllocs da(be);
+        DevText t = upload_text(be, da, T, n);
+        ElemBuf<idx_t> a = elem_buf<idx_t>(da, cnt), pv = elem_buf<idx_t>(da, npiv);
+        idx_t* Pm = da.get<idx_t>(npiv + 2);
+        be.h2d(a.sa, X, cnt * sizeof(idx_t));
+        be.h2d(pv.sa, piv, npiv * sizeof(idx_t));
+        SegBufs s = one_segment<idx_t>(be, da, cnt);
+        const uint32_t np = (uint32_t)npiv, bpr = (np + 255) / 256;
+        const uint32_t g1 = (uint32_t)((cnt + 255) / 256), g2 = (uint32_t)((npiv + 255) / 256);
+        if (t.bits == 2) {
+            if (cnt) CAPS_LAUNCH((make_keys_kernel<idx_t, 2>), g1, 256, be, (const uint32_t*)t.P, (const idx_t*)a.sa, cnt, a.key);
+            CAPS_LAUNCH((make_keys_kernel<idx_t, 2>), g2, 256, be, (const uint32_t*)t.P, (const idx_t*)pv.sa, npiv, pv.key);
+            CAPS_LAUNCH((locate_kernel<idx_t, 2>), bpr, 256, be, (const uint32_t*)t.P, n, (const uint64_t*)s.seg_start, 1u,
+                        (const uint64_t*)a.key, (const idx_t*)a.sa, (const uint64_t*)pv.key, (const idx_t*)pv.sa, np, Pm);
+        } else {
+            if (cnt) CAPS_LAUNCH((make_keys_kernel<idx_t, 8>), g1, 256, be, (const uint32_t*)t.P, (const idx_t*)a.sa, cnt, a.key);
+            CAPS_LAUNCH((make_keys_kernel<idx_t, 8>), g2, 256, be, (const uint32_t*)t.P, (const idx_t*)pv.sa, npiv, pv.key);
+            CAPS_LAUNCH((locate_kernel<idx_t, 8>), bpr, 256, be, (const uint32_t*)t.P, n, (const uint64_t*)s.seg_start, 1u,
+                        (const uint64_t*)a.key, (const idx_t*)a.sa, (const uint64_t*)pv.key, (const idx_t*)pv.sa, np, Pm);
+        }
+        be.d2h(out, Pm + 1, npiv * sizeof(idx_t));
+        be.sync();
+        return CAPS_SA_OK;
+    });
+}
+
+template <typename idx_t>
+int lcp_pairs(const char* T, uint64_t n, const idx_t* a, const idx_t* b, uint64_t cnt, idx_t* out, int device)
+{
+    if (int rc = check_common<idx_t>(T, n, 0)) return rc;
+    if (cnt == 0) return CAPS_SA_OK;
+    if (!a || !b || !out) return fail(CAPS_SA_EINVAL, "null pointer");
+    if (int rc = check_positions(a, cnt, n, "suffix position out of range")) return rc;
+    if (int rc = check_positions(b, cnt, n, "suffix position out of range")) return rc;
+    if (int rc = set_device(device)) return rc;
+    return guarded([&]() -> int {
+        Backend be(nullptr);
+        DevAllocs da(be);
+        DevText t = upload_text(be, da, T, n);
+        idx_t* da_ = da.get<idx_t>(cnt);
+        idx_t* db_ = da.get<idx_t>(cnt);
+        idx_t* dout = da.get<idx_t>(cnt);
+        be.h2d(da_, a, cnt * sizeof(idx_t));
+        be.h2d(db_, b, cnt * sizeof(idx_t));
+        const uint32_t g = (uint32_t)((cnt + 255) / 256);
+        if (t.bits == 2)
+            CAPS_LAUNCH((lcp_pairs_kernel<idx_t, 2>), g, 256, be, (const uint32_t*)t.P, n, (const idx_t*)da_, (const idx_t*)db_, cnt, dout);
+        else
+            CAPS_LAUNCH((lcp_pairs_kernel<idx_t, 8>), g, 256, be, (const uint32_t*)t.P, n, (const idx_t*)da_, (const idx_t*)db_, cnt, dout);
+        be.d2h(out, dout, cnt * sizeof(idx_t));
+        be.sync();
+        return CAPS_SA_OK;
+    });
+}
+
+}  // namespace caps
+
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+const char* CAPS_API(last_error)(void) { return caps::last_error_ref().c_str(); }
+const char* CAPS_API(version)(void) { return "caps-sa_amd 0.1 (gfx950)"; }
+
+int CAPS_API(workspace_bytes)(uint64_t n, uint64_t subproblem_count, int idx_bytes, uint64_t* bytes)
+{
+    if (!bytes || (idx_bytes != 4 && idx_bytes != 8)) return caps::fail(CAPS_SA_EINVAL, "bad argument");
+    *bytes = (idx_bytes == 4 ? caps::make_plan<uint32_t>(n, subproblem_count, nullptr).bytes
+                             : caps::make_plan<uint64_t>(n, subproblem_count, nullptr).bytes) + 256;
+    return CAPS_SA_OK;
+}
+
+#define CAPS_DEFINE_WIDTH(SFX, IDX)                                                                                        \
+    int CAPS_API(build_##SFX)(const char* T, uint64_t n, uint64_t p, uint64_t ctx, IDX* SA, IDX* LCP, int device,          \
+                              caps_sa_stats* st)                                                                           \
+    { return caps::build_host<IDX>(T, n, p, ctx, SA, LCP, device, st); }                                                   \
+    int CAPS_API(build_device_##SFX)(const void* dT, uint64_t n, uint64_t p, uint64_t ctx, void* dSA, void* dLCP,          \
+                                     void* ws, uint64_t ws_bytes, void* stream, caps_sa_stats* st)                         \
+    { return caps::build_device<IDX>(dT, n, p, ctx, dSA, dLCP, ws, ws_bytes, stream, st); }                                \
+    int CAPS_API(verify_device_##SFX)(const void* dT, uint64_t n, const void* dSA, const void* dLCP, void* stream,          \
+                                      uint64_t* n_errors)                                                                  \
+    { return caps::verify_device<IDX>(dT, n, dSA, dLCP, stream, n_errors); }                                               \
+    int CAPS_API(sort_suffixes_##SFX)(const char* T, uint64_t n, const IDX* idx, uint64_t cnt, IDX* osa, IDX* olcp, int d) \
+    { return caps::sort_suffixes<IDX>(T, n, idx, cnt, osa, olcp, d); }                                                     \
+    int CAPS_API(merge_##SFX)(const char* T, uint64_t n, const IDX* X, uint64_t lx, const IDX* Y, uint64_t ly,             \
+                              const IDX* LX, const IDX* LY, IDX* Z, IDX* LZ, int d)                                        \
+    { return caps::merge_runs<IDX>(T, n, X, lx, Y, ly, LX, LY, Z, LZ, d); }                                                \
+    int CAPS_API(upper_bound_##SFX)(const char* T, uint64_t n, const IDX* X, uint64_t cnt, const IDX* piv, uint64_t np,    \
+                                    IDX* out, int d)                                                                       \
+    { return caps::upper_bounds<IDX>(T, n, X, cnt, piv, np, out, d); }                                                     \
+    int CAPS_API(lcp_##SFX)(const char* T, uint64_t n, const IDX* a, const IDX* b, uint64_t cnt, IDX* out, int d)          \
+    { return caps::lcp_pairs<IDX>(T, n, a, b, cnt, out, d); }
+
+CAPS_DEFINE_WIDTH(u32, uint32_t)
+CAPS_DEFINE_WIDTH(u64, uint64_t)
+
+}  // extern "C"

@@ -1,0 +1,85 @@
+// caps-sa_amd/csrc/hip_backend.h -- HIP runtime plumbing for pipeline.h (product build).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace caps {
+
+struct HipError : std::runtime_error {
+    explicit HipError(const std::string& m) : std::runtime_error(m) {}
+};
+struct OomError : std::runtime_error {
+    explicit OomError(const std::string& m) : std::runtime_error(m) {}
+};
+
+inline void hip_check(hipError_t e, const char* what)
+{
+    if (e != hipSuccess) {
+        std::string m = std::string(what) + ": " + hipGetErrorString(e);
+        if (e == hipErrorOutOfMemory) throw OomError(m);
+        throw HipError(m);
+    }
+}
+#define CAPS_HIP(call) ::caps::hip_check((call), #call)
+
+struct BackendEvent { hipEvent_t ev = nullptr; };
+
+class Backend {
+public:
+    hipStream_t stream = nullptr;
+    explicit Backend(hipStream_t s) : stream(s) {}
+    ~Backend() { release_events(); }
+
+    BackendEvent record()
+    {
+        hipEvent_t e;
+        CAPS_HIP(hipEventCreate(&e));
+        pool_.push_back(e);
+        CAPS_HIP(hipEventRecord(e, stream));
+        return BackendEvent{e};
+    }
+    double elapsed_ms(BackendEvent a, BackendEvent b)
+    {
+        float ms = 0.f;
+        CAPS_HIP(hipEventElapsedTime(&ms, a.ev, b.ev));
+        return ms;
+    }
+    void release_events()
+    {
+        for (hipEvent_t e : pool_) (void)hipEventDestroy(e);
+        pool_.clear();
+    }
+    void* alloc(size_t bytes)
+    {
+        void* p = nullptr;
+        CAPS_HIP(hipMalloc(&p, bytes ? bytes : 1));
+        return p;
+    }
+    void free(void* p) { if (p) (void)hipFree(p); }
+    void memset(void* d, int v, size_t bytes) { CAPS_HIP(hipMemsetAsync(d, v, bytes, stream)); }
+    void h2d(void* d, const void* h, size_t bytes) { if (bytes) CAPS_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, stream)); }
+    void d2h(void* h, const void* d, size_t bytes) { if (bytes) CAPS_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, stream)); }
+    void d2d(void* d, const void* s, size_t bytes) { if (bytes) CAPS_HIP(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, stream)); }
+    void sync() { CAPS_HIP(hipStreamSynchronize(stream)); }
+    void check_launch(const char* name)
+    {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) throw HipError(std::string("launch of ") + name + ": " + hipGetErrorString(e));
+    }
+
+private:
+    std::vector<hipEvent_t> pool_;
+};
+
+}  // namespace caps
+
+// Launch on the backend's stream.  Host code checks operand shapes before every launch
+// (grid sizes are derived from the same n/p that size the buffers).
+#define CAPS_LAUNCH(kernel, grid, block, be, ...)                                                        \
+    do {                                                                                                 \
+        hipLaunchKernelGGL(kernel, dim3((uint32_t)(grid)), dim3((uint32_t)(block)), 0, (be).stream, __VA_ARGS__); \
+        (be).check_launch(#kernel);                                                                      \
+    } while (0)

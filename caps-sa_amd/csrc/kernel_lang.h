@@ -1,0 +1,75 @@
+// caps-sa_amd/csrc/kernel_lang.h
+//
+// Thin kernel-language layer.  Every kernel in kernels.h is written once, as a
+// sequence of block-uniform code and thread-parallel *phases*:
+//
+//     PAR(tid) { ...per-thread work, no barrier inside... }
+//     SYNC();
+//
+// * Product build (hipcc, gfx950): PAR runs its body once with tid = threadIdx.x,
+//   SYNC is __syncthreads(), SHARED_ARRAY is LDS, TL_* are registers.
+// * CAPS_EMUL build (g++, tests/emul only): the same source becomes a host function;
+//   PAR is a loop over the block's threads, SYNC is a no-op (phases are sequential).
+//   This exists because the development container has no GPU: kernel *logic* (index
+//   arithmetic, merge-path splits, ragged tiles) is debugged there.  It is test
+//   infrastructure: the shipped library never contains or dispatches to it, and the
+//   `-m gpu` parity tests never use it.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef CAPS_EMUL
+// ------------------------------------------------------------------ host emulation
+#include <vector>
+#include <algorithm>
+#include <cstring>
+#define HD inline
+#define DEV_INLINE inline
+#define GLOBAL_FN static void
+#define LAUNCH_BOUNDS(n)
+namespace caps { struct EmulCtx { uint32_t block_idx, grid_dim, block_dim; }; }
+#define KCTX const caps::EmulCtx& kctx_,
+#define K_BLOCK_IDX (kctx_.block_idx)
+#define K_GRID_DIM (kctx_.grid_dim)
+#define K_BLOCK_DIM (kctx_.block_dim)
+#define PAR(tid) for (uint32_t tid = 0; tid < kctx_.block_dim; ++tid)
+#define SYNC() ((void)0)
+#define SHARED_ARRAY(type, name, count) std::vector<type> name##_vec_(count); type* name = name##_vec_.data()
+#define TL_DECL(type, name, cnt) std::vector<type> name##_tl_((size_t)kctx_.block_dim * (cnt)); \
+    type* const name##_tlp_ = name##_tl_.data(); const uint32_t name##_tlc_ = (cnt)
+#define TL(name, tid, k) name##_tlp_[(size_t)(tid) * name##_tlc_ + (k)]
+#define UNROLL
+#define ATOMIC_OR_U32(ptr, v) (*(ptr) |= (v))
+#define ATOMIC_ADD_U64(ptr, v) (*(ptr) += (v))
+#define ATOMIC_MAX_U64(ptr, v) (*(ptr) = std::max<uint64_t>(*(ptr), (v)))
+static inline int caps_clz64(uint64_t x) { return __builtin_clzll(x); }
+static inline uint32_t caps_bswap32(uint32_t x) { return __builtin_bswap32(x); }
+#else
+// ------------------------------------------------------------------ gfx950 (product)
+#include <hip/hip_runtime.h>
+#define HD __host__ __device__ __forceinline__
+#define DEV_INLINE __device__ __forceinline__
+#define GLOBAL_FN __global__ void
+#define LAUNCH_BOUNDS(n) __launch_bounds__(n)
+#define KCTX
+#define K_BLOCK_IDX (blockIdx.x)
+#define K_GRID_DIM (gridDim.x)
+#define K_BLOCK_DIM (blockDim.x)
+#define PAR(tid) for (uint32_t tid = threadIdx.x, par_once_ = 1; par_once_; par_once_ = 0)
+#define SYNC() __syncthreads()
+#define SHARED_ARRAY(type, name, count) __shared__ type name[count]
+#define TL_DECL(type, name, cnt) type name##_reg_[cnt]
+#define TL(name, tid, k) name##_reg_[k]
+#define UNROLL _Pragma("unroll")
+#define ATOMIC_OR_U32(ptr, v) atomicOr((ptr), (v))
+#define ATOMIC_ADD_U64(ptr, v) atomicAdd((unsigned long long*)(ptr), (unsigned long long)(v))
+#define ATOMIC_MAX_U64(ptr, v) atomicMax((unsigned long long*)(ptr), (unsigned long long)(v))
+static __host__ __device__ __forceinline__ int caps_clz64(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __clzll((long long)x);
+#else
+    return __builtin_clzll(x);
+#endif
+}
+static __host__ __device__ __forceinline__ uint32_t caps_bswap32(uint32_t x) { return __builtin_bswap32(x); }
+#endif

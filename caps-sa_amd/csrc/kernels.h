@@ -1,0 +1,718 @@
+// caps-sa_amd/csrc/kernels.h
+//
+// The HIP kernels of the suffix-array / LCP-array construction path, written for
+// gfx950 (CDNA4, wave64, 160 KiB LDS per CU) in the phase style of kernel_lang.h.
+//
+// Reference rows -> kernels:
+//   a2 LCP<8> comparator                      -> text.h (window64 / pair_lcp / suffix_less)
+//   a4 merge_sort, a5 sort_subarrays          -> tile_sort_kernel (+ merge passes below)
+//   a3 merge (LCP-merge of two runs)          -> merge_partition_kernel + merge_pass_kernel
+//   a6 sample_pivots / select_pivots          -> sample_kernel, pick_pivots_kernel (+ the sorts)
+//   a7 upper_bound, a8 locate_pivots          -> locate_kernel
+//   a9 partition_sub_subarrays                -> partition_sizes_kernel, scan_sizes_kernel,
+//                                                collate_kernel
+//   a10 merge_sub_subarrays / sort_partition  -> tile_sort_kernel + merge passes per partition
+//   a11 compute_partition_boundary_lcp        -> boundary_lcp_kernel
+//
+// Data layout in HBM: struct-of-arrays per element -- key (u64, first 64/BITS chars of
+// the suffix), sa (idx_t, text position), lcp (idx_t, lcp with the predecessor in the
+// same sorted run; 0 for a run head, like the reference's convention at
+// src/Suffix_Array.cpp:117-118,354-356).  A "segment" is an independent sort problem
+// (a subarray in phase 1, the sample set, a partition in phase 2); segments are
+// described by seg_start[G+1] and are cut into tiles of TILE_E elements aligned to the
+// segment start.
+#pragma once
+#include "kernel_lang.h"
+#include "text.h"
+
+namespace caps {
+
+constexpr uint32_t TILE_E = 4096;      // elements per tile (one workgroup)
+constexpr uint32_t TILE_NT = 1024;     // threads per tile workgroup (16 waves)
+constexpr uint32_t TILE_EPT = TILE_E / TILE_NT;
+
+// Segment/tile descriptor shared by the tile-granular kernels.
+struct SegDesc {
+    const uint64_t* seg_start;   // [G+1] element offsets of the segments
+    const uint32_t* tile_off;    // [G+1] exclusive scan of ceil(len/TILE_E); tile_off[G] = #tiles
+    const uint32_t* tile_seg;    // [#tiles] segment of each tile
+    uint32_t G;
+};
+
+struct TileInfo {
+    uint64_t s0, s1;     // segment range
+    uint32_t tl;         // tile index inside the segment
+};
+
+DEV_INLINE TileInfo tile_info(const SegDesc& sd, uint32_t b)
+{
+    const uint32_t g = sd.tile_seg[b];
+    TileInfo t;
+    t.s0 = sd.seg_start[g];
+    t.s1 = sd.seg_start[g + 1];
+    t.tl = b - sd.tile_off[g];
+    return t;
+}
+
+// Geometry of the run pair a tile belongs to during a merge pass with run length R
+// (R is a multiple of TILE_E).  single_la != ~0: the segment is ONE pair whose first run
+// has length single_la (used by the stand-alone merge entry point).
+struct PairInfo {
+    uint64_t a0;         // start of run A (= start of the merged output)
+    uint64_t la, lb;     // run lengths
+    uint64_t d0;         // first output diagonal of this tile inside the pair
+};
+
+DEV_INLINE PairInfo pair_info(const TileInfo& t, uint64_t R, uint64_t single_la)
+{
+    PairInfo p;
+    if (single_la != ~0ull) {
+        p.a0 = t.s0;
+        p.la = single_la;
+        p.lb = (t.s1 - t.s0) - single_la;
+        p.d0 = (uint64_t)t.tl * TILE_E;
+        return p;
+    }
+    const uint64_t tpp = (2 * R) / TILE_E;             // tiles per pair
+    const uint64_t q = t.tl / tpp;
+    p.a0 = t.s0 + q * 2 * R;
+    const uint64_t left = t.s1 - p.a0;
+    p.la = left < R ? left : R;
+    p.lb = left - p.la < R ? left - p.la : R;
+    p.d0 = ((uint64_t)t.tl - q * tpp) * TILE_E;
+    return p;
+}
+
+// ----------------------------------------------------------------------------------
+// Input preparation
+// ----------------------------------------------------------------------------------
+
+// Which byte values occur in T: 256-bit presence set (8 x u32), OR-reduced.
+GLOBAL_FN LAUNCH_BOUNDS(256) alphabet_kernel(KCTX const uint8_t* __restrict__ T, uint64_t n, uint32_t* __restrict__ present)
+{
+    PAR(tid) {
+        uint32_t bits[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const uint64_t stride = (uint64_t)K_GRID_DIM * K_BLOCK_DIM * 16;
+        for (uint64_t i = ((uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid) * 16; i < n; i += stride) {
+            const uint64_t e = i + 16 < n ? i + 16 : n;
+            for (uint64_t j = i; j < e; ++j) {
+                const uint32_t c = T[j];
+                UNROLL
+                for (int w = 0; w < 8; ++w) bits[w] |= (c >> 5) == (uint32_t)w ? (1u << (c & 31)) : 0u;
+            }
+        }
+        UNROLL
+        for (int w = 0; w < 8; ++w)
+            if (bits[w]) ATOMIC_OR_U32(&present[w], bits[w]);
+    }
+}
+
+// Pack raw bytes into BITS-wide codes, big-endian inside each 32-bit word (text.h).
+// lut[256] maps byte -> code.  One thread per output word; words past the text are 0.
+template <int BITS>
+GLOBAL_FN LAUNCH_BOUNDS(256) pack_kernel(KCTX const uint8_t* __restrict__ T, uint64_t n, const uint8_t* __restrict__ lut,
+                                         uint32_t* __restrict__ P, uint64_t n_words)
+{
+    constexpr uint32_t CPW = TextTraits<BITS>::CPW;
+    PAR(tid) {
+        const uint64_t stride = (uint64_t)K_GRID_DIM * K_BLOCK_DIM;
+        for (uint64_t w = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid; w < n_words; w += stride) {
+            uint32_t v = 0;
+            const uint64_t base = w * CPW;
+            UNROLL
+            for (uint32_t c = 0; c < CPW; ++c) {
+                const uint64_t i = base + c;
+                const uint32_t code = i < n ? lut[T[i]] : 0u;
+                v |= code << (32 - BITS * (c + 1));
+            }
+            P[w] = v;
+        }
+    }
+}
+
+// key/sa for an arbitrary list of suffix positions (sample sort, stand-alone entry points).
+template <typename idx_t, int BITS>
+GLOBAL_FN LAUNCH_BOUNDS(256) make_keys_kernel(KCTX const uint32_t* __restrict__ P, const idx_t* __restrict__ sa, uint64_t cnt,
+                                              uint64_t* __restrict__ key)
+{
+    PAR(tid) {
+        const uint64_t i = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (i < cnt) key[i] = window64<BITS>(P, (uint64_t)sa[i]);
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// Segment descriptors
+// ----------------------------------------------------------------------------------
+
+// seg_start[g] = min(g * s, n_total) for g < G, seg_start[G] = n_total
+// (subarrays of the reference: src/Suffix_Array.cpp:171-173, the last one takes n % p).
+GLOBAL_FN LAUNCH_BOUNDS(256) uniform_segments_kernel(KCTX uint64_t* __restrict__ seg_start, uint32_t G, uint64_t s, uint64_t n_total)
+{
+    PAR(tid) {
+        const uint64_t g = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (g < G) seg_start[g] = g * s;
+        else if (g == G) seg_start[g] = n_total;
+    }
+}
+
+// Exclusive scan of sizes[G] into seg_start[G+1] (single workgroup).
+// Partition offsets of the reference's serial scan (src/Suffix_Array.cpp:319-330).
+// gfx950: per-wave inclusive scan with wave64 shuffles, wave totals combined through LDS.
+GLOBAL_FN LAUNCH_BOUNDS(1024) scan_sizes_kernel(KCTX const uint64_t* __restrict__ sizes, uint32_t G, uint64_t* __restrict__ seg_start)
+{
+#ifdef CAPS_EMUL
+    uint64_t run = 0;
+    for (uint32_t g = 0; g < G; ++g) { seg_start[g] = run; run += sizes[g]; }
+    seg_start[G] = run;
+#else
+    __shared__ uint64_t wave_tot[16];
+    __shared__ uint64_t carry_s;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < G; base += 1024) {
+        const uint32_t g = base + tid;
+        const uint64_t v = g < G ? sizes[g] : 0;
+        uint64_t x = v;                                    // inclusive scan inside the wave
+        UNROLL
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint64_t y = __shfl_up(x, d, 64);
+            if ((int)lane >= d) x += y;
+        }
+        if (lane == 63) wave_tot[wv] = x;
+        __syncthreads();
+        uint64_t off = carry_s;
+        for (uint32_t w = 0; w < wv; ++w) off += wave_tot[w];
+        if (g < G) seg_start[g] = off + x - v;
+        __syncthreads();
+        if (tid == 1023) carry_s = off + x;
+        __syncthreads();
+    }
+    if (tid == 0) seg_start[G] = carry_s;
+#endif
+}
+
+// tile_off[G+1] = exclusive scan of ceil(len/TILE_E); out2[0] = #tiles, out2[1] = max segment
+// length (out2 must be zeroed before the launch).  Single workgroup; LDS Hillis-Steele scan
+// per chunk of 1024 segments.
+GLOBAL_FN LAUNCH_BOUNDS(1024) seg_prepare_kernel(KCTX const uint64_t* __restrict__ seg_start, uint32_t G,
+                                                 uint32_t* __restrict__ tile_off, uint64_t* __restrict__ out2)
+{
+    SHARED_ARRAY(uint32_t, buf, 2048);
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < G; base += 1024) {
+        PAR(tid) {
+            const uint32_t g = base + tid;
+            uint64_t len = 0;
+            if (g < G) len = seg_start[g + 1] - seg_start[g];
+            buf[tid] = (uint32_t)((len + TILE_E - 1) / TILE_E);
+            if (len) ATOMIC_MAX_U64(&out2[1], len);
+        }
+        SYNC();
+        uint32_t src = 0;
+        for (uint32_t d = 1; d < 1024; d <<= 1) {
+            PAR(tid) {
+                buf[(src ^ 1) * 1024 + tid] = buf[src * 1024 + tid] + (tid >= d ? buf[src * 1024 + tid - d] : 0u);
+            }
+            SYNC();
+            src ^= 1;
+        }
+        PAR(tid) {
+            const uint32_t g = base + tid;
+            if (g < G) {
+                const uint64_t len = seg_start[g + 1] - seg_start[g];
+                tile_off[g] = carry + buf[src * 1024 + tid] - (uint32_t)((len + TILE_E - 1) / TILE_E);
+            }
+        }
+        SYNC();
+        carry += buf[src * 1024 + 1023];     // block-uniform
+        SYNC();
+    }
+    PAR(tid) {
+        if (tid == 0) { tile_off[G] = carry; out2[0] = carry; }
+    }
+}
+
+// tile_seg[b] = the segment g with tile_off[g] <= b < tile_off[g+1].
+GLOBAL_FN LAUNCH_BOUNDS(256) tile_map_kernel(KCTX const uint32_t* __restrict__ tile_off, uint32_t G, uint32_t* __restrict__ tile_seg)
+{
+    PAR(tid) {
+        const uint64_t b = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (b < tile_off[G]) {
+            uint32_t lo = 0, hi = G;               // largest g in [0, G) with tile_off[g] <= b
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) / 2;
+                if (tile_off[mid] <= b) lo = mid; else hi = mid;
+            }
+            tile_seg[b] = lo;
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// a4/a5: tile sort -- one workgroup sorts up to TILE_E suffixes in LDS and emits the
+// sorted run with its LCP array (reference: merge_sort, src/Suffix_Array.cpp:112-129,
+// called per subarray at :171-173).
+//
+// FROM_TEXT: the tile is TILE_E consecutive text positions (phase 1); keys are cut
+// from the packed text.  Otherwise (key, sa) pairs are read from in_key/in_sa.
+// In-LDS algorithm: bottom-up merge sort where every element finds its output slot
+// by a binary search in the sibling run (rank merge): no divergent serial merge,
+// ragged runs need no padding.  LCPs are produced once, at the end, from adjacent
+// keys (text only on equal keys).
+// LDS: 4096 x (8 + sizeof(idx_t)) = 48/64 KiB -> two workgroups (32 waves) per CU.
+// ----------------------------------------------------------------------------------
+template <typename idx_t, int BITS, bool FROM_TEXT>
+GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) tile_sort_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
+                                                  const uint64_t* in_key, const idx_t* in_sa,
+                                                  uint64_t* out_key, idx_t* out_sa, idx_t* out_lcp)
+{
+    const uint32_t b = K_BLOCK_IDX;
+    if (b >= sd.tile_off[sd.G]) return;
+    const TileInfo t = tile_info(sd, b);
+    const uint64_t start = t.s0 + (uint64_t)t.tl * TILE_E;
+    const uint32_t cnt = (uint32_t)(t.s1 - start < TILE_E ? t.s1 - start : TILE_E);
+
+    SHARED_ARRAY(uint64_t, skey, TILE_E);
+    SHARED_ARRAY(idx_t, ssa, TILE_E);
+    TL_DECL(uint64_t, rk, TILE_EPT);
+    TL_DECL(idx_t, rs, TILE_EPT);
+    TL_DECL(uint32_t, rd, TILE_EPT);
+
+    PAR(tid) {
+        UNROLL
+        for (uint32_t k = 0; k < TILE_EPT; ++k) {
+            const uint32_t e = tid + k * TILE_NT;
+            if (e < cnt) {
+                if (FROM_TEXT) {
+                    skey[e] = window64<BITS>(P, start + e);
+                    ssa[e] = (idx_t)(start + e);
+                } else {
+                    skey[e] = in_key[start + e];
+                    ssa[e] = in_sa[start + e];
+                }
+            }
+        }
+    }
+    SYNC();
+
+    for (uint32_t R = 1; R < cnt; R <<= 1) {
+        PAR(tid) {
+            UNROLL
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                const uint32_t e = tid + k * TILE_NT;
+                if (e < cnt) {
+                    const uint64_t key = skey[e];
+                    const idx_t sa = ssa[e];
+                    const uint32_t run = e / R;
+                    const uint32_t own_start = run * R;
+                    uint32_t sib_start = (run ^ 1u) * R;
+                    if (sib_start > cnt) sib_start = cnt;
+                    const uint32_t sib_end = sib_start + R < cnt ? sib_start + R : cnt;
+                    uint32_t lo = sib_start, hi = sib_end;       // #sibling elements < (key, sa)
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (suffix_less<BITS>(P, n, skey[mid], (uint64_t)ssa[mid], key, (uint64_t)sa)) lo = mid + 1;
+                        else hi = mid;
+                    }
+                    TL(rk, tid, k) = key;
+                    TL(rs, tid, k) = sa;
+                    TL(rd, tid, k) = (run & ~1u) * R + (e - own_start) + (lo - sib_start);
+                }
+            }
+        }
+        SYNC();
+        PAR(tid) {
+            UNROLL
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                const uint32_t e = tid + k * TILE_NT;
+                if (e < cnt) {
+                    const uint32_t d = TL(rd, tid, k);
+                    skey[d] = TL(rk, tid, k);
+                    ssa[d] = TL(rs, tid, k);
+                }
+            }
+        }
+        SYNC();
+    }
+
+    PAR(tid) {
+        UNROLL
+        for (uint32_t k = 0; k < TILE_EPT; ++k) {
+            const uint32_t e = tid + k * TILE_NT;
+            if (e < cnt) {
+                const uint64_t key = skey[e];
+                const idx_t sa = ssa[e];
+                uint64_t l = 0;
+                if (e) l = pair_lcp<BITS>(P, n, skey[e - 1], (uint64_t)ssa[e - 1], key, (uint64_t)sa);
+                out_key[start + e] = key;
+                out_sa[start + e] = sa;
+                out_lcp[start + e] = (idx_t)l;
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// a3: LCP-merge of run pairs (reference: merge, src/Suffix_Array.cpp:48-109).
+//
+// A pass merges, inside every segment, runs (2q, 2q+1) of length R into runs of 2R.
+// The output of a pair is cut into tiles of TILE_E; merge_partition_kernel finds, per
+// tile, how many elements of run A precede the tile's first output ("merge path"
+// split, full suffix comparator); merge_pass_kernel stages the tile's two input
+// pieces (key, sa, lcp) in LDS, ranks every element in the other piece by binary
+// search, and emits the merged tile with its LCPs, coalesced.
+//
+// LCP of an output element z taken from A with rank r in B:
+//     LCP_z = max( lcp_A[z] , lcp(z, B[r-1]) )
+// because its predecessor in the output is the larger of its two predecessors, and
+// for x <= y <= z: lcp(z, y) >= lcp(z, x).  lcp(z, B[r-1]) comes from the two keys
+// (text only when the keys are equal).  This is the quantity the reference's merge
+// tracks in `m` / `l_x` (cpp:59-79); the head of a merged run keeps LCP 0 (cpp:117).
+// ----------------------------------------------------------------------------------
+template <typename idx_t, int BITS>
+GLOBAL_FN LAUNCH_BOUNDS(256) merge_partition_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
+                                                    uint64_t R, uint64_t single_la,
+                                                    const uint64_t* __restrict__ key, const idx_t* __restrict__ sa,
+                                                    uint64_t* __restrict__ splits)
+{
+    PAR(tid) {
+        const uint64_t b = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (b < sd.tile_off[sd.G]) {
+            const TileInfo t = tile_info(sd, (uint32_t)b);
+            const PairInfo pr = pair_info(t, R, single_la);
+            const uint64_t A = pr.a0, B = pr.a0 + pr.la;
+            uint64_t lo = pr.d0 > pr.lb ? pr.d0 - pr.lb : 0;
+            uint64_t hi = pr.d0 < pr.la ? pr.d0 : pr.la;
+            while (lo < hi) {
+                const uint64_t mid = (lo + hi) >> 1;
+                const uint64_t ia = A + mid, ib = B + (pr.d0 - 1 - mid);
+                if (suffix_less<BITS>(P, n, key[ia], (uint64_t)sa[ia], key[ib], (uint64_t)sa[ib])) lo = mid + 1;
+                else hi = mid;
+            }
+            splits[b] = lo;
+        }
+    }
+}
+
+template <typename idx_t, int BITS>
+GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) merge_pass_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
+                                                   uint64_t R, uint64_t single_la, const uint64_t* __restrict__ splits,
+                                                   const uint64_t* __restrict__ in_key, const idx_t* __restrict__ in_sa,
+                                                   const idx_t* __restrict__ in_lcp,
+                                                   uint64_t* __restrict__ out_key, idx_t* __restrict__ out_sa,
+                                                   idx_t* __restrict__ out_lcp)
+{
+    const uint32_t b = K_BLOCK_IDX;
+    if (b >= sd.tile_off[sd.G]) return;
+    const TileInfo t = tile_info(sd, b);
+    const PairInfo pr = pair_info(t, R, single_la);
+    const uint64_t tot = pr.la + pr.lb;
+    const uint64_t d1 = pr.d0 + TILE_E < tot ? pr.d0 + TILE_E : tot;
+    const uint64_t i0 = splits[b];
+    const uint64_t i1 = d1 < tot ? splits[b + 1] : pr.la;
+    const uint64_t j0 = pr.d0 - i0, j1 = d1 - i1;
+    const uint32_t na = (uint32_t)(i1 - i0), nb = (uint32_t)(j1 - j0), cnt = na + nb;
+    const uint64_t srcA = pr.a0 + i0, srcB = pr.a0 + pr.la + j0;
+
+    // Elements just before each piece in its own run (predecessor candidates for the
+    // first-ranked elements of the other piece).  Block-uniform scalar loads.
+    const bool hA = i0 > 0, hB = j0 > 0;
+    const uint64_t hAk = hA ? in_key[srcA - 1] : 0, hBk = hB ? in_key[srcB - 1] : 0;
+    const uint64_t hAs = hA ? (uint64_t)in_sa[srcA - 1] : 0, hBs = hB ? (uint64_t)in_sa[srcB - 1] : 0;
+
+    SHARED_ARRAY(uint64_t, skey, TILE_E);
+    SHARED_ARRAY(idx_t, ssa, TILE_E);
+    SHARED_ARRAY(idx_t, slcp, TILE_E);
+    TL_DECL(uint64_t, rk, TILE_EPT);
+    TL_DECL(idx_t, rs, TILE_EPT);
+    TL_DECL(idx_t, rl, TILE_EPT);
+    TL_DECL(uint32_t, rd, TILE_EPT);
+
+    PAR(tid) {
+        UNROLL
+        for (uint32_t k = 0; k < TILE_EPT; ++k) {
+            const uint32_t x = tid + k * TILE_NT;
+            if (x < cnt) {
+                const uint64_t src = x < na ? srcA + x : srcB + (x - na);
+                skey[x] = in_key[src];
+                ssa[x] = in_sa[src];
+                slcp[x] = in_lcp[src];
+            }
+        }
+    }
+    SYNC();
+    PAR(tid) {
+        UNROLL
+        for (uint32_t k = 0; k < TILE_EPT; ++k) {
+            const uint32_t x = tid + k * TILE_NT;
+            if (x < cnt) {
+                const uint64_t key = skey[x];
+                const uint64_t sa = (uint64_t)ssa[x];
+                const bool fromA = x < na;
+                uint32_t lo = fromA ? na : 0u, hi = fromA ? cnt : na;
+                const uint32_t base = lo;
+                while (lo < hi) {                           // #elements of the other piece < (key, sa)
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (suffix_less<BITS>(P, n, skey[mid], (uint64_t)ssa[mid], key, sa)) lo = mid + 1;
+                    else hi = mid;
+                }
+                const uint32_t r = lo - base;
+                bool pv;                                    // predecessor in the other run
+                uint64_t pk, ps;
+                if (r > 0) { pv = true; pk = skey[lo - 1]; ps = (uint64_t)ssa[lo - 1]; }
+                else { pv = fromA ? hB : hA; pk = fromA ? hBk : hAk; ps = fromA ? hBs : hAs; }
+                uint64_t l = (uint64_t)slcp[x];
+                if (pv) {
+                    const uint64_t l2 = pair_lcp<BITS>(P, n, pk, ps, key, sa);
+                    l = l2 > l ? l2 : l;
+                }
+                TL(rk, tid, k) = key;
+                TL(rs, tid, k) = (idx_t)sa;
+                TL(rl, tid, k) = (idx_t)l;
+                TL(rd, tid, k) = (fromA ? x : x - na) + r;
+            }
+        }
+    }
+    SYNC();
+    PAR(tid) {
+        UNROLL
+        for (uint32_t k = 0; k < TILE_EPT; ++k) {
+            const uint32_t x = tid + k * TILE_NT;
+            if (x < cnt) {
+                const uint32_t d = TL(rd, tid, k);
+                skey[d] = TL(rk, tid, k);
+                ssa[d] = TL(rs, tid, k);
+                slcp[d] = TL(rl, tid, k);
+            }
+        }
+    }
+    SYNC();
+    PAR(tid) {
+        const uint64_t dst = pr.a0 + pr.d0;
+        UNROLL
+        for (uint32_t k = 0; k < TILE_EPT; ++k) {
+            const uint32_t x = tid + k * TILE_NT;
+            if (x < cnt) {
+                out_key[dst + x] = skey[x];
+                out_sa[dst + x] = ssa[x];
+                out_lcp[dst + x] = slcp[x];
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// a6: samples and pivots (reference: sample_pivots/select_pivots, cpp:187-222).
+// Unlike the reference's truncated gap (cpp:191: the top of every subarray is never
+// sampled), samples are spread over the whole sorted subarray; the output
+// does not depend on the pivots.
+// ----------------------------------------------------------------------------------
+template <typename idx_t>
+GLOBAL_FN LAUNCH_BOUNDS(256) sample_kernel(KCTX const uint64_t* __restrict__ seg_start, uint32_t G, uint32_t ppp,
+                                           const uint64_t* __restrict__ key, const idx_t* __restrict__ sa,
+                                           uint64_t* __restrict__ out_key, idx_t* __restrict__ out_sa)
+{
+    PAR(tid) {
+        const uint64_t t = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (t < (uint64_t)G * ppp) {
+            const uint32_t g = (uint32_t)(t / ppp), k = (uint32_t)(t % ppp);
+            const uint64_t s0 = seg_start[g], len = seg_start[g + 1] - s0;
+            const uint64_t at = s0 + ((uint64_t)(k + 1) * len) / (ppp + 1);
+            out_key[t] = key[at];
+            out_sa[t] = sa[at];
+        }
+    }
+}
+
+template <typename idx_t>
+GLOBAL_FN LAUNCH_BOUNDS(256) pick_pivots_kernel(KCTX const uint64_t* __restrict__ skey, const idx_t* __restrict__ ssa, uint64_t m,
+                                                uint32_t p, uint64_t* __restrict__ pkey, idx_t* __restrict__ psa)
+{
+    PAR(tid) {
+        const uint64_t j = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (j + 1 < p) {
+            const uint64_t at = ((j + 1) * m) / p;
+            pkey[j] = skey[at];
+            psa[j] = ssa[at];
+        }
+    }
+}
+
+// Maps a launch-order block id to a logical block id such that the blocks that share
+// an XCD (b % 8, MI355X_MICROARCH "Workgroup dispatch") work on a contiguous range of
+// logical blocks: consecutive logical blocks -- here the searches over one subarray --
+// then hit the same 4 MiB L2.  Speed only; any placement is correct.
+DEV_INLINE uint64_t xcd_swizzle(uint64_t b, uint64_t nb)
+{
+    const uint64_t q = nb / 8, r = nb % 8, x = b % 8, y = b / 8;
+    return x * q + (x < r ? x : r) + y;
+}
+
+// ----------------------------------------------------------------------------------
+// a7/a8: locate every pivot in every sorted segment (reference: upper_bound,
+// cpp:252-297, locate_pivots, cpp:225-249).  Pm is the reference's `P` matrix:
+// Pm[g*(np+2) .. ] = {0, ub(pivot_0), ..., ub(pivot_{np-1}), len_g}.
+// One thread per (segment, pivot); exact comparator (no 65,536-char cutoff, cpp:261).
+// ----------------------------------------------------------------------------------
+template <typename idx_t, int BITS>
+GLOBAL_FN LAUNCH_BOUNDS(256) locate_kernel(KCTX const uint32_t* __restrict__ P, uint64_t n,
+                                           const uint64_t* __restrict__ seg_start, uint32_t G,
+                                           const uint64_t* __restrict__ key, const idx_t* __restrict__ sa,
+                                           const uint64_t* __restrict__ pkey, const idx_t* __restrict__ psa, uint32_t np,
+                                           idx_t* __restrict__ Pm)
+{
+    const uint32_t bpr = (np + K_BLOCK_DIM - 1) / K_BLOCK_DIM;            // blocks per segment row
+    const uint64_t L = xcd_swizzle(K_BLOCK_IDX, (uint64_t)G * bpr);
+    const uint32_t g = (uint32_t)(L / bpr), jb = (uint32_t)(L % bpr);
+    const uint64_t s0 = seg_start[g], len = seg_start[g + 1] - s0;
+    PAR(tid) {
+        const uint32_t j = jb * K_BLOCK_DIM + tid;
+        idx_t* row = Pm + (uint64_t)g * (np + 2);
+        if (j < np) {
+            const uint64_t pk = pkey[j], ps = (uint64_t)psa[j];
+            uint64_t lo = 0, hi = len;                                    // first element > pivot
+            while (lo < hi) {
+                const uint64_t mid = (lo + hi) >> 1;
+                if (suffix_less<BITS>(P, n, pk, ps, key[s0 + mid], (uint64_t)sa[s0 + mid])) hi = mid;
+                else lo = mid + 1;
+            }
+            row[j + 1] = (idx_t)lo;
+        }
+        if (j == 0) { row[0] = 0; row[np + 1] = (idx_t)len; }
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// a9: partition sizes and the "ruler" (reference: partition_sub_subarrays, cpp:300-368).
+// Thread j walks column j of Pm: ruler[g*p + j] = offset of sub-subarray (g, j) inside
+// partition j (exclusive scan over g, cpp:340-349), sizes[j] = partition size (cpp:305-316).
+// ----------------------------------------------------------------------------------
+template <typename idx_t>
+GLOBAL_FN LAUNCH_BOUNDS(64) partition_sizes_kernel(KCTX const idx_t* __restrict__ Pm, uint32_t p,
+                                                   idx_t* __restrict__ ruler, uint64_t* __restrict__ sizes)
+{
+    PAR(tid) {
+        const uint32_t j = K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (j < p) {
+            uint64_t run = 0;
+            for (uint32_t g = 0; g < p; ++g) {
+                const idx_t* row = Pm + (uint64_t)g * (p + 1);
+                ruler[(uint64_t)g * p + j] = (idx_t)run;
+                run += (uint64_t)(row[j + 1] - row[j]);
+            }
+            sizes[j] = run;
+        }
+    }
+}
+
+// Collate: move every element of sorted subarray g to its slot in its partition
+// (reference: the p^2 memcpy's at cpp:343-358).  Element x of subarray g belongs to
+// partition j with Pm[g][j] <= x < Pm[g][j+1]; slot = part_start[j] + ruler[g][j] + (x - Pm[g][j]).
+// Reads are coalesced; writes land in runs of consecutive slots.  Only (key, sa) move:
+// phase 2 rebuilds the LCPs (the reference resets run-head LCPs here, cpp:356).
+template <typename idx_t>
+GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) collate_kernel(KCTX SegDesc sd, uint32_t p, const idx_t* __restrict__ Pm,
+                                                const idx_t* __restrict__ ruler, const uint64_t* __restrict__ part_start,
+                                                const uint64_t* __restrict__ in_key, const idx_t* __restrict__ in_sa,
+                                                uint64_t* __restrict__ out_key, idx_t* __restrict__ out_sa)
+{
+    const uint32_t b = K_BLOCK_IDX;
+    if (b >= sd.tile_off[sd.G]) return;
+    const uint32_t g = sd.tile_seg[b];
+    const TileInfo t = tile_info(sd, b);
+    const uint64_t start = t.s0 + (uint64_t)t.tl * TILE_E;
+    const uint32_t cnt = (uint32_t)(t.s1 - start < TILE_E ? t.s1 - start : TILE_E);
+    const idx_t* row = Pm + (uint64_t)g * (p + 1);
+    PAR(tid) {
+        UNROLL
+        for (uint32_t k = 0; k < TILE_EPT; ++k) {
+            const uint32_t e = tid + k * TILE_NT;
+            if (e < cnt) {
+                const uint64_t x = (uint64_t)t.tl * TILE_E + e;      // index inside the subarray
+                uint32_t lo = 0, hi = p;                             // j = #{j' in [1,p] : row[j'] <= x}
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if ((uint64_t)row[mid + 1] <= x) lo = mid + 1; else hi = mid;
+                }
+                const uint32_t j = lo;
+                const uint64_t dst = part_start[j] + (uint64_t)ruler[(uint64_t)g * p + j] + (x - (uint64_t)row[j]);
+                out_key[dst] = in_key[start + e];
+                out_sa[dst] = in_sa[start + e];
+            }
+        }
+    }
+}
+
+// a11: LCP at the first element of every segment but the first (reference:
+// compute_partition_boundary_lcp, cpp:431-447).  Empty segments are skipped by
+// construction (the reference runs out of bounds on trailing empty partitions).
+template <typename idx_t, int BITS>
+GLOBAL_FN LAUNCH_BOUNDS(256) boundary_lcp_kernel(KCTX const uint32_t* __restrict__ P, uint64_t n,
+                                                 const uint64_t* __restrict__ seg_start, uint32_t G, uint64_t total,
+                                                 const uint64_t* __restrict__ key, const idx_t* __restrict__ sa,
+                                                 idx_t* __restrict__ lcp)
+{
+    PAR(tid) {
+        const uint64_t j = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid + 1;
+        if (j < G) {
+            const uint64_t at = seg_start[j];
+            if (at > 0 && at < total && seg_start[j + 1] > at)
+                lcp[at] = (idx_t)pair_lcp<BITS>(P, n, key[at - 1], (uint64_t)sa[at - 1], key[at], (uint64_t)sa[at]);
+        }
+    }
+}
+
+// a2 as a stand-alone entry point: lcp of suffix pairs (a[i], b[i]).
+template <typename idx_t, int BITS>
+GLOBAL_FN LAUNCH_BOUNDS(256) lcp_pairs_kernel(KCTX const uint32_t* __restrict__ P, uint64_t n, const idx_t* __restrict__ a,
+                                              const idx_t* __restrict__ b, uint64_t cnt, idx_t* __restrict__ out)
+{
+    PAR(tid) {
+        const uint64_t i = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (i < cnt) {
+            const uint64_t x = a[i], y = b[i];
+            out[i] = (idx_t)(x == y ? n - x : deep_lcp<BITS>(P, n, x, y, 0));
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// Verifier (idea of the reference's never-called is_sorted,
+// cpp:512-536): works on the RAW text with byte loops, independent of the packed text
+// and keys.  err[0] += #violations; seen is an n-bit set for the permutation check.
+// ----------------------------------------------------------------------------------
+template <typename idx_t>
+GLOBAL_FN LAUNCH_BOUNDS(256) verify_kernel(KCTX const int8_t* __restrict__ T, uint64_t n, const idx_t* __restrict__ SA,
+                                           const idx_t* __restrict__ LCP, uint32_t* __restrict__ seen,
+                                           uint64_t* __restrict__ err)
+{
+    PAR(tid) {
+        const uint64_t stride = (uint64_t)K_GRID_DIM * K_BLOCK_DIM;
+        uint64_t bad = 0;
+        for (uint64_t i = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid; i < n; i += stride) {
+            const uint64_t b = SA[i];
+            if (b >= n) { ++bad; continue; }
+            const uint32_t bit = 1u << (b & 31);
+#ifdef CAPS_EMUL
+            const uint32_t old = seen[b >> 5]; seen[b >> 5] |= bit;
+#else
+            const uint32_t old = atomicOr(&seen[b >> 5], bit);
+#endif
+            if (old & bit) ++bad;
+            if (i == 0) { if (LCP[0] != 0) ++bad; continue; }
+            const uint64_t a = SA[i - 1];
+            if (a >= n) continue;                        // counted by its own thread
+            const uint64_t cap = n - (a > b ? a : b);
+            uint64_t l = 0;
+            while (l < cap && T[a + l] == T[b + l]) ++l;
+            if (l != (uint64_t)LCP[i]) ++bad;
+            if (l == cap) { if (a < b) ++bad; }
+            else if (!(T[a + l] < T[b + l])) ++bad;
+        }
+        if (bad) ATOMIC_ADD_U64(&err[0], bad);
+    }
+}
+
+}  // namespace caps

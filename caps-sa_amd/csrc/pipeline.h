@@ -1,0 +1,376 @@
+// caps-sa_amd/csrc/pipeline.h
+//
+// Host orchestration of the construction path: the GPU counterpart of
+// Suffix_Array::construct() (reference: src/Suffix_Array.cpp:466-494).  It only
+// sequences kernel launches on one HIP stream; all arithmetic is in kernels.h.
+//
+//   pack text -> [phase 1] sort p subarrays (tile sort + merge passes)
+//             -> sample, sort samples, pick p-1 pivots
+//             -> locate pivots in every subarray -> partition sizes / ruler / offsets
+//             -> collate sub-subarrays into partitions
+//             -> [phase 2] sort every partition (tile sort + merge passes)
+//             -> partition-boundary LCPs -> SA, LCP
+//
+// Written against a tiny backend interface (alloc / copies / launch) so that the same
+// sequence can be driven by the host emulation used in tests/emul (kernel_lang.h).
+#pragma once
+#include <cmath>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "../../include/caps_sa_hip.h"
+
+#ifdef CAPS_EMUL
+#include "../../tests/emul/emul_backend.h"
+#else
+#include "hip_backend.h"
+#endif
+
+namespace caps {
+
+template <typename idx_t> struct ElemBuf {
+    uint64_t* key = nullptr;
+    idx_t* sa = nullptr;
+    idx_t* lcp = nullptr;
+};
+
+// Bump allocator over one device allocation (or a dry run that only measures).
+struct Arena {
+    char* base = nullptr;
+    size_t off = 0;
+    template <typename T> T* take(size_t count)
+    {
+        off = (off + 255) & ~size_t(255);
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += count * sizeof(T);
+        return p;
+    }
+};
+
+struct SegBufs {
+    uint64_t* seg_start = nullptr;   // [G+1]
+    uint32_t* tile_off = nullptr;    // [G+1]
+    uint32_t* tile_seg = nullptr;    // [tile capacity]
+    uint64_t* out2 = nullptr;        // [2] = {#tiles, max segment length}
+    uint32_t G = 0;
+    SegDesc desc() const { return SegDesc{seg_start, tile_off, tile_seg, G}; }
+};
+
+template <typename idx_t> struct Plan {
+    uint64_t n = 0;
+    uint32_t p = 0;          // effective subproblem count (0/1 -> single segment)
+    uint32_t ppp = 0;        // samples per subarray
+    uint64_t m = 0;          // number of samples
+    uint64_t tile_cap = 0;   // capacity of the per-tile arrays
+    uint32_t* P = nullptr;
+    ElemBuf<idx_t> A, B, SA_, SB_;
+    uint64_t* pkey = nullptr;
+    idx_t* psa = nullptr;
+    idx_t* Pm = nullptr;
+    idx_t* ruler = nullptr;
+    uint64_t* sizes = nullptr;
+    SegBufs seg1, seg2, segS;
+    uint64_t* splits = nullptr;
+    uint32_t* present = nullptr;     // [8]
+    uint8_t* lut = nullptr;          // [256]
+    size_t bytes = 0;
+};
+
+// Effective subproblem count and samples per subarray: the reference's constructor,
+// src/Suffix_Array.cpp:24-27 (default 8192: include/Suffix_Array.hpp:42).
+inline void effective_params(uint64_t n, uint64_t p_arg, uint32_t* p_eff, uint32_t* ppp)
+{
+    uint64_t p = p_arg > 0 ? p_arg : 8192;
+    if (n / 16 < p) p = n / 16;
+    if (p < 2) { *p_eff = (uint32_t)p; *ppp = 0; return; }
+    const uint64_t a = (uint64_t)std::ceil(32.0 * std::log((double)n));
+    const uint64_t b = n / p - 1;
+    *p_eff = (uint32_t)p;
+    *ppp = (uint32_t)(a < b ? a : b);
+}
+
+template <typename idx_t>
+Plan<idx_t> make_plan(uint64_t n, uint64_t p_arg, char* base)
+{
+    Plan<idx_t> pl;
+    pl.n = n;
+    effective_params(n, p_arg, &pl.p, &pl.ppp);
+    Arena ar;
+    ar.base = base;
+    const uint64_t nn = n ? n : 1;
+    const bool split = pl.p >= 2;
+    const uint32_t p = split ? pl.p : 1;
+    pl.m = split ? (uint64_t)p * pl.ppp : 0;
+    pl.tile_cap = nn / TILE_E + p + 2;
+    pl.P = ar.take<uint32_t>(packed_words(nn, 8));
+    for (ElemBuf<idx_t>* b : {&pl.A, &pl.B}) {
+        b->key = ar.take<uint64_t>(nn);
+        b->sa = ar.take<idx_t>(nn);
+        b->lcp = ar.take<idx_t>(nn);
+    }
+    auto segs = [&](SegBufs& s, uint32_t G, uint64_t cap) {
+        s.G = G;
+        s.seg_start = ar.take<uint64_t>((size_t)G + 1);
+        s.tile_off = ar.take<uint32_t>((size_t)G + 1);
+        s.tile_seg = ar.take<uint32_t>(cap);
+        s.out2 = ar.take<uint64_t>(2);
+    };
+    segs(pl.seg1, p, pl.tile_cap);
+    if (split) {
+        for (ElemBuf<idx_t>* b : {&pl.SA_, &pl.SB_}) {
+            b->key = ar.take<uint64_t>(pl.m);
+            b->sa = ar.take<idx_t>(pl.m);
+            b->lcp = ar.take<idx_t>(pl.m);
+        }
+        pl.pkey = ar.take<uint64_t>(p);
+        pl.psa = ar.take<idx_t>(p);
+        pl.Pm = ar.take<idx_t>((size_t)p * (p + 1));
+        pl.ruler = ar.take<idx_t>((size_t)p * p);
+        pl.sizes = ar.take<uint64_t>(p);
+        segs(pl.seg2, p, pl.tile_cap);
+        segs(pl.segS, 1, pl.m / TILE_E + 3);
+    }
+    pl.splits = ar.take<uint64_t>(pl.tile_cap + 1);
+    pl.present = ar.take<uint32_t>(8);
+    pl.lut = ar.take<uint8_t>(256);
+    pl.bytes = ar.off + 256;
+    return pl;
+}
+
+// Timing of one kernel family across a build (HIP events on the build's stream).
+struct KernelClock {
+    std::vector<std::pair<BackendEvent, BackendEvent>> spans;
+    std::vector<uint64_t> elems;
+};
+
+// byte -> code preserving signed-char order (text.h).  Returns BITS.
+inline int build_lut(const uint32_t present[8], uint8_t lut[256])
+{
+    int sigma = 0;
+    for (int c = 0; c < 256; ++c) sigma += (present[c >> 5] >> (c & 31)) & 1;
+    if (sigma <= 4) {
+        for (int c = 0; c < 256; ++c) lut[c] = 0;
+        int rank = 0;
+        for (int v = -128; v < 128; ++v) {          // signed-char order
+            const int c = v & 0xFF;
+            if ((present[c >> 5] >> (c & 31)) & 1) lut[c] = (uint8_t)rank++;
+        }
+        return 2;
+    }
+    for (int c = 0; c < 256; ++c) lut[c] = (uint8_t)(c ^ 0x80);
+    return 8;
+}
+
+// Alphabet scan + packing of the raw device text dT into P (input
+// preparation on device).  present_dev: 8 x u32, lut_dev: 256 bytes.  Returns BITS.
+inline int prepare_text(Backend& be, const uint8_t* dT, uint64_t n, uint32_t* P, uint32_t* present_dev, uint8_t* lut_dev)
+{
+    be.memset(present_dev, 0, 8 * sizeof(uint32_t));
+    {
+        const uint64_t want = (n + 16 * 256 - 1) / (16 * 256);
+        const uint32_t grid = (uint32_t)(want < 4096 ? (want ? want : 1) : 4096);
+        CAPS_LAUNCH(alphabet_kernel, grid, 256, be, dT, n, present_dev);
+    }
+    uint32_t present[8];
+    be.d2h(present, present_dev, sizeof present);
+    be.sync();
+    uint8_t lut[256];
+    const int bits = build_lut(present, lut);
+    be.h2d(lut_dev, lut, 256);
+    const uint64_t n_words = packed_words(n, bits);
+    const uint64_t want = (n_words + 255) / 256;
+    const uint32_t grid = (uint32_t)(want < 65536 ? want : 65536);
+    if (bits == 2) CAPS_LAUNCH(pack_kernel<2>, grid, 256, be, dT, n, (const uint8_t*)lut_dev, P, n_words);
+    else CAPS_LAUNCH(pack_kernel<8>, grid, 256, be, dT, n, (const uint8_t*)lut_dev, P, n_words);
+    be.sync();                                    // lut[] lives on this stack frame
+    return bits;
+}
+
+inline void prepare_segments(Backend& be, const SegBufs& s, uint64_t tile_bound)
+{
+    be.memset(s.out2, 0, 2 * sizeof(uint64_t));
+    CAPS_LAUNCH(seg_prepare_kernel, 1, 1024, be, (const uint64_t*)s.seg_start, s.G, s.tile_off, s.out2);
+    const uint32_t grid = (uint32_t)((tile_bound + 255) / 256);
+    CAPS_LAUNCH(tile_map_kernel, grid ? grid : 1, 256, be, (const uint32_t*)s.tile_off, s.G, s.tile_seg);
+}
+
+inline uint32_t tiles_of(uint64_t len) { return (uint32_t)((len + TILE_E - 1) / TILE_E); }
+
+// Sort every segment: tile sort (in place on `cur`; FROM_TEXT: cut from the packed text)
+// + merge passes ping-ponging between cur and oth.  Returns the buffer holding the result.
+template <typename idx_t, int BITS>
+ElemBuf<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, uint64_t* splits, const SegBufs& s,
+                              uint32_t n_tiles, uint64_t max_len, bool from_text, ElemBuf<idx_t> cur, ElemBuf<idx_t> oth,
+                              uint64_t n_elems, uint32_t* n_passes, KernelClock* tile_clock, KernelClock* merge_clock)
+{
+    if (n_tiles == 0) return cur;
+    const SegDesc sd = s.desc();
+    BackendEvent t0 = be.record();
+    if (from_text)
+        CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, sd, P, n, (const uint64_t*)nullptr,
+                    (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp);
+    else
+        CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, sd, P, n, (const uint64_t*)cur.key,
+                    (const idx_t*)cur.sa, cur.key, cur.sa, cur.lcp);
+    BackendEvent t1 = be.record();
+    if (tile_clock) { tile_clock->spans.push_back({t0, t1}); tile_clock->elems.push_back(n_elems); }
+    uint32_t passes = 0;
+    for (uint64_t R = TILE_E; R < max_len; R *= 2) {
+        CAPS_LAUNCH((merge_partition_kernel<idx_t, BITS>), (n_tiles + 255) / 256, 256, be, sd, P, n, R, ~0ull,
+                    (const uint64_t*)cur.key, (const idx_t*)cur.sa, splits);
+        BackendEvent m0 = be.record();
+        CAPS_LAUNCH((merge_pass_kernel<idx_t, BITS>), n_tiles, TILE_NT, be, sd, P, n, R, ~0ull, (const uint64_t*)splits,
+                    (const uint64_t*)cur.key, (const idx_t*)cur.sa, (const idx_t*)cur.lcp, oth.key, oth.sa, oth.lcp);
+        BackendEvent m1 = be.record();
+        if (merge_clock) { merge_clock->spans.push_back({m0, m1}); merge_clock->elems.push_back(n_elems); }
+        std::swap(cur, oth);
+        ++passes;
+    }
+    if (n_passes) *n_passes += passes;
+    return cur;
+}
+
+template <typename idx_t> class Builder {
+public:
+    Builder(Backend& be, const Plan<idx_t>& pl) : be_(be), pl_(pl) {}
+
+    // dT: n raw bytes on the device.  dSA/dLCP: n idx_t each on the device.
+    void build(const uint8_t* dT, idx_t* dSA, idx_t* dLCP, caps_sa_stats* st)
+    {
+        const uint64_t n = pl_.n;
+        if (st) { *st = caps_sa_stats(); st->n = n; st->idx_bytes = sizeof(idx_t); st->p_eff = pl_.p; }
+        if (n == 0) return;
+        BackendEvent e0 = be_.record();
+        bits_ = prepare_text(be_, dT, n, pl_.P, pl_.present, pl_.lut);
+        BackendEvent e1 = be_.record();
+        if (bits_ == 2) run<2>(dSA, dLCP, st, e0, e1);
+        else run<8>(dSA, dLCP, st, e0, e1);
+    }
+
+    int bits() const { return bits_; }
+
+private:
+    Backend& be_;
+    const Plan<idx_t>& pl_;
+    int bits_ = 0;
+    KernelClock merge_clock_;
+    KernelClock tile_clock_;
+
+    template <int BITS>
+    ElemBuf<idx_t> seg_sort(const SegBufs& s, uint32_t n_tiles, uint64_t max_len, bool from_text, ElemBuf<idx_t> cur,
+                            ElemBuf<idx_t> oth, uint64_t n_elems, uint32_t* n_passes)
+    {
+        return segmented_sort<idx_t, BITS>(be_, pl_.P, pl_.n, pl_.splits, s, n_tiles, max_len, from_text, cur, oth, n_elems,
+                                           n_passes, &tile_clock_, &merge_clock_);
+    }
+    void prepare_segments(const SegBufs& s, uint64_t tile_bound) { ::caps::prepare_segments(be_, s, tile_bound); }
+
+    template <int BITS>
+    void run(idx_t* dSA, idx_t* dLCP, caps_sa_stats* st, BackendEvent e0, BackendEvent e1)
+    {
+        const uint64_t n = pl_.n;
+        const uint32_t p = pl_.p;
+        uint32_t passes1 = 0, passes2 = 0, passesS = 0;
+        ElemBuf<idx_t> res;
+        BackendEvent e2, e3, e4, e5, e6, e7;
+        uint64_t max_part = 0;
+
+        if (p < 2) {
+            // Below the reference's valid domain (n < 32 or p_eff < 2) the
+            // samplesort degenerates to ONE segment: tile sort + merge passes over [0, n).
+            CAPS_LAUNCH(uniform_segments_kernel, 1, 256, be_, pl_.seg1.seg_start, 1u, n, n);
+            prepare_segments(pl_.seg1, tiles_of(n));
+            res = seg_sort<BITS>(pl_.seg1, tiles_of(n), n, true, pl_.A, pl_.B, n, &passes1);
+            e2 = e3 = e4 = e5 = e6 = e7 = be_.record();
+        } else {
+            const uint64_t s = n / p, last = s + n % p;
+            // ---- phase 1 (a5): sort the p subarrays of contiguous text positions
+            CAPS_LAUNCH(uniform_segments_kernel, (p + 256) / 256, 256, be_, pl_.seg1.seg_start, p, s, n);
+            const uint32_t n_tiles1 = (p - 1) * tiles_of(s) + tiles_of(last);
+            prepare_segments(pl_.seg1, n_tiles1);
+            ElemBuf<idx_t> cur = seg_sort<BITS>(pl_.seg1, n_tiles1, last, true, pl_.A, pl_.B, n, &passes1);
+            ElemBuf<idx_t> oth = cur.key == pl_.A.key ? pl_.B : pl_.A;
+            e2 = be_.record();
+
+            // ---- pivots (a6)
+            const uint64_t m = pl_.m;
+            CAPS_LAUNCH((sample_kernel<idx_t>), (uint32_t)((m + 255) / 256), 256, be_, (const uint64_t*)pl_.seg1.seg_start, p,
+                        pl_.ppp, (const uint64_t*)cur.key, (const idx_t*)cur.sa, pl_.SA_.key, pl_.SA_.sa);
+            CAPS_LAUNCH(uniform_segments_kernel, 1, 256, be_, pl_.segS.seg_start, 1u, m, m);
+            prepare_segments(pl_.segS, tiles_of(m));
+            ElemBuf<idx_t> smp = seg_sort<BITS>(pl_.segS, tiles_of(m), m, false, pl_.SA_, pl_.SB_, m, &passesS);
+            CAPS_LAUNCH((pick_pivots_kernel<idx_t>), (p + 255) / 256, 256, be_, (const uint64_t*)smp.key, (const idx_t*)smp.sa,
+                        m, p, pl_.pkey, pl_.psa);
+            e3 = be_.record();
+
+            // ---- locate (a7/a8)
+            const uint32_t np = p - 1;
+            const uint32_t bpr = (np + 255) / 256;
+            CAPS_LAUNCH((locate_kernel<idx_t, BITS>), p * bpr, 256, be_, (const uint32_t*)pl_.P, n,
+                        (const uint64_t*)pl_.seg1.seg_start, p, (const uint64_t*)cur.key, (const idx_t*)cur.sa,
+                        (const uint64_t*)pl_.pkey, (const idx_t*)pl_.psa, np, pl_.Pm);
+            e4 = be_.record();
+
+            // ---- partition sizes, offsets, collate (a9)
+            CAPS_LAUNCH((partition_sizes_kernel<idx_t>), (p + 63) / 64, 64, be_, (const idx_t*)pl_.Pm, p, pl_.ruler, pl_.sizes);
+            CAPS_LAUNCH(scan_sizes_kernel, 1, 1024, be_, (const uint64_t*)pl_.sizes, p, pl_.seg2.seg_start);
+            prepare_segments(pl_.seg2, n / TILE_E + p + 1);
+            uint64_t out2[2];
+            be_.d2h(out2, pl_.seg2.out2, sizeof out2);
+            CAPS_LAUNCH((collate_kernel<idx_t>), n_tiles1, TILE_NT, be_, pl_.seg1.desc(), p, (const idx_t*)pl_.Pm,
+                        (const idx_t*)pl_.ruler, (const uint64_t*)pl_.seg2.seg_start, (const uint64_t*)cur.key,
+                        (const idx_t*)cur.sa, oth.key, oth.sa);
+            be_.sync();                                   // out2 = {#tiles, largest partition}
+            const uint32_t n_tiles2 = (uint32_t)out2[0];
+            max_part = out2[1];
+            e5 = be_.record();
+
+            // ---- phase 2 (a10): sort every partition
+            res = seg_sort<BITS>(pl_.seg2, n_tiles2, max_part, false, oth, cur, n, &passes2);
+            e6 = be_.record();
+
+            // ---- partition-boundary LCPs (a11)
+            CAPS_LAUNCH((boundary_lcp_kernel<idx_t, BITS>), (p + 255) / 256, 256, be_, (const uint32_t*)pl_.P, n,
+                        (const uint64_t*)pl_.seg2.seg_start, p, n, (const uint64_t*)res.key, (const idx_t*)res.sa, res.lcp);
+            e7 = be_.record();
+        }
+        be_.d2d(dSA, res.sa, n * sizeof(idx_t));
+        be_.d2d(dLCP, res.lcp, n * sizeof(idx_t));
+        BackendEvent e8 = be_.record();
+        be_.sync();
+
+        if (st) {
+            st->bits_per_char = BITS;
+            st->ppp = pl_.ppp;
+            st->max_partition = max_part;
+            st->merge_passes_phase1 = passes1;
+            st->merge_passes_phase2 = passes2;
+            st->merge_passes_samples = passesS;
+            st->workspace_bytes = pl_.bytes;
+            st->ms_pack = be_.elapsed_ms(e0, e1);
+            st->ms_sort_subarrays = be_.elapsed_ms(e1, e2);
+            st->ms_select_pivots = be_.elapsed_ms(e2, e3);
+            st->ms_locate_pivots = be_.elapsed_ms(e3, e4);
+            st->ms_partition = be_.elapsed_ms(e4, e5);
+            st->ms_merge_partitions = be_.elapsed_ms(e5, e6);
+            st->ms_boundary_lcp = be_.elapsed_ms(e6, e7);
+            st->ms_output = be_.elapsed_ms(e7, e8);
+            st->ms_total = be_.elapsed_ms(e0, e8);
+            auto sum = [&](KernelClock& c, double* ms, uint64_t* launches, uint64_t* elems) {
+                for (size_t i = 0; i < c.spans.size(); ++i) {
+                    *ms += be_.elapsed_ms(c.spans[i].first, c.spans[i].second);
+                    *elems += c.elems[i];
+                }
+                *launches = c.spans.size();
+            };
+            sum(merge_clock_, &st->merge_pass_ms, &st->merge_pass_launches, &st->merge_pass_elems);
+            sum(tile_clock_, &st->tile_sort_ms, &st->tile_sort_launches, &st->tile_sort_elems);
+        }
+        be_.release_events();
+    }
+};
+
+}  // namespace caps

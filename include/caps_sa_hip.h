@@ -1,0 +1,142 @@
+/*
+ * include/caps_sa_hip.h -- C ABI of the MI355X suffix-array / LCP-array construction path.
+ *
+ * This is the drop-in boundary: a plain-C shared library (libcaps_sa_hip.so) that sits
+ * UNDER the reference's class surface CaPS_SA::Suffix_Array<idx> (reference
+ * include/Suffix_Array.hpp:148-181).  The reference has no FFI of its own -- its only
+ * caller is src/main.cpp:78-80,84-86 -- so each entry point cites the C++ member it
+ * replaces.  caps-sa_amd/csrc/Suffix_Array.hpp is the host-side mirror of that class
+ * whose construct() calls caps_sa_hip_build_u32/_u64; INTEGRATION.md shows the binding a
+ * reference maintainer would add.
+ *
+ * Conventions: no exceptions, no exit(): every function returns 0 on success or a
+ * negative CAPS_SA_E* code (the reference calls std::exit, src/Suffix_Array.cpp:33-37);
+ * caps_sa_hip_last_error() returns a thread-local message.  Index width is chosen by
+ * the caller exactly like src/main.cpp:76-87 (n <= UINT32_MAX -> _u32, else _u64).
+ * Output is THE suffix array and LCP array of T[0..n): shorter suffix first when one is
+ * a prefix of the other, bytes ordered as signed char (src/Suffix_Array.cpp:75-77),
+ * LCP[0] = 0.  It does not depend on subproblem_count.
+ */
+#ifndef CAPS_SA_HIP_H
+#define CAPS_SA_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CAPS_SA_OK 0
+#define CAPS_SA_EINVAL (-1)       /* bad argument (null pointer, n too large for the index type) */
+#define CAPS_SA_EUNSUPPORTED (-2) /* bounded max_context (output not unique) */
+#define CAPS_SA_EHIP (-3)         /* HIP runtime error; see caps_sa_hip_last_error() */
+#define CAPS_SA_ENOMEM (-4)       /* device or host allocation failed */
+#define CAPS_SA_ENODEVICE (-5)    /* no usable GPU */
+
+/* Per-build record; replaces the per-phase stderr lines of construct()
+ * (src/Suffix_Array.cpp:469-493).  Times are HIP-event milliseconds on the build's stream. */
+typedef struct caps_sa_stats {
+    uint64_t n;
+    uint32_t idx_bytes;            /* 4 or 8 */
+    uint32_t p_eff;                /* effective subproblem count, src/Suffix_Array.cpp:24 */
+    uint32_t ppp;                  /* samples per subarray, src/Suffix_Array.cpp:27 */
+    uint32_t bits_per_char;        /* 2 (alphabet <= 4 symbols) or 8 */
+    uint32_t merge_passes_phase1, merge_passes_phase2, merge_passes_samples;
+    uint32_t reserved0;
+    uint64_t max_partition;        /* largest partition (elements) */
+    uint64_t workspace_bytes;
+    double ms_total;               /* whole build, device-resident interval */
+    double ms_pack;                /* alphabet scan + text packing */
+    double ms_sort_subarrays;      /* a5  sort_subarrays        (cpp:161-184) */
+    double ms_select_pivots;       /* a6  select_pivots         (cpp:197-222) */
+    double ms_locate_pivots;       /* a8  locate_pivots         (cpp:225-249) */
+    double ms_partition;           /* a9  partition_sub_subarrays (cpp:300-368) */
+    double ms_merge_partitions;    /* a10 merge_sub_subarrays   (cpp:371-409) */
+    double ms_boundary_lcp;        /* a11 compute_partition_boundary_lcp (cpp:431-447) */
+    double ms_output;              /* copy of SA/LCP into the caller's device buffers */
+    double ms_h2d, ms_d2h;         /* host-buffer entry points only */
+    /* the two tile-granular kernels, summed over their launches in this build */
+    double merge_pass_ms;  uint64_t merge_pass_launches;  uint64_t merge_pass_elems;
+    double tile_sort_ms;   uint64_t tile_sort_launches;   uint64_t tile_sort_elems;
+} caps_sa_stats;
+
+int caps_sa_hip_device_count(void);
+const char* caps_sa_hip_last_error(void);
+const char* caps_sa_hip_version(void);
+
+/* Device workspace a build of n suffixes needs (bytes). */
+int caps_sa_hip_workspace_bytes(uint64_t n, uint64_t subproblem_count, int idx_bytes, uint64_t* bytes);
+
+/*
+ * Replaces the body of Suffix_Array<uint32_t>::construct() / <uint64_t>
+ * (src/Suffix_Array.cpp:466-494; constructor arguments of include/Suffix_Array.hpp:155).
+ * T: n bytes, host memory, borrowed.  SA, LCP: n entries each, host memory owned by the
+ * caller (the class allocates them in its constructor, src/Suffix_Array.cpp:20-21).
+ * subproblem_count 0 -> 8192 (include/Suffix_Array.hpp:42), clamped to n/16 (cpp:24).
+ * max_context must be 0 or >= n (unbounded).  device: HIP device ordinal.
+ */
+int caps_sa_hip_build_u32(const char* T, uint64_t n, uint64_t subproblem_count, uint64_t max_context,
+                          uint32_t* SA, uint32_t* LCP, int device, caps_sa_stats* stats);
+int caps_sa_hip_build_u64(const char* T, uint64_t n, uint64_t subproblem_count, uint64_t max_context,
+                          uint64_t* SA, uint64_t* LCP, int device, caps_sa_stats* stats);
+
+/*
+ * Same construction with everything resident in HBM: dT (n bytes), dSA, dLCP (n entries)
+ * are device pointers on the current device; hip_stream is a hipStream_t (NULL = default
+ * stream).  workspace: device memory of at least caps_sa_hip_workspace_bytes(), or NULL
+ * to let the call allocate and free it.  Returns after the stream work has completed.
+ */
+int caps_sa_hip_build_device_u32(const void* dT, uint64_t n, uint64_t subproblem_count, uint64_t max_context,
+                                 void* dSA, void* dLCP, void* workspace, uint64_t workspace_bytes,
+                                 void* hip_stream, caps_sa_stats* stats);
+int caps_sa_hip_build_device_u64(const void* dT, uint64_t n, uint64_t subproblem_count, uint64_t max_context,
+                                 void* dSA, void* dLCP, void* workspace, uint64_t workspace_bytes,
+                                 void* hip_stream, caps_sa_stats* stats);
+
+/*
+ * Device verifier in the spirit of the reference's (never called) is_sorted
+ * (src/Suffix_Array.cpp:512-536) plus a permutation check; byte loops on the raw text,
+ * independent of the build kernels' packed text.  *n_errors = 0 iff (dSA, dLCP) is the
+ * suffix array and LCP array of dT.
+ */
+int caps_sa_hip_verify_device_u32(const void* dT, uint64_t n, const void* dSA, const void* dLCP,
+                                  void* hip_stream, uint64_t* n_errors);
+int caps_sa_hip_verify_device_u64(const void* dT, uint64_t n, const void* dSA, const void* dLCP,
+                                  void* hip_stream, uint64_t* n_errors);
+
+/* ---- kernel-level entry points (host buffers) for differential tests -------------- */
+
+/* merge_sort (src/Suffix_Array.cpp:112-129) of an arbitrary list of cnt distinct suffix
+ * positions: out_sa = sorted list, out_lcp = its LCP array (out_lcp[0] = 0). */
+int caps_sa_hip_sort_suffixes_u32(const char* T, uint64_t n, const uint32_t* idx, uint64_t cnt,
+                                  uint32_t* out_sa, uint32_t* out_lcp, int device);
+int caps_sa_hip_sort_suffixes_u64(const char* T, uint64_t n, const uint64_t* idx, uint64_t cnt,
+                                  uint64_t* out_sa, uint64_t* out_lcp, int device);
+
+/* merge (src/Suffix_Array.cpp:48-109): X, Y sorted suffix runs with their LCP arrays ->
+ * Z (len_x + len_y) and LCP_z. */
+int caps_sa_hip_merge_u32(const char* T, uint64_t n, const uint32_t* X, uint64_t len_x, const uint32_t* Y,
+                          uint64_t len_y, const uint32_t* LCP_x, const uint32_t* LCP_y, uint32_t* Z,
+                          uint32_t* LCP_z, int device);
+int caps_sa_hip_merge_u64(const char* T, uint64_t n, const uint64_t* X, uint64_t len_x, const uint64_t* Y,
+                          uint64_t len_y, const uint64_t* LCP_x, const uint64_t* LCP_y, uint64_t* Z,
+                          uint64_t* LCP_z, int device);
+
+/* upper_bound (src/Suffix_Array.cpp:252-297) without the 65,536-char cutoff: for each
+ * pivot suffix position, the number of elements of the sorted list X that are <= it. */
+int caps_sa_hip_upper_bound_u32(const char* T, uint64_t n, const uint32_t* X, uint64_t cnt,
+                                const uint32_t* pivots, uint64_t n_pivots, uint32_t* out, int device);
+int caps_sa_hip_upper_bound_u64(const char* T, uint64_t n, const uint64_t* X, uint64_t cnt,
+                                const uint64_t* pivots, uint64_t n_pivots, uint64_t* out, int device);
+
+/* LCP<8> (include/Suffix_Array.hpp:195-241): out[i] = lcp(T[a[i]..), T[b[i]..)). */
+int caps_sa_hip_lcp_u32(const char* T, uint64_t n, const uint32_t* a, const uint32_t* b, uint64_t cnt,
+                        uint32_t* out, int device);
+int caps_sa_hip_lcp_u64(const char* T, uint64_t n, const uint64_t* a, const uint64_t* b, uint64_t cnt,
+                        uint64_t* out, int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAPS_SA_HIP_H */

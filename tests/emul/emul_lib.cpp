@@ -1,0 +1,12 @@
+// tests/emul/emul_lib.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+// Host emulation of the kernels in caps-sa_amd/csrc (see emul_backend.h, kernel_lang.h):
+// the same sources compiled with g++ -DCAPS_EMUL, exported as caps_sa_emul_*.  Used by
+// tests/test_emul_*.py to debug kernel logic in the GPU-less dev container.
+#define CAPS_EMUL 1
+#define CAPS_API(name) caps_sa_emul_##name
+#include "../../caps-sa_amd/csrc/capi_impl.h"
+
+namespace caps {
+int set_device(int) { return CAPS_SA_OK; }
+}
+extern "C" int caps_sa_emul_device_count(void) { return 1; }

@@ -1,0 +1,19 @@
+"""Loader of the host emulation of the HIP kernels (tests/emul, test infrastructure)."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMUL_DIR = os.path.join(ROOT, "tests", "emul")
+_emul = None
+
+
+def emul():
+    global _emul
+    if _emul is None:
+        subprocess.check_call(["make", "-s", "-C", EMUL_DIR, "libcaps_sa_emul.so"])
+        if ROOT not in sys.path:
+            sys.path.insert(0, ROOT)
+        import caps_sa_amd
+        _emul = caps_sa_amd.CapsLib(os.path.join(EMUL_DIR, "libcaps_sa_emul.so"), "caps_sa_emul_")
+    return _emul

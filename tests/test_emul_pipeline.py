@@ -1,0 +1,101 @@
+"""CPU: LOGIC of the HIP kernels, run through their host emulation (tests/emul), against
+the oracle.  This is a development aid for the GPU-less container; the parity tests proper
+are the -m gpu tests in test_gpu_parity.py, which run the real kernels."""
+import numpy as np
+import pytest
+
+from conftest import text_bytes
+from emul_util import emul
+
+DNA = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def _same(E, oracle, T, p, bits=32):
+    SA, LCP, st = E.build(T, p=p, idx_bits=bits)
+    SAo, LCPo = oracle.naive_sa_lcp(T, idx_bits=bits)
+    assert np.array_equal(SA, SAo), f"SA mismatch n={T.size} p={p}"
+    assert np.array_equal(LCP, LCPo), f"LCP mismatch n={T.size} p={p}"
+    return st
+
+
+def test_golden_cases(oracle, golden_cases):
+    E = emul()
+    for c in golden_cases:
+        T = text_bytes(c["text"])
+        for p in (0, 2, 5):
+            SA, LCP, _ = E.build(T, p=p)
+            assert SA.tolist() == c["sa"], (c["name"], p)
+            assert LCP.tolist() == c["lcp"], (c["name"], p)
+
+
+@pytest.mark.parametrize("n,p", [(200000, 7), (200001, 0), (300007, 16), (100000, 1), (4096, 2), (4097, 2),
+                                 (8191, 3), (8193, 0), (65536 + 17, 4)])
+def test_random_dna(oracle, n, p):
+    rs = np.random.RandomState(n % 1000 + p)
+    st = _same(emul(), oracle, rs.choice(DNA, size=n), p)
+    assert st["bits_per_char"] == 2
+
+
+def test_byte_alphabet_and_signed_order(oracle):
+    rs = np.random.RandomState(3)
+    st = _same(emul(), oracle, rs.choice(np.frombuffer(b"abcdefghijklmnopqrstuvwxyz", dtype=np.uint8), size=150000), 5)
+    assert st["bits_per_char"] == 8
+    _same(emul(), oracle, rs.choice(np.array([0x41, 0x7F, 0x80, 0xFF, 0], dtype=np.uint8), size=100000), 6)
+    _same(emul(), oracle, rs.randint(0, 256, size=50000).astype(np.uint8), 3)
+
+
+def test_deep_lcp_inputs(oracle):
+    rs = np.random.RandomState(4)
+    E = emul()
+    n = 20000
+    SA, LCP, _ = E.build(np.full(n, ord("A"), dtype=np.uint8), p=4)
+    assert np.array_equal(SA, np.arange(n - 1, -1, -1, dtype=np.uint32))       # SURVEY 0.8 closed form
+    assert np.array_equal(LCP, np.arange(n, dtype=np.uint32))
+    _same(E, oracle, np.tile(np.frombuffer(b"AC", dtype=np.uint8), 6000), 3)
+    _same(E, oracle, np.tile(rs.choice(DNA, size=37), 500), 9)
+    # 2-bit alphabet whose smallest symbol collides with the end-of-text padding code
+    _same(E, oracle, rs.choice(np.frombuffer(b"AT", dtype=np.uint8), size=30000, p=[0.9, 0.1]), 4)
+
+
+def test_u64_indices(oracle):
+    rs = np.random.RandomState(5)
+    _same(emul(), oracle, rs.choice(DNA, size=120000), 11, bits=64)
+
+
+def test_unbounded_context_only(oracle):
+    E = emul()
+    T = np.random.RandomState(6).choice(DNA, size=1000)
+    import caps_sa_amd
+    with pytest.raises(caps_sa_amd.CapsSaError):
+        E.build(T, max_context=10)
+    E.build(T, max_context=1000)        # >= n is unbounded
+
+
+def test_kernel_level_entry_points(oracle):
+    E = emul()
+    rs = np.random.RandomState(7)
+    T = rs.choice(DNA, size=60000)
+    idx = rs.permutation(60000)[:25000].astype(np.uint32)
+    # a4 merge_sort
+    sa, lcp = E.sort_suffixes(T, idx)
+    so, lo = oracle.merge_sort(T, idx)
+    assert np.array_equal(sa, so) and np.array_equal(lcp, lo)
+    # a3 merge, ragged lengths
+    xa, xl = oracle.merge_sort(T, idx[:9000])
+    ya, yl = oracle.merge_sort(T, idx[9000:])
+    Z, LZ = E.merge(T, xa, ya, xl, yl)
+    Zo, LZo = oracle.merge(T, xa, ya, xl, yl)
+    assert np.array_equal(Z, Zo) and np.array_equal(LZ, LZo)
+    Z, LZ = E.merge(T, xa, ya[:0], xl, yl[:0])
+    assert np.array_equal(Z, xa) and np.array_equal(LZ, xl)
+    # a7 upper_bound (members and non-members of the list)
+    piv = np.concatenate([sa[::997], rs.randint(0, 60000, size=50).astype(np.uint32)])
+    ub = E.upper_bound(T, sa, piv)
+    for pv, u in zip(piv.tolist(), ub.tolist()):
+        assert u == oracle.upper_bound(T, sa, pv)
+    # a2 LCP
+    a = rs.randint(0, 60000, size=500).astype(np.uint32)
+    b = rs.randint(0, 60000, size=500).astype(np.uint32)
+    out = E.lcp(T, a, b)
+    for x, y, l in zip(a.tolist(), b.tolist(), out.tolist()):
+        assert l == oracle.lcp(T, x, y)
