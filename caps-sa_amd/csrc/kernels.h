@@ -506,8 +506,11 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) merge_pass_kernel(KCTX SegDesc sd, const uint32
 // ----------------------------------------------------------------------------------
 // a6: samples and pivots (reference: sample_pivots/select_pivots, cpp:187-222).
 // Unlike the reference's truncated gap (cpp:191: the top of every subarray is never
-// sampled), samples are spread over the whole sorted subarray; the output
-// does not depend on the pivots.
+// sampled), sample k sits at the CENTRE of the k-th of ppp equal slices of the
+// sorted subarray: the rank of a pivot among the samples is then an unbiased estimate of
+// its rank among all suffixes, and the first/last partitions are not p*gap/2 oversized
+// (samples at slice ends made them ~10x the mean at C2).  The output does not depend on
+// the pivots.
 // ----------------------------------------------------------------------------------
 template <typename idx_t>
 GLOBAL_FN LAUNCH_BOUNDS(256) sample_kernel(KCTX const uint64_t* __restrict__ seg_start, uint32_t G, uint32_t ppp,
@@ -519,7 +522,7 @@ GLOBAL_FN LAUNCH_BOUNDS(256) sample_kernel(KCTX const uint64_t* __restrict__ seg
         if (t < (uint64_t)G * ppp) {
             const uint32_t g = (uint32_t)(t / ppp), k = (uint32_t)(t % ppp);
             const uint64_t s0 = seg_start[g], len = seg_start[g + 1] - s0;
-            const uint64_t at = s0 + ((uint64_t)(k + 1) * len) / (ppp + 1);
+            const uint64_t at = s0 + ((uint64_t)(2 * k + 1) * len) / (2 * (uint64_t)ppp);
             out_key[t] = key[at];
             out_sa[t] = sa[at];
         }

@@ -1,0 +1,189 @@
+"""GPU (-m gpu): parity of the HIP path with the oracle, through the C ABI of
+libcaps_sa_hip.so.  Bit-exact: SA and LCP are integer arrays.
+
+Sizes: oracle comparisons at sizes the oracle finishes in seconds; committed golden
+fixtures; and, at BASELINE.json's sizes, size-independent properties (exact verifier on
+the device: permutation + adjacent-pair order + exact LCP) plus closed forms."""
+import numpy as np
+import pytest
+
+from conftest import text_bytes
+
+pytestmark = pytest.mark.gpu
+DNA = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+@pytest.fixture(scope="module")
+def L():
+    import torch  # noqa: F401  -- first, so that this process has ONE HIP runtime (torch's)
+    import caps_sa_amd
+    lib = caps_sa_amd.lib()
+    if lib.device_count() < 1:
+        pytest.fail("no HIP device: the -m gpu tests need a GPU (there is no CPU fallback)")
+    return lib
+
+
+def _same(L, oracle, T, p, bits=32, ref="build"):
+    SA, LCP, st = L.build(T, p=p, idx_bits=bits)
+    if ref == "build":
+        SAo, LCPo = oracle.build_sa_lcp(T, p=p, idx_bits=bits)
+    else:
+        SAo, LCPo = oracle.naive_sa_lcp(T, idx_bits=bits)
+    assert np.array_equal(SA, SAo), f"SA mismatch n={T.size} p={p}"
+    assert np.array_equal(LCP, LCPo), f"LCP mismatch n={T.size} p={p}"
+    return st
+
+
+def test_golden_cases(L, golden_cases):
+    for c in golden_cases:
+        T = text_bytes(c["text"])
+        for p in (0, 2, 5):
+            SA, LCP, _ = L.build(T, p=p)
+            assert SA.tolist() == c["sa"], (c["name"], p)
+            assert LCP.tolist() == c["lcp"], (c["name"], p)
+
+
+def test_reference_dump_digest_pins(L, oracle):
+    """Same digests the real reference produced (tests/test_oracle_pins.py)."""
+    for seed, N, dump_sha in [(1, 1000, "fb18c177a9caa2ae"), (7, 4096, "af073a56da834b57"),
+                              (123, 100000, "24db5e1b31a804d4")]:
+        T = oracle.remap(oracle.gen_rand_seq(seed, N))
+        SA, LCP, _ = L.build(T)
+        assert oracle.dump_sha256(SA, LCP)[:16] == dump_sha
+
+
+@pytest.mark.parametrize("n,p", [(200000, 7), (200001, 0), (300007, 16), (100000, 1), (4096, 2), (4097, 2),
+                                 (8191, 3), (8193, 0), (65536 + 17, 4), (1, 0), (5, 0), (31, 0), (32, 0), (33, 3)])
+def test_random_dna_vs_naive(L, oracle, n, p):
+    rs = np.random.RandomState(n % 1000 + p)
+    st = _same(L, oracle, rs.choice(DNA, size=n), p, ref="naive")
+    assert st["bits_per_char"] == 2
+
+
+def test_c1_like_fasta_standin_vs_oracle(L, oracle):
+    """BASELINE config 0 stand-in: header line + bases wrapped at 70 columns, CLI remap, p=8000."""
+    rs = np.random.RandomState(1)
+    body = rs.choice(DNA, size=4_641_652)
+    lines = [b">synthetic stand-in for data/ecoli.fa\n"]
+    raw = body.tobytes()
+    lines += [raw[i:i + 70] + b"\n" for i in range(0, len(raw), 70)]
+    T = oracle.remap(np.frombuffer(b"".join(lines), dtype=np.uint8))
+    st = _same(L, oracle, T, 8000)
+    assert st["p_eff"] == 8000
+
+
+def test_16mi_vs_oracle_and_reference_digest(L, oracle):
+    T = oracle.remap(oracle.gen_rand_seq(42, 16 * 1024 * 1024))
+    SA, LCP, st = L.build(T, p=8000)
+    assert oracle.dump_sha256(SA, LCP) == "8feac4aca81da6d0457628f62282ea6225837697123508e7359b9dacf5abf64e"
+    assert st["merge_passes_phase2"] >= 0
+
+
+def test_byte_alphabets_and_signed_order(L, oracle):
+    rs = np.random.RandomState(3)
+    st = _same(L, oracle, rs.choice(np.frombuffer(b"abcdefghijklmnopqrstuvwxyz", dtype=np.uint8), size=1_000_000), 37)
+    assert st["bits_per_char"] == 8
+    _same(L, oracle, rs.choice(np.array([0x41, 0x7F, 0x80, 0xFF, 0], dtype=np.uint8), size=300000), 6)
+    _same(L, oracle, rs.randint(0, 256, size=500000).astype(np.uint8), 0)
+
+
+def test_deep_lcp_inputs(L, oracle):
+    rs = np.random.RandomState(4)
+    n = 100_000                                   # BASELINE config 4 shape (a^n) at a size the quadratic path allows
+    SA, LCP, _ = L.build(np.full(n, ord("a"), dtype=np.uint8), p=0)
+    assert np.array_equal(SA, np.arange(n - 1, -1, -1, dtype=np.uint32))       # SURVEY 0.8 closed form
+    assert np.array_equal(LCP, np.arange(n, dtype=np.uint32))
+    _same(L, oracle, np.tile(np.frombuffer(b"AC", dtype=np.uint8), 20000), 3, ref="naive")
+    _same(L, oracle, np.tile(rs.choice(DNA, size=37), 2000), 9, ref="naive")
+    _same(L, oracle, rs.choice(np.frombuffer(b"AT", dtype=np.uint8), size=300000, p=[0.9, 0.1]), 4)
+    # planted long repeats inside random DNA (genome-like)
+    T = rs.choice(DNA, size=2_000_000)
+    T[1_000_000:1_050_000] = T[100_000:150_000]
+    T[1_500_000:1_500_400] = ord("G")
+    _same(L, oracle, T, 64)
+
+
+def test_u64_indices(L, oracle):
+    rs = np.random.RandomState(5)
+    _same(L, oracle, rs.choice(DNA, size=1_200_000), 111, bits=64)
+
+
+def test_unbounded_context_only(L):
+    import caps_sa_amd
+    T = np.random.RandomState(6).choice(DNA, size=1000)
+    with pytest.raises(caps_sa_amd.CapsSaError):
+        L.build(T, max_context=10)
+    L.build(T, max_context=1000)
+
+
+def test_kernel_level_entry_points(L, oracle):
+    rs = np.random.RandomState(7)
+    T = rs.choice(DNA, size=600000)
+    idx = rs.permutation(600000)[:250000].astype(np.uint32)
+    sa, lcp = L.sort_suffixes(T, idx)                                   # a4 merge_sort
+    so, lo = oracle.merge_sort(T, idx)
+    assert np.array_equal(sa, so) and np.array_equal(lcp, lo)
+    xa, xl = oracle.merge_sort(T, idx[:90001])                          # a3 merge
+    ya, yl = oracle.merge_sort(T, idx[90001:])
+    Z, LZ = L.merge(T, xa, ya, xl, yl)
+    Zo, LZo = oracle.merge(T, xa, ya, xl, yl)
+    assert np.array_equal(Z, Zo) and np.array_equal(LZ, LZo)
+    piv = np.concatenate([sa[::9973], rs.randint(0, 600000, size=50).astype(np.uint32)])
+    ub = L.upper_bound(T, sa, piv)                                      # a7 upper_bound
+    for pv, u in zip(piv.tolist(), ub.tolist()):
+        assert u == oracle.upper_bound(T, sa, pv)
+    a = rs.randint(0, 600000, size=5000).astype(np.uint32)              # a2 LCP
+    b = rs.randint(0, 600000, size=5000).astype(np.uint32)
+    out = L.lcp(T, a, b)
+    for x, y, l in zip(a.tolist(), b.tolist(), out.tolist()):
+        assert l == oracle.lcp(T, x, y)
+
+
+def test_suffix_array_class_mirror(L, oracle, tmp_path):
+    import caps_sa_amd
+    T = oracle.remap(oracle.gen_rand_seq(7, 4096))
+    sa = caps_sa_amd.SuffixArray(T, subproblem_count=16)
+    with pytest.raises(RuntimeError):
+        sa.SA()
+    sa.construct()
+    assert sa.n() == 4097
+    path = tmp_path / "dump.bin"
+    sa.dump(str(path))
+    import hashlib
+    assert hashlib.sha256(path.read_bytes()).hexdigest()[:16] == "af073a56da834b57"   # reference dump digest
+
+
+def _device_build_and_verify(L, n, p, seed):
+    """Device-resident build + exact device verifier; returns stats."""
+    import torch
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda")
+    T = torch.empty(n, dtype=torch.uint8, device="cuda")
+    step = 1 << 28
+    for o in range(0, n, step):
+        m = min(step, n - o)
+        T[o:o + m] = lut[torch.randint(0, 4, (m,), device="cuda", generator=g, dtype=torch.int64)]
+    T[n - 1] = ord("C")                                   # the CLI maps the trailing newline to 'C'
+    SA = torch.empty(n, dtype=torch.int32, device="cuda")
+    LCP = torch.empty(n, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    st = L.build_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr(), p=p)
+    errs = L.verify_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr())
+    assert errs == 0, f"{errs} violations"
+    # a corrupted result must be caught by the verifier
+    SA[n // 2], SA[n // 2 + 1] = SA[n // 2 + 1].clone(), SA[n // 2].clone()
+    assert L.verify_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr()) > 0
+    return st
+
+
+def test_c2_256mib_device_resident(L):
+    """BASELINE config 1: 256 MiB random DNA, u32, p = 8000."""
+    st = _device_build_and_verify(L, 268_435_457, 8000, 42)
+    assert st["p_eff"] == 8000 and st["bits_per_char"] == 2
+
+
+def test_c3_3g_device_resident(L):
+    """BASELINE headline size: 3e9 bases (+1), u32, p = 8000.  Property check on the device."""
+    st = _device_build_and_verify(L, 3_000_000_001, 8000, 42)
+    assert st["p_eff"] == 8000
