@@ -14,7 +14,7 @@ import subprocess
 
 import numpy as np
 
-from ._binding import CapsLib, CapsSaError, Stats, EXPORTS  # noqa: F401
+from ._binding import CapsLib, CapsSaError, Stats, Shard, ShardInfo, EXPORTS  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcaps_sa_hip.so")

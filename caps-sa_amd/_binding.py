@@ -50,7 +50,30 @@ class Stats(ctypes.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved0"}
 
 
-EXPORTS = ["device_count", "last_error", "version", "workspace_bytes"] + [
+class ShardInfo(ctypes.Structure):
+    """caps_sa_shard_info (include/caps_sa_hip.h)."""
+    _fields_ = [
+        ("n", ctypes.c_uint64),
+        ("p", ctypes.c_uint32), ("ppp", ctypes.c_uint32), ("rank", ctypes.c_uint32), ("world", ctypes.c_uint32),
+        ("g0", ctypes.c_uint32), ("g1", ctypes.c_uint32),
+        ("bits_per_char", ctypes.c_uint32), ("idx_bytes", ctypes.c_uint32),
+        ("part_lo", ctypes.c_uint32), ("part_hi", ctypes.c_uint32),
+        ("local_elems", ctypes.c_uint64),
+        ("m_local", ctypes.c_uint64), ("m_total", ctypes.c_uint64),
+        ("recv_total", ctypes.c_uint64),
+        ("slice_off", ctypes.c_uint64),
+        ("ms_phase1", ctypes.c_double), ("ms_pivots", ctypes.c_double), ("ms_collate", ctypes.c_double),
+        ("ms_phase2", ctypes.c_double),
+    ]
+
+    def as_dict(self) -> dict:
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+SHARD_EXPORTS = ["shard_create", "shard_destroy", "shard_info", "shard_phase1", "shard_pivots", "shard_collate",
+                 "shard_phase2", "shard_last_sa", "shard_fix_first_lcp"]
+
+EXPORTS = ["device_count", "last_error", "version", "workspace_bytes"] + SHARD_EXPORTS + [
     f"{name}_{sfx}"
     for sfx in ("u32", "u64")
     for name in ("build", "build_device", "verify_device", "sort_suffixes", "merge", "upper_bound", "lcp")
@@ -95,8 +118,30 @@ class CapsLib:
             f(f"lcp_{sfx}").restype = _ci
             f(f"lcp_{sfx}").argtypes = [_vp, _u64, _vp, _vp, _u64, _vp, _ci]
 
+        f("shard_create").restype = _ci
+        f("shard_create").argtypes = [_vp, _u64, _u64, _ci, _ci, _ci, _vp, ctypes.POINTER(_vp)]
+        f("shard_destroy").restype = None
+        f("shard_destroy").argtypes = [_vp]
+        f("shard_info").restype = _ci
+        f("shard_info").argtypes = [_vp, ctypes.POINTER(ShardInfo)]
+        f("shard_phase1").restype = _ci
+        f("shard_phase1").argtypes = [_vp, _vp, _vp]
+        f("shard_pivots").restype = _ci
+        f("shard_pivots").argtypes = [_vp, _vp, _vp, _vp]
+        f("shard_collate").restype = _ci
+        f("shard_collate").argtypes = [_vp, _vp, _vp, _vp, _vp, _vp]
+        f("shard_phase2").restype = _ci
+        f("shard_phase2").argtypes = [_vp, _vp, _vp, _vp, _vp]
+        f("shard_last_sa").restype = _ci
+        f("shard_last_sa").argtypes = [_vp, ctypes.POINTER(_u64)]
+        f("shard_fix_first_lcp").restype = _ci
+        f("shard_fix_first_lcp").argtypes = [_vp, _u64, _vp]
+
     def _f(self, name: str):
         return getattr(self.dll, self.prefix + name)
+
+    def shard(self, dT_ptr: int, n: int, p: int, idx_bits: int, rank: int, world: int, stream: int = 0) -> "Shard":
+        return Shard(self, dT_ptr, n, p, idx_bits, rank, world, stream)
 
     def _check(self, rc: int):
         if rc != 0:
@@ -187,3 +232,55 @@ class CapsLib:
         self._check(self._f(f"lcp_{sfx}")(T.ctypes.data, T.size, a.ctypes.data, b.ctypes.data, a.size,
                                           out.ctypes.data, device))
         return out
+
+
+class Shard:
+    """One rank of the multi-GPU construction (caps_sa_hip_shard_*, include/caps_sa_hip.h).
+    Pointers are raw device addresses (torch tensors' data_ptr())."""
+
+    def __init__(self, lib: CapsLib, dT_ptr: int, n: int, p: int, idx_bits: int, rank: int, world: int, stream: int = 0):
+        self.lib = lib
+        self.h = _vp(None)
+        lib._check(lib._f("shard_create")(dT_ptr, n, p, idx_bits // 8, rank, world, stream or None, ctypes.byref(self.h)))
+
+    def close(self):
+        if self.h:
+            self.lib._f("shard_destroy")(self.h)
+            self.h = _vp(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self) -> dict:
+        inf = ShardInfo()
+        self.lib._check(self.lib._f("shard_info")(self.h, ctypes.byref(inf)))
+        return inf.as_dict()
+
+    def phase1(self, d_sample_keys: int, d_sample_sa: int):
+        self.lib._check(self.lib._f("shard_phase1")(self.h, d_sample_keys or None, d_sample_sa or None))
+
+    def pivots(self, d_all_keys: int, d_all_sa: int, d_local_sizes: int):
+        self.lib._check(self.lib._f("shard_pivots")(self.h, d_all_keys, d_all_sa, d_local_sizes))
+
+    def collate(self, all_sizes: np.ndarray, d_send_keys: int, d_send_sa: int):
+        all_sizes = np.ascontiguousarray(all_sizes, dtype=np.uint64)
+        world = all_sizes.shape[0]
+        sc = np.zeros(world, dtype=np.uint64)
+        rc = np.zeros(world, dtype=np.uint64)
+        self.lib._check(self.lib._f("shard_collate")(self.h, all_sizes.ctypes.data, d_send_keys or None, d_send_sa or None,
+                                                     sc.ctypes.data, rc.ctypes.data))
+        return sc, rc
+
+    def phase2(self, d_recv_keys: int, d_recv_sa: int, dSA: int, dLCP: int):
+        self.lib._check(self.lib._f("shard_phase2")(self.h, d_recv_keys or None, d_recv_sa or None, dSA or None, dLCP or None))
+
+    def last_sa(self) -> int:
+        v = _u64(0)
+        self.lib._check(self.lib._f("shard_last_sa")(self.h, ctypes.byref(v)))
+        return v.value
+
+    def fix_first_lcp(self, prev_sa: int, dLCP: int):
+        self.lib._check(self.lib._f("shard_fix_first_lcp")(self.h, prev_sa, dLCP or None))

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "pipeline.h"
+#include "shard.h"
 
 #ifndef CAPS_API
 #error "define CAPS_API(name) before including capi_impl.h"
@@ -386,5 +387,65 @@ int CAPS_API(workspace_bytes)(uint64_t n, uint64_t subproblem_count, int idx_byt
 
 CAPS_DEFINE_WIDTH(u32, uint32_t)
 CAPS_DEFINE_WIDTH(u64, uint64_t)
+
+
+struct caps_sa_shard { std::unique_ptr<caps::ShardBase> impl; };
+
+caps_sa_shard* caps_shard_new(const void* dT, uint64_t n, uint64_t p, int idx_bytes, int rank, int world, void* stream)
+{
+    caps_sa_shard* s = new caps_sa_shard;
+    try {
+        if (idx_bytes == 4) s->impl.reset(new caps::Shard<uint32_t>(dT, n, p, rank, world, stream));
+        else s->impl.reset(new caps::Shard<uint64_t>(dT, n, p, rank, world, stream));
+    } catch (...) { delete s; throw; }
+    return s;
+}
+
+int CAPS_API(shard_create)(const void* dT, uint64_t n, uint64_t p, int idx_bytes, int rank, int world, void* stream,
+                           caps_sa_shard** out)
+{
+    if (!out || !dT || (idx_bytes != 4 && idx_bytes != 8) || world < 1 || rank < 0 || rank >= world)
+        return caps::fail(CAPS_SA_EINVAL, "bad argument");
+    if (idx_bytes == 4 && n > 0xFFFFFFFFull) return caps::fail(CAPS_SA_EINVAL, "n does not fit 32-bit indices");
+    *out = nullptr;
+    return caps::guarded([&]() -> int { *out = caps_shard_new(dT, n, p, idx_bytes, rank, world, stream); return CAPS_SA_OK; });
+}
+void CAPS_API(shard_destroy)(caps_sa_shard* s) { delete s; }
+int CAPS_API(shard_info)(const caps_sa_shard* s, caps_sa_shard_info* info)
+{
+    if (!s || !info) return caps::fail(CAPS_SA_EINVAL, "null pointer");
+    s->impl->info(info);
+    return CAPS_SA_OK;
+}
+int CAPS_API(shard_phase1)(caps_sa_shard* s, void* k, void* a)
+{
+    if (!s) return caps::fail(CAPS_SA_EINVAL, "null shard");
+    return caps::guarded([&]() -> int { s->impl->phase1(k, a); return CAPS_SA_OK; });
+}
+int CAPS_API(shard_pivots)(caps_sa_shard* s, const void* k, const void* a, void* sizes)
+{
+    if (!s || !k || !a || !sizes) return caps::fail(CAPS_SA_EINVAL, "null pointer");
+    return caps::guarded([&]() -> int { s->impl->pivots(k, a, sizes); return CAPS_SA_OK; });
+}
+int CAPS_API(shard_collate)(caps_sa_shard* s, const uint64_t* all_sizes, void* k, void* a, uint64_t* sc, uint64_t* rc)
+{
+    if (!s || !all_sizes || !sc || !rc) return caps::fail(CAPS_SA_EINVAL, "null pointer");
+    return caps::guarded([&]() -> int { s->impl->collate(all_sizes, k, a, sc, rc); return CAPS_SA_OK; });
+}
+int CAPS_API(shard_phase2)(caps_sa_shard* s, const void* k, const void* a, void* dSA, void* dLCP)
+{
+    if (!s) return caps::fail(CAPS_SA_EINVAL, "null shard");
+    return caps::guarded([&]() -> int { s->impl->phase2(k, a, dSA, dLCP); return CAPS_SA_OK; });
+}
+int CAPS_API(shard_last_sa)(caps_sa_shard* s, uint64_t* last_sa)
+{
+    if (!s || !last_sa) return caps::fail(CAPS_SA_EINVAL, "null pointer");
+    return caps::guarded([&]() -> int { *last_sa = s->impl->last_sa(); return CAPS_SA_OK; });
+}
+int CAPS_API(shard_fix_first_lcp)(caps_sa_shard* s, uint64_t prev_sa, void* dLCP)
+{
+    if (!s) return caps::fail(CAPS_SA_EINVAL, "null shard");
+    return caps::guarded([&]() -> int { s->impl->fix_first_lcp(prev_sa, dLCP); return CAPS_SA_OK; });
+}
 
 }  // extern "C"

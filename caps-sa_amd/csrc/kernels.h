@@ -255,8 +255,10 @@ GLOBAL_FN LAUNCH_BOUNDS(256) tile_map_kernel(KCTX const uint32_t* __restrict__ t
 // sorted run with its LCP array (reference: merge_sort, src/Suffix_Array.cpp:112-129,
 // called per subarray at :171-173).
 //
-// FROM_TEXT: the tile is TILE_E consecutive text positions (phase 1); keys are cut
-// from the packed text.  Otherwise (key, sa) pairs are read from in_key/in_sa.
+// FROM_TEXT: the tile is TILE_E consecutive text positions (phase 1), element i of the
+// arrays being text position text_base + i (text_base != 0 on a shard that owns a slice of
+// the subarrays); keys are cut from the packed text.  Otherwise (key, sa) pairs are read
+// from in_key/in_sa.
 // In-LDS algorithm: bottom-up merge sort where every element finds its output slot
 // by a binary search in the sibling run (rank merge): no divergent serial merge,
 // ragged runs need no padding.  LCPs are produced once, at the end, from adjacent
@@ -265,7 +267,7 @@ GLOBAL_FN LAUNCH_BOUNDS(256) tile_map_kernel(KCTX const uint32_t* __restrict__ t
 // ----------------------------------------------------------------------------------
 template <typename idx_t, int BITS, bool FROM_TEXT>
 GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) tile_sort_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
-                                                  const uint64_t* in_key, const idx_t* in_sa,
+                                                  uint64_t text_base, const uint64_t* in_key, const idx_t* in_sa,
                                                   uint64_t* out_key, idx_t* out_sa, idx_t* out_lcp)
 {
     const uint32_t b = K_BLOCK_IDX;
@@ -286,8 +288,8 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) tile_sort_kernel(KCTX SegDesc sd, const uint32_
             const uint32_t e = tid + k * TILE_NT;
             if (e < cnt) {
                 if (FROM_TEXT) {
-                    skey[e] = window64<BITS>(P, start + e);
-                    ssa[e] = (idx_t)(start + e);
+                    skey[e] = window64<BITS>(P, text_base + start + e);
+                    ssa[e] = (idx_t)(text_base + start + e);
                 } else {
                     skey[e] = in_key[start + e];
                     ssa[e] = in_sa[start + e];
@@ -593,14 +595,14 @@ GLOBAL_FN LAUNCH_BOUNDS(256) locate_kernel(KCTX const uint32_t* __restrict__ P, 
 // partition j (exclusive scan over g, cpp:340-349), sizes[j] = partition size (cpp:305-316).
 // ----------------------------------------------------------------------------------
 template <typename idx_t>
-GLOBAL_FN LAUNCH_BOUNDS(64) partition_sizes_kernel(KCTX const idx_t* __restrict__ Pm, uint32_t p,
+GLOBAL_FN LAUNCH_BOUNDS(64) partition_sizes_kernel(KCTX const idx_t* __restrict__ Pm, uint32_t G, uint32_t p,
                                                    idx_t* __restrict__ ruler, uint64_t* __restrict__ sizes)
 {
     PAR(tid) {
         const uint32_t j = K_BLOCK_IDX * K_BLOCK_DIM + tid;
         if (j < p) {
             uint64_t run = 0;
-            for (uint32_t g = 0; g < p; ++g) {
+            for (uint32_t g = 0; g < G; ++g) {                 // G sorted subarrays (all p, or a shard's slice)
                 const idx_t* row = Pm + (uint64_t)g * (p + 1);
                 ruler[(uint64_t)g * p + j] = (idx_t)run;
                 run += (uint64_t)(row[j + 1] - row[j]);
@@ -678,6 +680,38 @@ GLOBAL_FN LAUNCH_BOUNDS(256) lcp_pairs_kernel(KCTX const uint32_t* __restrict__ 
             const uint64_t x = a[i], y = b[i];
             out[i] = (idx_t)(x == y ? n - x : deep_lcp<BITS>(P, n, x, y, 0));
         }
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// Multi-GPU exchange helpers.  After the all-to-all-v a rank holds, per source
+// rank, that rank's sub-subarrays of the partitions it now owns; regroup_kernel moves run
+// d (desc[3d] = source offset, desc[3d+1] = destination offset, desc[3d+2] = length) so
+// that every partition is contiguous.  One workgroup per run.
+// ----------------------------------------------------------------------------------
+template <typename idx_t>
+GLOBAL_FN LAUNCH_BOUNDS(256) regroup_kernel(KCTX const uint64_t* __restrict__ desc, const uint64_t* __restrict__ in_key,
+                                            const idx_t* __restrict__ in_sa, uint64_t* __restrict__ out_key,
+                                            idx_t* __restrict__ out_sa)
+{
+    const uint64_t src = desc[3 * (uint64_t)K_BLOCK_IDX], dst = desc[3 * (uint64_t)K_BLOCK_IDX + 1],
+                   len = desc[3 * (uint64_t)K_BLOCK_IDX + 2];
+    PAR(tid) {
+        for (uint64_t i = tid; i < len; i += K_BLOCK_DIM) {
+            out_key[dst + i] = in_key[src + i];
+            out_sa[dst + i] = in_sa[src + i];
+        }
+    }
+}
+
+// LCP of the first suffix of a rank's slice with the last suffix of the previous
+// non-empty slice (the a11 boundary between GPUs).
+template <typename idx_t, int BITS>
+GLOBAL_FN LAUNCH_BOUNDS(64) first_lcp_kernel(KCTX const uint32_t* __restrict__ P, uint64_t n, uint64_t prev_sa,
+                                             const idx_t* __restrict__ sa, idx_t* __restrict__ lcp)
+{
+    PAR(tid) {
+        if (tid == 0 && K_BLOCK_IDX == 0) lcp[0] = (idx_t)deep_lcp<BITS>(P, n, prev_sa, (uint64_t)sa[0], 0);
     }
 }
 

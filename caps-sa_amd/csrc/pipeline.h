@@ -204,16 +204,17 @@ inline uint32_t tiles_of(uint64_t len) { return (uint32_t)((len + TILE_E - 1) / 
 template <typename idx_t, int BITS>
 ElemBuf<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, uint64_t* splits, const SegBufs& s,
                               uint32_t n_tiles, uint64_t max_len, bool from_text, ElemBuf<idx_t> cur, ElemBuf<idx_t> oth,
-                              uint64_t n_elems, uint32_t* n_passes, KernelClock* tile_clock, KernelClock* merge_clock)
+                              uint64_t n_elems, uint32_t* n_passes, KernelClock* tile_clock, KernelClock* merge_clock,
+                              uint64_t text_base = 0)
 {
     if (n_tiles == 0) return cur;
     const SegDesc sd = s.desc();
     BackendEvent t0 = be.record();
     if (from_text)
-        CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, sd, P, n, (const uint64_t*)nullptr,
+        CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, sd, P, n, text_base, (const uint64_t*)nullptr,
                     (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp);
     else
-        CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, sd, P, n, (const uint64_t*)cur.key,
+        CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, (const uint64_t*)cur.key,
                     (const idx_t*)cur.sa, cur.key, cur.sa, cur.lcp);
     BackendEvent t1 = be.record();
     if (tile_clock) { tile_clock->spans.push_back({t0, t1}); tile_clock->elems.push_back(n_elems); }
@@ -315,7 +316,7 @@ private:
             e4 = be_.record();
 
             // ---- partition sizes, offsets, collate (a9)
-            CAPS_LAUNCH((partition_sizes_kernel<idx_t>), (p + 63) / 64, 64, be_, (const idx_t*)pl_.Pm, p, pl_.ruler, pl_.sizes);
+            CAPS_LAUNCH((partition_sizes_kernel<idx_t>), (p + 63) / 64, 64, be_, (const idx_t*)pl_.Pm, p, p, pl_.ruler, pl_.sizes);
             CAPS_LAUNCH(scan_sizes_kernel, 1, 1024, be_, (const uint64_t*)pl_.sizes, p, pl_.seg2.seg_start);
             prepare_segments(pl_.seg2, n / TILE_E + p + 1);
             uint64_t out2[2];

@@ -1,0 +1,178 @@
+"""caps_sa_dist.py -- multi-GPU SA+LCP construction: one process per GPU, torch.distributed.
+
+Host driver of the sharded path.  The kernels run inside
+libcaps_sa_hip.so through the caps_sa_hip_shard_* entry points; this module only issues the
+collectives between them, with backend "nccl" (= RCCL over xGMI) on GPUs:
+
+    phase1 (local)  -> all_gather(samples)          small: p*ppp*(8+w) bytes in total
+    pivots (local)  -> all_gather(partition sizes)  p u64 per rank
+    collate (local) -> all_to_all_v(key, sa)        THE exchange: (8+w)*n*(G-1)/G bytes, direct p2p
+    phase2 (local)  -> all_gather(last SA of slice) 1 idx per rank
+    fix first LCP of the slice (local)
+
+The text is replicated; rank r ends up with the contiguous slice
+[slice_off, slice_off + slice_len) of the global SA and LCP arrays in its own HBM.
+`lib` is a CapsLib binding: the product library on GPUs; the CPU tests (gloo, world size 2)
+pass the host emulation of the same sources instead.
+"""
+from __future__ import annotations
+
+import json
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def _idx_dtype(idx_bits: int):
+    return torch.int32 if idx_bits == 32 else torch.int64
+
+
+def _all_gather_var(t: torch.Tensor, counts: list[int]) -> torch.Tensor:
+    """all_gather of per-rank tensors of different lengths (pads to the longest)."""
+    world = dist.get_world_size()
+    mx = max(counts) if counts else 0
+    pad = torch.zeros(mx, dtype=t.dtype, device=t.device)
+    pad[:t.numel()] = t
+    out = torch.empty(mx * world, dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, pad)
+    return torch.cat([out[r * mx:r * mx + counts[r]] for r in range(world)])
+
+
+def build_sharded(lib, T: torch.Tensor, p: int = 0, idx_bits: int | None = None, stream: int = 0):
+    """Collective: every rank passes the same text T (uint8 tensor on its device).
+
+    Returns (SA_slice, LCP_slice, slice_off, info dict).  SA/LCP slices are tensors on T's
+    device with the signed dtype of the same width as the unsigned indices."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n = T.numel()
+    idx_bits = idx_bits or (32 if n <= 0xFFFFFFFF else 64)
+    dt = _idx_dtype(idx_bits)
+    dev = T.device
+    sh = lib.shard(T.data_ptr(), n, p, idx_bits, rank, world, stream)
+    try:
+        inf = sh.info()
+        P = inf["p"]
+        # ---- phase 1 + samples
+        sk = torch.empty(max(inf["m_local"], 1), dtype=torch.int64, device=dev)
+        ss = torch.empty(max(inf["m_local"], 1), dtype=dt, device=dev)
+        sh.phase1(sk.data_ptr(), ss.data_ptr())
+        counts = [((r + 1) * P // world - r * P // world) * inf["ppp"] for r in range(world)]
+        all_k = _all_gather_var(sk[:inf["m_local"]], counts)
+        all_s = _all_gather_var(ss[:inf["m_local"]], counts)
+        assert all_k.numel() == inf["m_total"]
+        # ---- pivots + local partition sizes
+        sizes = torch.empty(P, dtype=torch.int64, device=dev)
+        sh.pivots(all_k.data_ptr(), all_s.data_ptr(), sizes.data_ptr())
+        all_sizes = torch.empty(world * P, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(all_sizes, sizes)
+        all_sizes_h = all_sizes.cpu().numpy().astype(np.uint64).reshape(world, P)
+        # ---- collate into destination-major send buffers
+        send_k = torch.empty(max(inf["local_elems"], 1), dtype=torch.int64, device=dev)
+        send_s = torch.empty(max(inf["local_elems"], 1), dtype=dt, device=dev)
+        sc, rc = sh.collate(all_sizes_h, send_k.data_ptr(), send_s.data_ptr())
+        sc = [int(x) for x in sc]
+        rc = [int(x) for x in rc]
+        total = sum(rc)
+        # ---- THE exchange (RCCL all-to-all-v over xGMI on GPUs)
+        recv_k = torch.empty(max(total, 1), dtype=torch.int64, device=dev)
+        recv_s = torch.empty(max(total, 1), dtype=dt, device=dev)
+        t0 = time.perf_counter()
+        dist.all_to_all_single(recv_k[:total], send_k[:sum(sc)], output_split_sizes=rc, input_split_sizes=sc)
+        dist.all_to_all_single(recv_s[:total], send_s[:sum(sc)], output_split_sizes=rc, input_split_sizes=sc)
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        ms_exchange = 1e3 * (time.perf_counter() - t0)
+        del send_k, send_s
+        # ---- phase 2
+        SA = torch.empty(max(total, 1), dtype=dt, device=dev)
+        LCP = torch.empty(max(total, 1), dtype=dt, device=dev)
+        sh.phase2(recv_k.data_ptr(), recv_s.data_ptr(), SA.data_ptr(), LCP.data_ptr())
+        # ---- boundary LCP between consecutive slices
+        last = torch.tensor([sh.last_sa() - (1 << 64) if sh.last_sa() >= (1 << 63) else sh.last_sa()], dtype=torch.int64,
+                            device=dev)
+        lasts = torch.empty(world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(lasts, last)
+        prev = 0xFFFFFFFFFFFFFFFF
+        for r in range(rank - 1, -1, -1):
+            v = int(lasts[r].item())
+            if v != -1:
+                prev = v
+                break
+        sh.fix_first_lcp(prev, LCP.data_ptr())
+        info = sh.info()
+        info["ms_exchange"] = ms_exchange
+        info["send_counts"] = sc
+        info["recv_counts"] = rc
+        return SA[:total], LCP[:total], info["slice_off"], info
+    finally:
+        sh.close()
+
+
+def bench_main(args, rank: int, local_rank: int, world: int):
+    """bench.py's N > 1 leg: same C3 text on every GPU, strong scaling."""
+    import caps_sa_amd
+    from bench import WORKLOADS, make_text
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist.init_process_group("nccl", device_id=dev)
+    L = caps_sa_amd.lib()
+    n_bases, desc = WORKLOADS[args.workload]
+    if args.bases:
+        n_bases, desc = args.bases, f"custom: {args.bases} random DNA bases + remapped newline, p={args.p}"
+    n = n_bases + 1
+    idx_bits = 32 if n <= 0xFFFFFFFF else 64
+    T = make_text(torch, n_bases, args.seed, dev)          # identical on every rank (same seed)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        return build_sharded(L, T, args.p, idx_bits, stream)
+
+    for _ in range(args.warmup):
+        out = step()
+        del out
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        SA, LCP, off, info = step()
+    dist.barrier()
+    torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    errs = None
+    if args.verify:
+        errs = verify_sharded(L, T, SA, LCP, off, idx_bits)
+    if rank == 0:
+        out = {
+            "metric": "suffixes/sec (SA+LCP build)", "value": n / (elapsed / args.steps), "unit": "suffixes/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": f"u{idx_bits}",
+            "data": "synthetic",
+            "config": {"workload": desc, "n": n, "subproblems": info["p"], "bits_per_char": info["bits_per_char"],
+                       "parallelism": f"{world} GPUs: text replicated, subarrays and partitions sharded, "
+                                      "one RCCL all-to-all-v"},
+            "rank0_ms": {k: info[k] for k in ("ms_phase1", "ms_pivots", "ms_collate", "ms_exchange", "ms_phase2")},
+            "roofline": None, "cpu_baseline": None,
+        }
+        if errs is not None:
+            out["verify_errors"] = errs
+        print(json.dumps(out))
+    dist.destroy_process_group()
+
+
+def verify_sharded(lib, T, SA, LCP, off, idx_bits) -> int:
+    """Gathers the slices on every rank and runs the device verifier (testing aid)."""
+    world = dist.get_world_size()
+    n = T.numel()
+    cnt = torch.tensor([SA.numel()], dtype=torch.int64, device=T.device)
+    cnts = torch.empty(world, dtype=torch.int64, device=T.device)
+    dist.all_gather_into_tensor(cnts, cnt)
+    counts = [int(x) for x in cnts.tolist()]
+    SA_all = _all_gather_var(SA, counts)
+    LCP_all = _all_gather_var(LCP, counts)
+    assert SA_all.numel() == n
+    return lib.verify_device(T.data_ptr(), n, SA_all.data_ptr(), LCP_all.data_ptr(), idx_bits=idx_bits)

@@ -136,6 +136,51 @@ int caps_sa_hip_lcp_u32(const char* T, uint64_t n, const uint32_t* a, const uint
 int caps_sa_hip_lcp_u64(const char* T, uint64_t n, const uint64_t* a, const uint64_t* b, uint64_t cnt,
                         uint64_t* out, int device);
 
+
+/* ---- multi-GPU: one shard per process/GPU ----------------------------
+ * The reference has no distributed mode; these entry points cut construct() at its one
+ * exchange step (partition_sub_subarrays, src/Suffix_Array.cpp:300-368) so that a host
+ * driver can run the collectives between them (caps_sa_dist.py: torch.distributed / RCCL):
+ *
+ *   shard_create -> shard_phase1 -> [all_gather samples] -> shard_pivots
+ *   -> [all_gather partition sizes] -> shard_collate -> [all_to_all_v of (key, sa)]
+ *   -> shard_phase2 -> [all_gather last SA] -> shard_fix_first_lcp
+ *
+ * The text is replicated (dT: n bytes on this rank's device).  Rank r sorts subarrays
+ * [r*p/world, (r+1)*p/world) and ends up owning a contiguous slice of the global SA/LCP.
+ * All d_* pointers are device pointers on the rank's device; idx_bytes is 4 or 8. */
+typedef struct caps_sa_shard caps_sa_shard;
+typedef struct caps_sa_shard_info {
+    uint64_t n;
+    uint32_t p, ppp, rank, world;
+    uint32_t g0, g1;               /* subarrays sorted by this rank */
+    uint32_t bits_per_char, idx_bytes;
+    uint32_t part_lo, part_hi;     /* partitions owned after shard_collate */
+    uint64_t local_elems;          /* elements of this rank's subarrays = capacity of the send buffers */
+    uint64_t m_local, m_total;     /* samples of this rank / of all ranks */
+    uint64_t recv_total;           /* elements of the owned partitions (after shard_collate) */
+    uint64_t slice_off;            /* position of the rank's slice in the global SA/LCP */
+    double ms_phase1, ms_pivots, ms_collate, ms_phase2;
+} caps_sa_shard_info;
+
+int caps_sa_hip_shard_create(const void* dT, uint64_t n, uint64_t subproblem_count, int idx_bytes, int rank, int world,
+                             void* hip_stream, caps_sa_shard** out);
+void caps_sa_hip_shard_destroy(caps_sa_shard* s);
+int caps_sa_hip_shard_info(const caps_sa_shard* s, caps_sa_shard_info* info);
+/* d_sample_keys: u64[m_local], d_sample_sa: idx[m_local] */
+int caps_sa_hip_shard_phase1(caps_sa_shard* s, void* d_sample_keys, void* d_sample_sa);
+/* d_all_keys: u64[m_total], d_all_sa: idx[m_total] (any order); d_local_sizes: u64[p] out */
+int caps_sa_hip_shard_pivots(caps_sa_shard* s, const void* d_all_keys, const void* d_all_sa, void* d_local_sizes);
+/* all_sizes: HOST u64[world][p]; d_send_*: [local_elems]; send_counts/recv_counts: HOST u64[world] out */
+int caps_sa_hip_shard_collate(caps_sa_shard* s, const uint64_t* all_sizes, void* d_send_keys, void* d_send_sa,
+                              uint64_t* send_counts, uint64_t* recv_counts);
+/* d_recv_*: [recv_total], source-rank-major; dSA/dLCP: idx[recv_total] out */
+int caps_sa_hip_shard_phase2(caps_sa_shard* s, const void* d_recv_keys, const void* d_recv_sa, void* dSA, void* dLCP);
+/* last SA value of the slice (UINT64_MAX when the slice is empty) */
+int caps_sa_hip_shard_last_sa(caps_sa_shard* s, uint64_t* last_sa);
+/* prev_sa: last SA value of the nearest non-empty lower rank (UINT64_MAX: none) */
+int caps_sa_hip_shard_fix_first_lcp(caps_sa_shard* s, uint64_t prev_sa, void* dLCP);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,55 @@
+"""Worker of tests/test_dist_gloo.py: runs the sharded driver on CPU tensors over gloo with
+the host emulation of the kernels, gathers the slices and compares with the oracle."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    import caps_sa_dist
+    import oracle as O
+    from emul_util import emul
+    E = emul()
+    cases = []
+    rs = np.random.RandomState(11)
+    dna = np.frombuffer(b"ACGT", dtype=np.uint8)
+    cases.append((rs.choice(dna, size=150_001), 12, 32))
+    cases.append((rs.choice(dna, size=40_000), 7, 32))                      # p not divisible by world
+    cases.append((rs.choice(np.frombuffer(b"abcdefgh", dtype=np.uint8), size=60_000), 16, 64))
+    cases.append((np.tile(rs.choice(dna, size=37), 300), 5, 32))            # deep LCPs, skewed partitions
+    cases.append((rs.choice(dna, size=100), 0, 32))                          # p_eff = 6
+    ok = True
+    for T_np, p, bits in cases:
+        T = torch.from_numpy(T_np.copy())
+        SA, LCP, off, info = caps_sa_dist.build_sharded(E, T, p, bits)
+        cnt = torch.tensor([SA.numel()], dtype=torch.int64)
+        cnts = torch.empty(world, dtype=torch.int64)
+        dist.all_gather_into_tensor(cnts, cnt)
+        counts = [int(x) for x in cnts.tolist()]
+        offs = torch.empty(world, dtype=torch.int64)
+        dist.all_gather_into_tensor(offs, torch.tensor([off], dtype=torch.int64))
+        assert offs.tolist() == [sum(counts[:r]) for r in range(world)], (offs.tolist(), counts)
+        SA_all = caps_sa_dist._all_gather_var(SA, counts).numpy()
+        LCP_all = caps_sa_dist._all_gather_var(LCP, counts).numpy()
+        dt = np.uint32 if bits == 32 else np.uint64
+        SAo, LCPo = O.naive_sa_lcp(T_np, idx_bits=bits)
+        good = np.array_equal(SA_all.view(dt), SAo) and np.array_equal(LCP_all.view(dt), LCPo)
+        if rank == 0:
+            print(f"case n={T_np.size} p={p} bits={bits} counts={counts} {'OK' if good else 'MISMATCH'}", flush=True)
+        ok = ok and good
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

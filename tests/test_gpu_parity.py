@@ -187,3 +187,32 @@ def test_c3_3g_device_resident(L):
     """BASELINE headline size: 3e9 bases (+1), u32, p = 8000.  Property check on the device."""
     st = _device_build_and_verify(L, 3_000_000_001, 8000, 42)
     assert st["p_eff"] == 8000
+
+
+def test_sharded_driver_single_rank_rccl(L):
+    """The multi-GPU driver (caps_sa_dist.py) with the real kernels and backend nccl (RCCL) at
+    world size 1 -- all a 1-GPU box allows; world sizes 2 and 3 run on CPU over gloo
+    (tests/test_dist_gloo.py).  Checked with the device verifier and against the 1-GPU build."""
+    import os
+    import torch
+    import torch.distributed as dist
+    import caps_sa_dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        n = 20_000_001
+        g = torch.Generator(device="cuda")
+        g.manual_seed(3)
+        lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda")
+        T = lut[torch.randint(0, 4, (n,), device="cuda", generator=g, dtype=torch.int64)]
+        SA, LCP, off, info = caps_sa_dist.build_sharded(L, T, 500, 32)
+        assert off == 0 and SA.numel() == n
+        assert L.verify_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr()) == 0
+        SA1 = torch.empty(n, dtype=torch.int32, device="cuda")
+        LCP1 = torch.empty(n, dtype=torch.int32, device="cuda")
+        L.build_device(T.data_ptr(), n, SA1.data_ptr(), LCP1.data_ptr(), p=500)
+        assert torch.equal(SA, SA1) and torch.equal(LCP, LCP1)
+    finally:
+        dist.destroy_process_group()
