@@ -76,7 +76,7 @@ SHARD_EXPORTS = ["shard_create", "shard_destroy", "shard_info", "shard_phase1", 
 EXPORTS = ["device_count", "last_error", "version", "workspace_bytes"] + SHARD_EXPORTS + [
     f"{name}_{sfx}"
     for sfx in ("u32", "u64")
-    for name in ("build", "build_device", "verify_device", "sort_suffixes", "merge", "upper_bound", "lcp")
+    for name in ("build", "build_device", "verify_device", "sort_suffixes", "sort_segments", "merge", "upper_bound", "lcp")
 ]
 
 
@@ -111,6 +111,8 @@ class CapsLib:
             f(f"verify_device_{sfx}").argtypes = [_vp, _u64, _vp, _vp, _vp, ctypes.POINTER(_u64)]
             f(f"sort_suffixes_{sfx}").restype = _ci
             f(f"sort_suffixes_{sfx}").argtypes = [_vp, _u64, _vp, _u64, _vp, _vp, _ci]
+            f(f"sort_segments_{sfx}").restype = _ci
+            f(f"sort_segments_{sfx}").argtypes = [_vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp, _ci]
             f(f"merge_{sfx}").restype = _ci
             f(f"merge_{sfx}").argtypes = [_vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp, _vp, _vp, _ci]
             f(f"upper_bound_{sfx}").restype = _ci
@@ -201,6 +203,17 @@ class CapsLib:
         out_lcp = np.empty_like(idx)
         self._check(self._f(f"sort_suffixes_{sfx}")(T.ctypes.data, T.size, idx.ctypes.data, idx.size,
                                                     out_sa.ctypes.data, out_lcp.ctypes.data, device))
+        return out_sa, out_lcp
+
+    def sort_segments(self, T, idx, seg_start, idx_bits: int = 32, device: int = 0):
+        T = self._text(T)
+        sfx, dt = _sfx(idx_bits)
+        idx = np.ascontiguousarray(idx, dtype=dt)
+        seg = np.ascontiguousarray(seg_start, dtype=np.uint64)
+        out_sa = np.empty_like(idx)
+        out_lcp = np.empty_like(idx)
+        self._check(self._f(f"sort_segments_{sfx}")(T.ctypes.data, T.size, idx.ctypes.data, idx.size, seg.ctypes.data,
+                                                    seg.size - 1, out_sa.ctypes.data, out_lcp.ctypes.data, device))
         return out_sa, out_lcp
 
     def merge(self, T, X, Y, LX, LY, idx_bits: int = 32, device: int = 0):

@@ -218,20 +218,82 @@ int sort_suffixes(const char* T, uint64_t n, const idx_t* idx, uint64_t cnt, idx
         DevAllocs da(be);
         DevText t = upload_text(be, da, T, n);
         ElemBuf<idx_t> a = elem_buf<idx_t>(da, cnt), b = elem_buf<idx_t>(da, cnt);
-        uint64_t* splits = da.get<uint64_t>(tiles_of(cnt) + 2);
+        TileDesc* desc = da.get<TileDesc>(tiles_of(cnt) + 2);
+        idx_t* osa = da.get<idx_t>(cnt);
+        idx_t* olcp = da.get<idx_t>(cnt);
         be.h2d(a.sa, idx, cnt * sizeof(idx_t));
         SegBufs s = one_segment<idx_t>(be, da, cnt);
-        ElemBuf<idx_t> r;
         const uint32_t g = (uint32_t)((cnt + 255) / 256);
         if (t.bits == 2) {
             CAPS_LAUNCH((make_keys_kernel<idx_t, 2>), g, 256, be, (const uint32_t*)t.P, (const idx_t*)a.sa, cnt, a.key);
-            r = segmented_sort<idx_t, 2>(be, t.P, n, splits, s, tiles_of(cnt), cnt, false, a, b, cnt, nullptr, nullptr, nullptr);
+            SortResult<idx_t> r = segmented_sort<idx_t, 2>(be, t.P, n, desc, s, tiles_of(cnt), cnt, false, a, b, cnt, true, false,
+                                                           nullptr, nullptr);
+            finalize<idx_t, 2>(be, t.P, n, s, tiles_of(cnt), r, osa, olcp);
         } else {
             CAPS_LAUNCH((make_keys_kernel<idx_t, 8>), g, 256, be, (const uint32_t*)t.P, (const idx_t*)a.sa, cnt, a.key);
-            r = segmented_sort<idx_t, 8>(be, t.P, n, splits, s, tiles_of(cnt), cnt, false, a, b, cnt, nullptr, nullptr, nullptr);
+            SortResult<idx_t> r = segmented_sort<idx_t, 8>(be, t.P, n, desc, s, tiles_of(cnt), cnt, false, a, b, cnt, true, false,
+                                                           nullptr, nullptr);
+            finalize<idx_t, 8>(be, t.P, n, s, tiles_of(cnt), r, osa, olcp);
         }
-        be.d2h(out_sa, r.sa, cnt * sizeof(idx_t));
-        be.d2h(out_lcp, r.lcp, cnt * sizeof(idx_t));
+        be.d2h(out_sa, osa, cnt * sizeof(idx_t));
+        be.d2h(out_lcp, olcp, cnt * sizeof(idx_t));
+        be.sync();
+        return CAPS_SA_OK;
+    });
+}
+
+// Independent sorts of consecutive segments of a suffix list (the shape of phase 2:
+// sort_partition over every partition, src/Suffix_Array.cpp:388-404), with finished segments
+// sitting out later passes.  out_lcp at a segment head = lcp with the last suffix of the
+// previous non-empty segment (what compute_partition_boundary_lcp produces, cpp:431-447).
+template <typename idx_t>
+int sort_segments(const char* T, uint64_t n, const idx_t* idx, uint64_t cnt, const uint64_t* seg_start, uint64_t G,
+                  idx_t* out_sa, idx_t* out_lcp, int device)
+{
+    if (int rc = check_common<idx_t>(T, n, 0)) return rc;
+    if (cnt == 0) return CAPS_SA_OK;
+    if (!idx || !out_sa || !out_lcp || !seg_start || G == 0 || G > 0x7fffffffull) return fail(CAPS_SA_EINVAL, "bad argument");
+    if (seg_start[0] != 0 || seg_start[G] != cnt) return fail(CAPS_SA_EINVAL, "segments must cover [0, cnt)");
+    uint64_t max_len = 0, n_tiles = 0;
+    for (uint64_t g = 0; g < G; ++g) {
+        if (seg_start[g + 1] < seg_start[g]) return fail(CAPS_SA_EINVAL, "segment offsets must be non-decreasing");
+        const uint64_t len = seg_start[g + 1] - seg_start[g];
+        max_len = len > max_len ? len : max_len;
+        n_tiles += tiles_of(len);
+    }
+    if (int rc = check_positions(idx, cnt, n, "suffix position out of range")) return rc;
+    if (int rc = set_device(device)) return rc;
+    return guarded([&]() -> int {
+        Backend be(nullptr);
+        DevAllocs da(be);
+        DevText t = upload_text(be, da, T, n);
+        ElemBuf<idx_t> a = elem_buf<idx_t>(da, cnt), b = elem_buf<idx_t>(da, cnt);
+        TileDesc* desc = da.get<TileDesc>(n_tiles + 2);
+        idx_t* osa = da.get<idx_t>(cnt);
+        idx_t* olcp = da.get<idx_t>(cnt);
+        SegBufs s;
+        s.G = (uint32_t)G;
+        s.seg_start = da.get<uint64_t>(G + 1);
+        s.tile_off = da.get<uint32_t>(G + 1);
+        s.tile_seg = da.get<uint32_t>(n_tiles + 2);
+        s.out2 = da.get<uint64_t>(2);
+        be.h2d(a.sa, idx, cnt * sizeof(idx_t));
+        be.h2d(s.seg_start, seg_start, (G + 1) * sizeof(uint64_t));
+        prepare_segments(be, s, n_tiles);
+        const uint32_t g = (uint32_t)((cnt + 255) / 256);
+        if (t.bits == 2) {
+            CAPS_LAUNCH((make_keys_kernel<idx_t, 2>), g, 256, be, (const uint32_t*)t.P, (const idx_t*)a.sa, cnt, a.key);
+            SortResult<idx_t> r = segmented_sort<idx_t, 2>(be, t.P, n, desc, s, (uint32_t)n_tiles, max_len, false, a, b, cnt, true,
+                                                           true, nullptr, nullptr);
+            finalize<idx_t, 2>(be, t.P, n, s, (uint32_t)n_tiles, r, osa, olcp);
+        } else {
+            CAPS_LAUNCH((make_keys_kernel<idx_t, 8>), g, 256, be, (const uint32_t*)t.P, (const idx_t*)a.sa, cnt, a.key);
+            SortResult<idx_t> r = segmented_sort<idx_t, 8>(be, t.P, n, desc, s, (uint32_t)n_tiles, max_len, false, a, b, cnt, true,
+                                                           true, nullptr, nullptr);
+            finalize<idx_t, 8>(be, t.P, n, s, (uint32_t)n_tiles, r, osa, olcp);
+        }
+        be.d2h(out_sa, osa, cnt * sizeof(idx_t));
+        be.d2h(out_lcp, olcp, cnt * sizeof(idx_t));
         be.sync();
         return CAPS_SA_OK;
     });
@@ -253,26 +315,28 @@ int merge_runs(const char* T, uint64_t n, const idx_t* X, uint64_t len_x, const 
         DevAllocs da(be);
         DevText t = upload_text(be, da, T, n);
         ElemBuf<idx_t> a = elem_buf<idx_t>(da, cnt), b = elem_buf<idx_t>(da, cnt);
-        uint64_t* splits = da.get<uint64_t>(tiles_of(cnt) + 2);
+        TileDesc* desc = da.get<TileDesc>(tiles_of(cnt) + 2);
         be.h2d(a.sa, X, len_x * sizeof(idx_t));
         be.h2d(a.sa + len_x, Y, len_y * sizeof(idx_t));
-        be.h2d(a.lcp, LX, len_x * sizeof(idx_t));
-        be.h2d(a.lcp + len_x, LY, len_y * sizeof(idx_t));
+        // LX / LY are accepted for signature parity with the reference's merge; the kernel
+        // rebuilds the LCPs of the merged run from the keys (kernels.h, "LCPs").
+        (void)LX; (void)LY;
         SegBufs s = one_segment<idx_t>(be, da, cnt);
         const SegDesc sd = s.desc();
         const uint32_t nt = tiles_of(cnt), g = (uint32_t)((cnt + 255) / 256);
+        const uint32_t pg = nt < be.persistent_blocks() ? nt : be.persistent_blocks();
         if (t.bits == 2) {
             CAPS_LAUNCH((make_keys_kernel<idx_t, 2>), g, 256, be, (const uint32_t*)t.P, (const idx_t*)a.sa, cnt, a.key);
             CAPS_LAUNCH((merge_partition_kernel<idx_t, 2>), (nt + 255) / 256, 256, be, sd, (const uint32_t*)t.P, n, (uint64_t)TILE_E,
-                        len_x, (const uint64_t*)a.key, (const idx_t*)a.sa, splits);
-            CAPS_LAUNCH((merge_pass_kernel<idx_t, 2>), nt, TILE_NT, be, sd, (const uint32_t*)t.P, n, (uint64_t)TILE_E, len_x,
-                        (const uint64_t*)splits, (const uint64_t*)a.key, (const idx_t*)a.sa, (const idx_t*)a.lcp, b.key, b.sa, b.lcp);
+                        len_x, 0u, 1u, (const uint64_t*)a.key, (const idx_t*)a.sa, desc, (uint64_t*)nullptr);
+            CAPS_LAUNCH((merge_pass_kernel<idx_t, 2>), pg, TILE_NT, be, (const TileDesc*)desc, nt, (const uint32_t*)t.P, n,
+                        (const uint64_t*)a.key, (const idx_t*)a.sa, b.key, b.sa, b.lcp);
         } else {
             CAPS_LAUNCH((make_keys_kernel<idx_t, 8>), g, 256, be, (const uint32_t*)t.P, (const idx_t*)a.sa, cnt, a.key);
             CAPS_LAUNCH((merge_partition_kernel<idx_t, 8>), (nt + 255) / 256, 256, be, sd, (const uint32_t*)t.P, n, (uint64_t)TILE_E,
-                        len_x, (const uint64_t*)a.key, (const idx_t*)a.sa, splits);
-            CAPS_LAUNCH((merge_pass_kernel<idx_t, 8>), nt, TILE_NT, be, sd, (const uint32_t*)t.P, n, (uint64_t)TILE_E, len_x,
-                        (const uint64_t*)splits, (const uint64_t*)a.key, (const idx_t*)a.sa, (const idx_t*)a.lcp, b.key, b.sa, b.lcp);
+                        len_x, 0u, 1u, (const uint64_t*)a.key, (const idx_t*)a.sa, desc, (uint64_t*)nullptr);
+            CAPS_LAUNCH((merge_pass_kernel<idx_t, 8>), pg, TILE_NT, be, (const TileDesc*)desc, nt, (const uint32_t*)t.P, n,
+                        (const uint64_t*)a.key, (const idx_t*)a.sa, b.key, b.sa, b.lcp);
         }
         be.d2h(Z, b.sa, cnt * sizeof(idx_t));
         be.d2h(LZ, b.lcp, cnt * sizeof(idx_t));
@@ -376,6 +440,9 @@ int CAPS_API(workspace_bytes)(uint64_t n, uint64_t subproblem_count, int idx_byt
     { return caps::verify_device<IDX>(dT, n, dSA, dLCP, stream, n_errors); }                                               \
     int CAPS_API(sort_suffixes_##SFX)(const char* T, uint64_t n, const IDX* idx, uint64_t cnt, IDX* osa, IDX* olcp, int d) \
     { return caps::sort_suffixes<IDX>(T, n, idx, cnt, osa, olcp, d); }                                                     \
+    int CAPS_API(sort_segments_##SFX)(const char* T, uint64_t n, const IDX* idx, uint64_t cnt, const uint64_t* seg,        \
+                                      uint64_t G, IDX* osa, IDX* olcp, int d)                                              \
+    { return caps::sort_segments<IDX>(T, n, idx, cnt, seg, G, osa, olcp, d); }                                             \
     int CAPS_API(merge_##SFX)(const char* T, uint64_t n, const IDX* X, uint64_t lx, const IDX* Y, uint64_t ly,             \
                               const IDX* LX, const IDX* LY, IDX* Z, IDX* LZ, int d)                                        \
     { return caps::merge_runs<IDX>(T, n, X, lx, Y, ly, LX, LY, Z, LZ, d); }                                                \

@@ -64,6 +64,17 @@ public:
     void d2h(void* h, const void* d, size_t bytes) { if (bytes) CAPS_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, stream)); }
     void d2d(void* d, const void* s, size_t bytes) { if (bytes) CAPS_HIP(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, stream)); }
     void sync() { CAPS_HIP(hipStreamSynchronize(stream)); }
+    // Grid of the persistent kernels: two 1024-thread workgroups per CU (LDS and thread limits).
+    uint32_t persistent_blocks()
+    {
+        if (!pblocks_) {
+            int dev = 0, cus = 0;
+            CAPS_HIP(hipGetDevice(&dev));
+            CAPS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+            pblocks_ = (uint32_t)(cus > 0 ? cus : 256) * 2;
+        }
+        return pblocks_;
+    }
     void check_launch(const char* name)
     {
         hipError_t e = hipGetLastError();
@@ -72,6 +83,7 @@ public:
 
 private:
     std::vector<hipEvent_t> pool_;
+    uint32_t pblocks_ = 0;
 };
 
 }  // namespace caps

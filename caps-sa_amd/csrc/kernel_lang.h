@@ -41,6 +41,7 @@ namespace caps { struct EmulCtx { uint32_t block_idx, grid_dim, block_dim; }; }
 #define UNROLL
 #define ATOMIC_OR_U32(ptr, v) (*(ptr) |= (v))
 #define ATOMIC_ADD_U64(ptr, v) (*(ptr) += (v))
+#define ATOMIC_ADD_LDS_U64(ptr, v) (*(ptr) += (v))
 #define ATOMIC_MAX_U64(ptr, v) (*(ptr) = std::max<uint64_t>(*(ptr), (v)))
 static inline int caps_clz64(uint64_t x) { return __builtin_clzll(x); }
 static inline uint32_t caps_bswap32(uint32_t x) { return __builtin_bswap32(x); }
@@ -63,6 +64,7 @@ static inline uint32_t caps_bswap32(uint32_t x) { return __builtin_bswap32(x); }
 #define UNROLL _Pragma("unroll")
 #define ATOMIC_OR_U32(ptr, v) atomicOr((ptr), (v))
 #define ATOMIC_ADD_U64(ptr, v) atomicAdd((unsigned long long*)(ptr), (unsigned long long)(v))
+#define ATOMIC_ADD_LDS_U64(ptr, v) atomicAdd((unsigned long long*)(ptr), (unsigned long long)(v))
 #define ATOMIC_MAX_U64(ptr, v) atomicMax((unsigned long long*)(ptr), (unsigned long long)(v))
 static __host__ __device__ __forceinline__ int caps_clz64(uint64_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)

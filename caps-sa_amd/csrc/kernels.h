@@ -12,12 +12,12 @@
 //   a9 partition_sub_subarrays                -> partition_sizes_kernel, scan_sizes_kernel,
 //                                                collate_kernel
 //   a10 merge_sub_subarrays / sort_partition  -> tile_sort_kernel + merge passes per partition
-//   a11 compute_partition_boundary_lcp        -> boundary_lcp_kernel
+//   a11 compute_partition_boundary_lcp        -> finalize_kernel (segment-head LCPs while gathering SA/LCP)
 //
 // Data layout in HBM: struct-of-arrays per element -- key (u64, first 64/BITS chars of
-// the suffix), sa (idx_t, text position), lcp (idx_t, lcp with the predecessor in the
-// same sorted run; 0 for a run head, like the reference's convention at
-// src/Suffix_Array.cpp:117-118,354-356).  A "segment" is an independent sort problem
+// the suffix), sa (idx_t, text position), and -- written only by the sort step that
+// completes a segment -- lcp (idx_t, lcp with the predecessor in the sorted segment; 0 for
+// the segment head, the reference's convention at src/Suffix_Array.cpp:117-118,354-356).  A "segment" is an independent sort problem
 // (a subarray in phase 1, the sample set, a partition in phase 2); segments are
 // described by seg_start[G+1] and are cut into tiles of TILE_E elements aligned to the
 // segment start.
@@ -267,14 +267,18 @@ GLOBAL_FN LAUNCH_BOUNDS(256) tile_map_kernel(KCTX const uint32_t* __restrict__ t
 // ----------------------------------------------------------------------------------
 template <typename idx_t, int BITS, bool FROM_TEXT>
 GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) tile_sort_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
-                                                  uint64_t text_base, const uint64_t* in_key, const idx_t* in_sa,
-                                                  uint64_t* out_key, idx_t* out_sa, idx_t* out_lcp)
+                                                  uint64_t text_base, uint32_t lcp_mode, const uint64_t* in_key,
+                                                  const idx_t* in_sa, uint64_t* out_key, idx_t* out_sa, idx_t* out_lcp)
 {
     const uint32_t b = K_BLOCK_IDX;
     if (b >= sd.tile_off[sd.G]) return;
     const TileInfo t = tile_info(sd, b);
     const uint64_t start = t.s0 + (uint64_t)t.tl * TILE_E;
     const uint32_t cnt = (uint32_t)(t.s1 - start < TILE_E ? t.s1 - start : TILE_E);
+
+    // LCPs are only needed from the sort that completes a segment: lcp_mode 0 = never,
+    // 1 = when the whole segment is this tile (otherwise its final merge pass emits them).
+    const bool with_lcp = lcp_mode != 0 && (t.s1 - t.s0) <= TILE_E;
 
     SHARED_ARRAY(uint64_t, skey, TILE_E);
     SHARED_ARRAY(idx_t, ssa, TILE_E);
@@ -346,11 +350,13 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) tile_sort_kernel(KCTX SegDesc sd, const uint32_
             if (e < cnt) {
                 const uint64_t key = skey[e];
                 const idx_t sa = ssa[e];
-                uint64_t l = 0;
-                if (e) l = pair_lcp<BITS>(P, n, skey[e - 1], (uint64_t)ssa[e - 1], key, (uint64_t)sa);
                 out_key[start + e] = key;
                 out_sa[start + e] = sa;
-                out_lcp[start + e] = (idx_t)l;
+                if (with_lcp) {
+                    uint64_t l = 0;
+                    if (e) l = pair_lcp<BITS>(P, n, skey[e - 1], (uint64_t)ssa[e - 1], key, (uint64_t)sa);
+                    out_lcp[start + e] = (idx_t)l;
+                }
             }
         }
     }
@@ -360,147 +366,268 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) tile_sort_kernel(KCTX SegDesc sd, const uint32_
 // a3: LCP-merge of run pairs (reference: merge, src/Suffix_Array.cpp:48-109).
 //
 // A pass merges, inside every segment, runs (2q, 2q+1) of length R into runs of 2R.
-// The output of a pair is cut into tiles of TILE_E; merge_partition_kernel finds, per
-// tile, how many elements of run A precede the tile's first output ("merge path"
-// split, full suffix comparator); merge_pass_kernel stages the tile's two input
-// pieces (key, sa, lcp) in LDS, ranks every element in the other piece by binary
-// search, and emits the merged tile with its LCPs, coalesced.
+// The output of a pair is cut into tiles of TILE_E outputs.
 //
-// LCP of an output element z taken from A with rank r in B:
-//     LCP_z = max( lcp_A[z] , lcp(z, B[r-1]) )
-// because its predecessor in the output is the larger of its two predecessors, and
-// for x <= y <= z: lcp(z, y) >= lcp(z, x).  lcp(z, B[r-1]) comes from the two keys
-// (text only when the keys are equal).  This is the quantity the reference's merge
-// tracks in `m` / `l_x` (cpp:59-79); the head of a merged run keeps LCP 0 (cpp:117).
+//  merge_partition_kernel  one thread per tile: "merge path" splits of the tile's first
+//      and last output diagonal (binary search with the full suffix comparator) -> a
+//      48-byte TileDesc {source pieces, destination, flags}.  Segments that are already
+//      a single run (len <= R) are marked inactive when skip_finished is set: they stay
+//      in the buffer their last pass wrote (parity of passes_for(len)), so skewed
+//      partitions cost passes only for their own tiles.
+//  merge_pass_kernel       persistent workgroups walk the tiles.  Per tile: the two input
+//      pieces (key, sa) are staged in LDS, every element finds its output slot by a
+//      binary search in the other piece (rank merge: no divergent serial merge), the
+//      merged tile is written back coalesced.  The global loads of the NEXT tile are
+//      issued into registers before the rank phase, so HBM latency overlaps the LDS work.
+//
+// LCPs: keys make the reference's LCP bookkeeping (`m`, `l_x`, cpp:59-79) unnecessary for
+// ordering, so intermediate passes move no LCPs at all.  The pass that completes a segment
+// (flag FINAL) emits them: LCP_z[k] = lcp(z[k-1], z[k]) from the adjacent keys of the merged
+// tile (text only when the keys are equal); the predecessor of the tile's first output is
+// the larger of the two elements preceding the pieces; a segment head keeps 0 (cpp:117).
 // ----------------------------------------------------------------------------------
+struct TileDesc {
+    uint64_t srcA, srcB, dst;   // element offsets of the two input pieces and of the output
+    uint32_t na, nb;            // piece lengths (na + nb <= TILE_E; 0/0 = inactive tile)
+    uint32_t flags;             // TD_*
+    uint32_t pad;
+};
+constexpr uint32_t TD_HALO_A = 1, TD_HALO_B = 2, TD_FINAL = 4;
+
+// Number of merge passes a segment of `len` elements takes (runs E, 2E, 4E, ... < len).
+HD uint32_t passes_for(uint64_t len)
+{
+    const uint64_t tiles = (len + TILE_E - 1) / TILE_E;
+    return tiles <= 1 ? 0u : (uint32_t)(64 - caps_clz64(tiles - 1));
+}
+
+template <typename idx_t, int BITS>
+DEV_INLINE uint64_t merge_path_split(const uint32_t* __restrict__ P, uint64_t n, const uint64_t* __restrict__ key,
+                                     const idx_t* __restrict__ sa, uint64_t A, uint64_t la, uint64_t B, uint64_t lb, uint64_t d)
+{
+    uint64_t lo = d > lb ? d - lb : 0;
+    uint64_t hi = d < la ? d : la;
+    while (lo < hi) {                                      // #elements of A among the first d outputs
+        const uint64_t mid = (lo + hi) >> 1;
+        const uint64_t ia = A + mid, ib = B + (d - 1 - mid);
+        if (suffix_less<BITS>(P, n, key[ia], (uint64_t)sa[ia], key[ib], (uint64_t)sa[ib])) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
 template <typename idx_t, int BITS>
 GLOBAL_FN LAUNCH_BOUNDS(256) merge_partition_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
-                                                    uint64_t R, uint64_t single_la,
+                                                    uint64_t R, uint64_t single_la, uint32_t skip_finished, uint32_t need_lcp,
                                                     const uint64_t* __restrict__ key, const idx_t* __restrict__ sa,
-                                                    uint64_t* __restrict__ splits)
+                                                    TileDesc* __restrict__ desc, uint64_t* __restrict__ moved)
 {
+    // moved (optional): += elements this pass really merges, one global atomic per workgroup
+    SHARED_ARRAY(uint64_t, acc, 1);
+    PAR(tid) { if (tid == 0) acc[0] = 0; }
+    SYNC();
     PAR(tid) {
         const uint64_t b = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
         if (b < sd.tile_off[sd.G]) {
             const TileInfo t = tile_info(sd, (uint32_t)b);
-            const PairInfo pr = pair_info(t, R, single_la);
-            const uint64_t A = pr.a0, B = pr.a0 + pr.la;
-            uint64_t lo = pr.d0 > pr.lb ? pr.d0 - pr.lb : 0;
-            uint64_t hi = pr.d0 < pr.la ? pr.d0 : pr.la;
-            while (lo < hi) {
-                const uint64_t mid = (lo + hi) >> 1;
-                const uint64_t ia = A + mid, ib = B + (pr.d0 - 1 - mid);
-                if (suffix_less<BITS>(P, n, key[ia], (uint64_t)sa[ia], key[ib], (uint64_t)sa[ib])) lo = mid + 1;
-                else hi = mid;
+            const uint64_t seglen = t.s1 - t.s0;
+            TileDesc d;
+            d.srcA = d.srcB = d.dst = 0;
+            d.na = d.nb = d.flags = d.pad = 0;
+            if (single_la != ~0ull || !skip_finished || seglen > R) {
+                const PairInfo pr = pair_info(t, R, single_la);
+                const uint64_t tot = pr.la + pr.lb;
+                const uint64_t d1 = pr.d0 + TILE_E < tot ? pr.d0 + TILE_E : tot;
+                const uint64_t A = pr.a0, B = pr.a0 + pr.la;
+                const uint64_t i0 = merge_path_split<idx_t, BITS>(P, n, key, sa, A, pr.la, B, pr.lb, pr.d0);
+                const uint64_t i1 = d1 < tot ? merge_path_split<idx_t, BITS>(P, n, key, sa, A, pr.la, B, pr.lb, d1) : pr.la;
+                const uint64_t j0 = pr.d0 - i0, j1 = d1 - i1;
+                d.srcA = A + i0;
+                d.srcB = B + j0;
+                d.dst = pr.a0 + pr.d0;
+                d.na = (uint32_t)(i1 - i0);
+                d.nb = (uint32_t)(j1 - j0);
+                d.flags = (i0 > 0 ? TD_HALO_A : 0u) | (j0 > 0 ? TD_HALO_B : 0u);
+                if (need_lcp && (single_la != ~0ull || 2 * R >= seglen)) d.flags |= TD_FINAL;
             }
-            splits[b] = lo;
+            desc[b] = d;
+            if (moved && (d.na + d.nb)) ATOMIC_ADD_LDS_U64(&acc[0], (uint64_t)(d.na + d.nb));
         }
     }
+    SYNC();
+    PAR(tid) { if (tid == 0 && moved && acc[0]) ATOMIC_ADD_U64(moved, acc[0]); }
 }
 
 template <typename idx_t, int BITS>
-GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) merge_pass_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
-                                                   uint64_t R, uint64_t single_la, const uint64_t* __restrict__ splits,
+GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) merge_pass_kernel(KCTX const TileDesc* __restrict__ desc, uint32_t n_tiles,
+                                                   const uint32_t* __restrict__ P, uint64_t n,
                                                    const uint64_t* __restrict__ in_key, const idx_t* __restrict__ in_sa,
-                                                   const idx_t* __restrict__ in_lcp,
                                                    uint64_t* __restrict__ out_key, idx_t* __restrict__ out_sa,
                                                    idx_t* __restrict__ out_lcp)
 {
-    const uint32_t b = K_BLOCK_IDX;
-    if (b >= sd.tile_off[sd.G]) return;
-    const TileInfo t = tile_info(sd, b);
-    const PairInfo pr = pair_info(t, R, single_la);
-    const uint64_t tot = pr.la + pr.lb;
-    const uint64_t d1 = pr.d0 + TILE_E < tot ? pr.d0 + TILE_E : tot;
-    const uint64_t i0 = splits[b];
-    const uint64_t i1 = d1 < tot ? splits[b + 1] : pr.la;
-    const uint64_t j0 = pr.d0 - i0, j1 = d1 - i1;
-    const uint32_t na = (uint32_t)(i1 - i0), nb = (uint32_t)(j1 - j0), cnt = na + nb;
-    const uint64_t srcA = pr.a0 + i0, srcB = pr.a0 + pr.la + j0;
-
-    // Elements just before each piece in its own run (predecessor candidates for the
-    // first-ranked elements of the other piece).  Block-uniform scalar loads.
-    const bool hA = i0 > 0, hB = j0 > 0;
-    const uint64_t hAk = hA ? in_key[srcA - 1] : 0, hBk = hB ? in_key[srcB - 1] : 0;
-    const uint64_t hAs = hA ? (uint64_t)in_sa[srcA - 1] : 0, hBs = hB ? (uint64_t)in_sa[srcB - 1] : 0;
-
     SHARED_ARRAY(uint64_t, skey, TILE_E);
     SHARED_ARRAY(idx_t, ssa, TILE_E);
-    SHARED_ARRAY(idx_t, slcp, TILE_E);
-    TL_DECL(uint64_t, rk, TILE_EPT);
+    TL_DECL(uint64_t, pk, TILE_EPT);      // prefetched (next tile)
+    TL_DECL(idx_t, ps, TILE_EPT);
+    TL_DECL(uint64_t, rk, TILE_EPT);      // element being ranked
     TL_DECL(idx_t, rs, TILE_EPT);
-    TL_DECL(idx_t, rl, TILE_EPT);
     TL_DECL(uint32_t, rd, TILE_EPT);
 
+    uint32_t t = K_BLOCK_IDX;
+    if (t >= n_tiles) return;
+    TileDesc d = desc[t];
     PAR(tid) {
         UNROLL
         for (uint32_t k = 0; k < TILE_EPT; ++k) {
             const uint32_t x = tid + k * TILE_NT;
-            if (x < cnt) {
-                const uint64_t src = x < na ? srcA + x : srcB + (x - na);
-                skey[x] = in_key[src];
-                ssa[x] = in_sa[src];
-                slcp[x] = in_lcp[src];
+            if (x < d.na + d.nb) {
+                const uint64_t src = x < d.na ? d.srcA + x : d.srcB + (x - d.na);
+                TL(pk, tid, k) = in_key[src];
+                TL(ps, tid, k) = in_sa[src];
             }
         }
     }
-    SYNC();
-    PAR(tid) {
-        UNROLL
-        for (uint32_t k = 0; k < TILE_EPT; ++k) {
-            const uint32_t x = tid + k * TILE_NT;
-            if (x < cnt) {
-                const uint64_t key = skey[x];
-                const uint64_t sa = (uint64_t)ssa[x];
-                const bool fromA = x < na;
-                uint32_t lo = fromA ? na : 0u, hi = fromA ? cnt : na;
-                const uint32_t base = lo;
-                while (lo < hi) {                           // #elements of the other piece < (key, sa)
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (suffix_less<BITS>(P, n, skey[mid], (uint64_t)ssa[mid], key, sa)) lo = mid + 1;
-                    else hi = mid;
+    while (true) {
+        const uint32_t na = d.na, cnt = d.na + d.nb;
+        PAR(tid) {
+            UNROLL
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                const uint32_t x = tid + k * TILE_NT;
+                if (x < cnt) { skey[x] = TL(pk, tid, k); ssa[x] = TL(ps, tid, k); }
+            }
+        }
+        SYNC();
+        // issue the next tile's loads; they stay in flight during the rank phase
+        const uint32_t t_next = t + K_GRID_DIM;
+        TileDesc dn = d;
+        if (t_next < n_tiles) {
+            dn = desc[t_next];
+            PAR(tid) {
+                UNROLL
+                for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                    const uint32_t x = tid + k * TILE_NT;
+                    if (x < dn.na + dn.nb) {
+                        const uint64_t src = x < dn.na ? dn.srcA + x : dn.srcB + (x - dn.na);
+                        TL(pk, tid, k) = in_key[src];
+                        TL(ps, tid, k) = in_sa[src];
+                    }
                 }
-                const uint32_t r = lo - base;
-                bool pv;                                    // predecessor in the other run
-                uint64_t pk, ps;
-                if (r > 0) { pv = true; pk = skey[lo - 1]; ps = (uint64_t)ssa[lo - 1]; }
-                else { pv = fromA ? hB : hA; pk = fromA ? hBk : hAk; ps = fromA ? hBs : hAs; }
-                uint64_t l = (uint64_t)slcp[x];
-                if (pv) {
-                    const uint64_t l2 = pair_lcp<BITS>(P, n, pk, ps, key, sa);
-                    l = l2 > l ? l2 : l;
+            }
+        }
+        PAR(tid) {
+            UNROLL
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                const uint32_t x = tid + k * TILE_NT;
+                if (x < cnt) {
+                    const uint64_t key = skey[x];
+                    const uint64_t sa = (uint64_t)ssa[x];
+                    const bool fromA = x < na;
+                    uint32_t lo = fromA ? na : 0u, hi = fromA ? cnt : na;
+                    const uint32_t base = lo;
+                    while (lo < hi) {                           // #elements of the other piece < (key, sa)
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (suffix_less<BITS>(P, n, skey[mid], (uint64_t)ssa[mid], key, sa)) lo = mid + 1;
+                        else hi = mid;
+                    }
+                    TL(rk, tid, k) = key;
+                    TL(rs, tid, k) = (idx_t)sa;
+                    TL(rd, tid, k) = (fromA ? x : x - na) + (lo - base);
                 }
-                TL(rk, tid, k) = key;
-                TL(rs, tid, k) = (idx_t)sa;
-                TL(rl, tid, k) = (idx_t)l;
-                TL(rd, tid, k) = (fromA ? x : x - na) + r;
             }
         }
-    }
-    SYNC();
-    PAR(tid) {
-        UNROLL
-        for (uint32_t k = 0; k < TILE_EPT; ++k) {
-            const uint32_t x = tid + k * TILE_NT;
-            if (x < cnt) {
-                const uint32_t d = TL(rd, tid, k);
-                skey[d] = TL(rk, tid, k);
-                ssa[d] = TL(rs, tid, k);
-                slcp[d] = TL(rl, tid, k);
+        SYNC();
+        PAR(tid) {
+            UNROLL
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                const uint32_t x = tid + k * TILE_NT;
+                if (x < cnt) {
+                    const uint32_t dd = TL(rd, tid, k);
+                    skey[dd] = TL(rk, tid, k);
+                    ssa[dd] = TL(rs, tid, k);
+                }
             }
         }
-    }
-    SYNC();
-    PAR(tid) {
-        const uint64_t dst = pr.a0 + pr.d0;
-        UNROLL
-        for (uint32_t k = 0; k < TILE_EPT; ++k) {
-            const uint32_t x = tid + k * TILE_NT;
-            if (x < cnt) {
-                out_key[dst + x] = skey[x];
-                out_sa[dst + x] = ssa[x];
-                out_lcp[dst + x] = slcp[x];
+        SYNC();
+        if (d.flags & TD_FINAL) {
+            // block-uniform scalar loads: the elements preceding the two pieces
+            const bool hA = d.flags & TD_HALO_A, hB = d.flags & TD_HALO_B;
+            const uint64_t hAk = hA ? in_key[d.srcA - 1] : 0, hBk = hB ? in_key[d.srcB - 1] : 0;
+            const uint64_t hAs = hA ? (uint64_t)in_sa[d.srcA - 1] : 0, hBs = hB ? (uint64_t)in_sa[d.srcB - 1] : 0;
+            PAR(tid) {
+                UNROLL
+                for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                    const uint32_t x = tid + k * TILE_NT;
+                    if (x < cnt) {
+                        const uint64_t key = skey[x];
+                        const uint64_t sa = (uint64_t)ssa[x];
+                        uint64_t l = 0;
+                        if (x) l = pair_lcp<BITS>(P, n, skey[x - 1], (uint64_t)ssa[x - 1], key, sa);
+                        else {
+                            if (hA) l = pair_lcp<BITS>(P, n, hAk, hAs, key, sa);
+                            if (hB) { const uint64_t l2 = pair_lcp<BITS>(P, n, hBk, hBs, key, sa); l = l2 > l ? l2 : l; }
+                        }
+                        out_key[d.dst + x] = key;
+                        out_sa[d.dst + x] = (idx_t)sa;
+                        out_lcp[d.dst + x] = (idx_t)l;
+                    }
+                }
             }
+        } else {
+            PAR(tid) {
+                UNROLL
+                for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                    const uint32_t x = tid + k * TILE_NT;
+                    if (x < cnt) { out_key[d.dst + x] = skey[x]; out_sa[d.dst + x] = ssa[x]; }
+                }
+            }
+        }
+        if (t_next >= n_tiles) break;
+        SYNC();
+        t = t_next;
+        d = dn;
+    }
+}
+
+// Result of a segmented sort with skip_finished: segment g sits in buffer (passes_for(len_g) & 1)
+// (0 = the buffer the tile sort wrote).  finalize_kernel gathers SA and LCP of every segment
+// into the caller's arrays and computes the LCP at the head of every segment but the first
+// (a11: compute_partition_boundary_lcp, src/Suffix_Array.cpp:431-447); empty segments are
+// skipped (the reference runs out of bounds on trailing empty partitions).
+template <typename idx_t> struct PingPong {
+    const uint64_t* key[2];
+    const idx_t* sa[2];
+    const idx_t* lcp[2];
+};
+
+template <typename idx_t, int BITS>
+GLOBAL_FN LAUNCH_BOUNDS(256) finalize_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n, PingPong<idx_t> pp,
+                                             uint32_t skip_finished, uint32_t uniform_sel, idx_t* __restrict__ dSA,
+                                             idx_t* __restrict__ dLCP)
+{
+    const uint32_t b = K_BLOCK_IDX;
+    if (b >= sd.tile_off[sd.G]) return;
+    const uint32_t g = sd.tile_seg[b];
+    const TileInfo t = tile_info(sd, b);
+    const uint64_t start = t.s0 + (uint64_t)t.tl * TILE_E;
+    const uint32_t cnt = (uint32_t)(t.s1 - start < TILE_E ? t.s1 - start : TILE_E);
+    const uint32_t sel = skip_finished ? (passes_for(t.s1 - t.s0) & 1u) : uniform_sel;
+    const idx_t* __restrict__ src_sa = pp.sa[sel];
+    const idx_t* __restrict__ src_lcp = pp.lcp[sel];
+    PAR(tid) {
+        for (uint32_t e = tid; e < cnt; e += K_BLOCK_DIM) {
+            dSA[start + e] = src_sa[start + e];
+            uint64_t l = (uint64_t)src_lcp[start + e];
+            if (e == 0 && t.tl == 0 && start > 0) {
+                // head of segment g: predecessor = last element of the nearest non-empty segment below
+                uint32_t h = g;
+                while (h > 0 && sd.seg_start[h] == sd.seg_start[h - 1]) --h;      // skip empty ones
+                // seg_start[h] == start; the previous segment [seg_start[h-1], start) is non-empty (start > 0)
+                const uint64_t plen = sd.seg_start[h] - sd.seg_start[h - 1];
+                const uint32_t psel = skip_finished ? (passes_for(plen) & 1u) : uniform_sel;
+                l = pair_lcp<BITS>(P, n, pp.key[psel][start - 1], (uint64_t)pp.sa[psel][start - 1], pp.key[sel][start],
+                                   (uint64_t)src_sa[start]);
+            }
+            dLCP[start + e] = (idx_t)l;
         }
     }
 }
@@ -646,25 +773,6 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) collate_kernel(KCTX SegDesc sd, uint32_t p, con
                 out_key[dst] = in_key[start + e];
                 out_sa[dst] = in_sa[start + e];
             }
-        }
-    }
-}
-
-// a11: LCP at the first element of every segment but the first (reference:
-// compute_partition_boundary_lcp, cpp:431-447).  Empty segments are skipped by
-// construction (the reference runs out of bounds on trailing empty partitions).
-template <typename idx_t, int BITS>
-GLOBAL_FN LAUNCH_BOUNDS(256) boundary_lcp_kernel(KCTX const uint32_t* __restrict__ P, uint64_t n,
-                                                 const uint64_t* __restrict__ seg_start, uint32_t G, uint64_t total,
-                                                 const uint64_t* __restrict__ key, const idx_t* __restrict__ sa,
-                                                 idx_t* __restrict__ lcp)
-{
-    PAR(tid) {
-        const uint64_t j = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid + 1;
-        if (j < G) {
-            const uint64_t at = seg_start[j];
-            if (at > 0 && at < total && seg_start[j + 1] > at)
-                lcp[at] = (idx_t)pair_lcp<BITS>(P, n, key[at - 1], (uint64_t)sa[at - 1], key[at], (uint64_t)sa[at]);
         }
     }
 }

@@ -59,6 +59,8 @@ struct SegBufs {
     SegDesc desc() const { return SegDesc{seg_start, tile_off, tile_seg, G}; }
 };
 
+constexpr uint32_t kMaxPasses = 96;
+
 template <typename idx_t> struct Plan {
     uint64_t n = 0;
     uint32_t p = 0;          // effective subproblem count (0/1 -> single segment)
@@ -73,7 +75,8 @@ template <typename idx_t> struct Plan {
     idx_t* ruler = nullptr;
     uint64_t* sizes = nullptr;
     SegBufs seg1, seg2, segS;
-    uint64_t* splits = nullptr;
+    TileDesc* desc = nullptr;        // [tile_cap] per-pass tile descriptors
+    uint64_t* pass_elems = nullptr;  // [kMaxPasses] elements merged by each timed pass
     uint32_t* present = nullptr;     // [8]
     uint8_t* lut = nullptr;          // [256]
     size_t bytes = 0;
@@ -133,7 +136,8 @@ Plan<idx_t> make_plan(uint64_t n, uint64_t p_arg, char* base)
         segs(pl.seg2, p, pl.tile_cap);
         segs(pl.segS, 1, pl.m / TILE_E + 3);
     }
-    pl.splits = ar.take<uint64_t>(pl.tile_cap + 1);
+    pl.desc = ar.take<TileDesc>(pl.tile_cap + 1);
+    pl.pass_elems = ar.take<uint64_t>(kMaxPasses);
     pl.present = ar.take<uint32_t>(8);
     pl.lut = ar.take<uint8_t>(256);
     pl.bytes = ar.off + 256;
@@ -199,39 +203,71 @@ inline void prepare_segments(Backend& be, const SegBufs& s, uint64_t tile_bound)
 
 inline uint32_t tiles_of(uint64_t len) { return (uint32_t)((len + TILE_E - 1) / TILE_E); }
 
+// Result of segmented_sort: data of segment g is in buf[sel(g)], sel = passes_for(len_g) & 1
+// when skip_finished, else passes & 1 for every segment (buf[0] = the tile sort's output).
+template <typename idx_t> struct SortResult {
+    ElemBuf<idx_t> buf[2];
+    uint32_t passes = 0;
+    bool skip_finished = false;
+    ElemBuf<idx_t> uniform() const { return buf[passes & 1]; }      // valid when !skip_finished
+    PingPong<idx_t> pingpong() const
+    {
+        PingPong<idx_t> pp;
+        for (int i = 0; i < 2; ++i) { pp.key[i] = buf[i].key; pp.sa[i] = buf[i].sa; pp.lcp[i] = buf[i].lcp; }
+        return pp;
+    }
+};
+
 // Sort every segment: tile sort (in place on `cur`; FROM_TEXT: cut from the packed text)
-// + merge passes ping-ponging between cur and oth.  Returns the buffer holding the result.
+// + merge passes ping-ponging between cur and oth.
+//   need_lcp       LCPs are emitted by the step that completes each segment
+//   skip_finished  segments that are already one run sit out the remaining passes
 template <typename idx_t, int BITS>
-ElemBuf<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, uint64_t* splits, const SegBufs& s,
-                              uint32_t n_tiles, uint64_t max_len, bool from_text, ElemBuf<idx_t> cur, ElemBuf<idx_t> oth,
-                              uint64_t n_elems, uint32_t* n_passes, KernelClock* tile_clock, KernelClock* merge_clock,
-                              uint64_t text_base = 0)
+SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, TileDesc* desc, const SegBufs& s,
+                                 uint32_t n_tiles, uint64_t max_len, bool from_text, ElemBuf<idx_t> cur, ElemBuf<idx_t> oth,
+                                 uint64_t n_elems, bool need_lcp, bool skip_finished, KernelClock* tile_clock,
+                                 KernelClock* merge_clock, uint64_t text_base = 0, uint64_t* pass_counters = nullptr)
 {
-    if (n_tiles == 0) return cur;
+    SortResult<idx_t> r;
+    r.buf[0] = cur;
+    r.buf[1] = oth;
+    r.skip_finished = skip_finished;
+    if (n_tiles == 0) return r;
     const SegDesc sd = s.desc();
+    const uint32_t lcp_mode = need_lcp ? 1u : 0u;
     BackendEvent t0 = be.record();
     if (from_text)
-        CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, sd, P, n, text_base, (const uint64_t*)nullptr,
-                    (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp);
+        CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, sd, P, n, text_base, lcp_mode,
+                    (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp);
     else
-        CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, (const uint64_t*)cur.key,
-                    (const idx_t*)cur.sa, cur.key, cur.sa, cur.lcp);
+        CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode,
+                    (const uint64_t*)cur.key, (const idx_t*)cur.sa, cur.key, cur.sa, cur.lcp);
     BackendEvent t1 = be.record();
     if (tile_clock) { tile_clock->spans.push_back({t0, t1}); tile_clock->elems.push_back(n_elems); }
-    uint32_t passes = 0;
+    const uint32_t grid = n_tiles < be.persistent_blocks() ? n_tiles : be.persistent_blocks();
     for (uint64_t R = TILE_E; R < max_len; R *= 2) {
         CAPS_LAUNCH((merge_partition_kernel<idx_t, BITS>), (n_tiles + 255) / 256, 256, be, sd, P, n, R, ~0ull,
-                    (const uint64_t*)cur.key, (const idx_t*)cur.sa, splits);
+                    skip_finished ? 1u : 0u, lcp_mode, (const uint64_t*)cur.key, (const idx_t*)cur.sa, desc,
+                    pass_counters ? pass_counters + r.passes : (uint64_t*)nullptr);
         BackendEvent m0 = be.record();
-        CAPS_LAUNCH((merge_pass_kernel<idx_t, BITS>), n_tiles, TILE_NT, be, sd, P, n, R, ~0ull, (const uint64_t*)splits,
-                    (const uint64_t*)cur.key, (const idx_t*)cur.sa, (const idx_t*)cur.lcp, oth.key, oth.sa, oth.lcp);
+        CAPS_LAUNCH((merge_pass_kernel<idx_t, BITS>), grid, TILE_NT, be, (const TileDesc*)desc, n_tiles, P, n,
+                    (const uint64_t*)cur.key, (const idx_t*)cur.sa, oth.key, oth.sa, oth.lcp);
         BackendEvent m1 = be.record();
         if (merge_clock) { merge_clock->spans.push_back({m0, m1}); merge_clock->elems.push_back(n_elems); }
         std::swap(cur, oth);
-        ++passes;
+        ++r.passes;
     }
-    if (n_passes) *n_passes += passes;
-    return cur;
+    return r;
+}
+
+// Gather SA/LCP of a sorted segment set into the caller's arrays + segment-head LCPs (a11).
+template <typename idx_t, int BITS>
+void finalize(Backend& be, const uint32_t* P, uint64_t n, const SegBufs& s, uint32_t n_tiles, const SortResult<idx_t>& r,
+              idx_t* dSA, idx_t* dLCP)
+{
+    if (n_tiles == 0) return;
+    CAPS_LAUNCH((finalize_kernel<idx_t, BITS>), n_tiles, 256, be, s.desc(), P, n, r.pingpong(), r.skip_finished ? 1u : 0u,
+                r.passes & 1u, dSA, dLCP);
 }
 
 template <typename idx_t> class Builder {
@@ -259,13 +295,20 @@ private:
     int bits_ = 0;
     KernelClock merge_clock_;
     KernelClock tile_clock_;
+    uint32_t pass_base_ = 0;
 
     template <int BITS>
-    ElemBuf<idx_t> seg_sort(const SegBufs& s, uint32_t n_tiles, uint64_t max_len, bool from_text, ElemBuf<idx_t> cur,
-                            ElemBuf<idx_t> oth, uint64_t n_elems, uint32_t* n_passes)
+    SortResult<idx_t> seg_sort(const SegBufs& s, uint32_t n_tiles, uint64_t max_len, bool from_text, ElemBuf<idx_t> cur,
+                               ElemBuf<idx_t> oth, uint64_t n_elems, bool need_lcp, bool skip_finished, bool timed)
     {
-        return segmented_sort<idx_t, BITS>(be_, pl_.P, pl_.n, pl_.splits, s, n_tiles, max_len, from_text, cur, oth, n_elems,
-                                           n_passes, &tile_clock_, &merge_clock_);
+        // timed: the full-size sorts (phase 1, phase 2) feed the kernel clocks of caps_sa_stats;
+        // their passes count the elements they really move in pl_.pass_elems[pass_base_ ...]
+        uint64_t* counters = timed ? pl_.pass_elems + pass_base_ : nullptr;
+        SortResult<idx_t> r = segmented_sort<idx_t, BITS>(be_, pl_.P, pl_.n, pl_.desc, s, n_tiles, max_len, from_text, cur, oth,
+                                                          n_elems, need_lcp, skip_finished, timed ? &tile_clock_ : nullptr,
+                                                          timed ? &merge_clock_ : nullptr, 0, counters);
+        if (timed) pass_base_ += r.passes;
+        return r;
     }
     void prepare_segments(const SegBufs& s, uint64_t tile_bound) { ::caps::prepare_segments(be_, s, tile_bound); }
 
@@ -275,24 +318,30 @@ private:
         const uint64_t n = pl_.n;
         const uint32_t p = pl_.p;
         uint32_t passes1 = 0, passes2 = 0, passesS = 0;
-        ElemBuf<idx_t> res;
         BackendEvent e2, e3, e4, e5, e6, e7;
         uint64_t max_part = 0;
+        be_.memset(pl_.pass_elems, 0, kMaxPasses * sizeof(uint64_t));
 
         if (p < 2) {
             // Below the reference's valid domain (n < 32 or p_eff < 2) the
             // samplesort degenerates to ONE segment: tile sort + merge passes over [0, n).
             CAPS_LAUNCH(uniform_segments_kernel, 1, 256, be_, pl_.seg1.seg_start, 1u, n, n);
             prepare_segments(pl_.seg1, tiles_of(n));
-            res = seg_sort<BITS>(pl_.seg1, tiles_of(n), n, true, pl_.A, pl_.B, n, &passes1);
-            e2 = e3 = e4 = e5 = e6 = e7 = be_.record();
+            SortResult<idx_t> r = seg_sort<BITS>(pl_.seg1, tiles_of(n), n, true, pl_.A, pl_.B, n, true, false, true);
+            passes1 = r.passes;
+            e2 = e3 = e4 = e5 = e6 = be_.record();
+            finalize<idx_t, BITS>(be_, pl_.P, n, pl_.seg1, tiles_of(n), r, dSA, dLCP);
+            e7 = be_.record();
         } else {
             const uint64_t s = n / p, last = s + n % p;
-            // ---- phase 1 (a5): sort the p subarrays of contiguous text positions
+            // ---- phase 1 (a5): sort the p subarrays of contiguous text positions (no LCPs needed:
+            //      the collate step moves only keys and indices)
             CAPS_LAUNCH(uniform_segments_kernel, (p + 256) / 256, 256, be_, pl_.seg1.seg_start, p, s, n);
             const uint32_t n_tiles1 = (p - 1) * tiles_of(s) + tiles_of(last);
             prepare_segments(pl_.seg1, n_tiles1);
-            ElemBuf<idx_t> cur = seg_sort<BITS>(pl_.seg1, n_tiles1, last, true, pl_.A, pl_.B, n, &passes1);
+            SortResult<idx_t> r1 = seg_sort<BITS>(pl_.seg1, n_tiles1, last, true, pl_.A, pl_.B, n, false, false, true);
+            passes1 = r1.passes;
+            ElemBuf<idx_t> cur = r1.uniform();
             ElemBuf<idx_t> oth = cur.key == pl_.A.key ? pl_.B : pl_.A;
             e2 = be_.record();
 
@@ -302,7 +351,9 @@ private:
                         pl_.ppp, (const uint64_t*)cur.key, (const idx_t*)cur.sa, pl_.SA_.key, pl_.SA_.sa);
             CAPS_LAUNCH(uniform_segments_kernel, 1, 256, be_, pl_.segS.seg_start, 1u, m, m);
             prepare_segments(pl_.segS, tiles_of(m));
-            ElemBuf<idx_t> smp = seg_sort<BITS>(pl_.segS, tiles_of(m), m, false, pl_.SA_, pl_.SB_, m, &passesS);
+            SortResult<idx_t> rs = seg_sort<BITS>(pl_.segS, tiles_of(m), m, false, pl_.SA_, pl_.SB_, m, false, false, false);
+            passesS = rs.passes;
+            ElemBuf<idx_t> smp = rs.uniform();
             CAPS_LAUNCH((pick_pivots_kernel<idx_t>), (p + 255) / 256, 256, be_, (const uint64_t*)smp.key, (const idx_t*)smp.sa,
                         m, p, pl_.pkey, pl_.psa);
             e3 = be_.record();
@@ -329,17 +380,17 @@ private:
             max_part = out2[1];
             e5 = be_.record();
 
-            // ---- phase 2 (a10): sort every partition
-            res = seg_sort<BITS>(pl_.seg2, n_tiles2, max_part, false, oth, cur, n, &passes2);
+            // ---- phase 2 (a10): sort every partition; a partition's last step emits its LCPs
+            SortResult<idx_t> r2 = seg_sort<BITS>(pl_.seg2, n_tiles2, max_part, false, oth, cur, n, true, true, true);
+            passes2 = r2.passes;
             e6 = be_.record();
 
-            // ---- partition-boundary LCPs (a11)
-            CAPS_LAUNCH((boundary_lcp_kernel<idx_t, BITS>), (p + 255) / 256, 256, be_, (const uint32_t*)pl_.P, n,
-                        (const uint64_t*)pl_.seg2.seg_start, p, n, (const uint64_t*)res.key, (const idx_t*)res.sa, res.lcp);
+            // ---- gather SA/LCP + partition-boundary LCPs (a11)
+            finalize<idx_t, BITS>(be_, pl_.P, n, pl_.seg2, n_tiles2, r2, dSA, dLCP);
             e7 = be_.record();
         }
-        be_.d2d(dSA, res.sa, n * sizeof(idx_t));
-        be_.d2d(dLCP, res.lcp, n * sizeof(idx_t));
+        uint64_t pass_elems[kMaxPasses];
+        be_.d2h(pass_elems, pl_.pass_elems, sizeof pass_elems);
         BackendEvent e8 = be_.record();
         be_.sync();
 
@@ -369,6 +420,8 @@ private:
             };
             sum(merge_clock_, &st->merge_pass_ms, &st->merge_pass_launches, &st->merge_pass_elems);
             sum(tile_clock_, &st->tile_sort_ms, &st->tile_sort_launches, &st->tile_sort_elems);
+            st->merge_pass_elems = 0;                      // elements the timed passes really merged
+            for (uint32_t i = 0; i < pass_base_ && i < kMaxPasses; ++i) st->merge_pass_elems += pass_elems[i];
         }
         be_.release_events();
     }

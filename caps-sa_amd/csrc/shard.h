@@ -75,7 +75,7 @@ public:
             sizes_ = get<uint64_t>(p_);
             lstart_ = get<uint64_t>((size_t)p_ + 1);
             const uint64_t a = local_n_ / TILE_E + G_ + 3, b = m_total_ / TILE_E + 3;
-            splits_ = get<uint64_t>(a > b ? a : b);
+            tdesc_ = get<TileDesc>(a > b ? a : b);
         } catch (...) {
             release();
             throw;
@@ -102,8 +102,8 @@ public:
             const uint64_t last = local_n_ - (uint64_t)(G_ - 1) * s_;
             n_tiles1_ = (G_ - 1) * tiles_of(s_) + tiles_of(last);
             prepare_segments(be_, seg1_, n_tiles1_);
-            cur_ = bits_ == 2 ? sort<2>(seg1_, n_tiles1_, last, true, A_, B_, local_n_, text_base_)
-                              : sort<8>(seg1_, n_tiles1_, last, true, A_, B_, local_n_, text_base_);
+            cur_ = (bits_ == 2 ? sort<2>(seg1_, n_tiles1_, last, true, A_, B_, local_n_, text_base_, false, false)
+                               : sort<8>(seg1_, n_tiles1_, last, true, A_, B_, local_n_, text_base_, false, false)).uniform();
             oth_ = cur_.key == A_.key ? B_ : A_;
             CAPS_LAUNCH((sample_kernel<idx_t>), (uint32_t)((m_local_ + 255) / 256), 256, be_, (const uint64_t*)seg1_.seg_start, G_,
                         ppp_, (const uint64_t*)cur_.key, (const idx_t*)cur_.sa, static_cast<uint64_t*>(d_sample_keys),
@@ -122,8 +122,8 @@ public:
         be_.d2d(SA_.sa, d_all_sa, m_total_ * sizeof(idx_t));
         CAPS_LAUNCH(uniform_segments_kernel, 1, 256, be_, segS_.seg_start, 1u, m_total_, m_total_);
         prepare_segments(be_, segS_, tiles_of(m_total_));
-        ElemBuf<idx_t> smp = bits_ == 2 ? sort<2>(segS_, tiles_of(m_total_), m_total_, false, SA_, SB_, m_total_, 0)
-                                        : sort<8>(segS_, tiles_of(m_total_), m_total_, false, SA_, SB_, m_total_, 0);
+        ElemBuf<idx_t> smp = (bits_ == 2 ? sort<2>(segS_, tiles_of(m_total_), m_total_, false, SA_, SB_, m_total_, 0, false, false)
+                                         : sort<8>(segS_, tiles_of(m_total_), m_total_, false, SA_, SB_, m_total_, 0, false, false)).uniform();
         CAPS_LAUNCH((pick_pivots_kernel<idx_t>), (p_ + 255) / 256, 256, be_, (const uint64_t*)smp.key, (const idx_t*)smp.sa,
                     m_total_, p_, pkey_, psa_);
         const uint32_t np = p_ - 1, bpr = (np + 255) / 256;
@@ -195,7 +195,7 @@ public:
         B2_ = elems(recv_total_);
         seg2_ = segs(G2_ ? G2_ : 1, recv_total_ / TILE_E + G2_ + 2);
         seg2_.G = G2_;
-        splits2_ = get<uint64_t>(recv_total_ / TILE_E + G2_ + 3);
+        tdesc2_ = get<TileDesc>(recv_total_ / TILE_E + G2_ + 3);
         std::vector<uint64_t> st((size_t)G2_ + 1, 0);
         max_len2_ = 0;
         n_tiles2_ = 0;
@@ -237,18 +237,16 @@ public:
                 CAPS_LAUNCH((regroup_kernel<idx_t>), n_desc_, 256, be_, (const uint64_t*)desc_, static_cast<const uint64_t*>(d_recv_keys),
                             static_cast<const idx_t*>(d_recv_sa), A2_.key, A2_.sa);
             prepare_segments(be_, seg2_, n_tiles2_);
-            std::swap(splits_, splits2_);
-            res_ = bits_ == 2 ? sort<2>(seg2_, n_tiles2_, max_len2_, false, A2_, B2_, recv_total_, 0)
-                              : sort<8>(seg2_, n_tiles2_, max_len2_, false, A2_, B2_, recv_total_, 0);
-            std::swap(splits_, splits2_);
-            if (bits_ == 2)
-                CAPS_LAUNCH((boundary_lcp_kernel<idx_t, 2>), (G2_ + 255) / 256, 256, be_, (const uint32_t*)P_, n_,
-                            (const uint64_t*)seg2_.seg_start, G2_, recv_total_, (const uint64_t*)res_.key, (const idx_t*)res_.sa, res_.lcp);
-            else
-                CAPS_LAUNCH((boundary_lcp_kernel<idx_t, 8>), (G2_ + 255) / 256, 256, be_, (const uint32_t*)P_, n_,
-                            (const uint64_t*)seg2_.seg_start, G2_, recv_total_, (const uint64_t*)res_.key, (const idx_t*)res_.sa, res_.lcp);
-            be_.d2d(dSA, res_.sa, recv_total_ * sizeof(idx_t));
-            be_.d2d(dLCP, res_.lcp, recv_total_ * sizeof(idx_t));
+            std::swap(tdesc_, tdesc2_);
+            if (bits_ == 2) {
+                SortResult<idx_t> r = sort<2>(seg2_, n_tiles2_, max_len2_, false, A2_, B2_, recv_total_, 0, true, true);
+                finalize<idx_t, 2>(be_, P_, n_, seg2_, n_tiles2_, r, static_cast<idx_t*>(dSA), static_cast<idx_t*>(dLCP));
+            } else {
+                SortResult<idx_t> r = sort<8>(seg2_, n_tiles2_, max_len2_, false, A2_, B2_, recv_total_, 0, true, true);
+                finalize<idx_t, 8>(be_, P_, n_, seg2_, n_tiles2_, r, static_cast<idx_t*>(dSA), static_cast<idx_t*>(dLCP));
+            }
+            std::swap(tdesc_, tdesc2_);
+            dSA_ = static_cast<idx_t*>(dSA);
         }
         BackendEvent e1 = be_.record();
         be_.sync();
@@ -260,7 +258,7 @@ public:
     {
         if (!recv_total_) return ~0ull;
         idx_t v = 0;
-        be_.d2h(&v, res_.sa + (recv_total_ - 1), sizeof(idx_t));
+        be_.d2h(&v, dSA_ + (recv_total_ - 1), sizeof(idx_t));
         be_.sync();
         return (uint64_t)v;
     }
@@ -269,10 +267,10 @@ public:
     {
         if (!recv_total_ || prev_sa == ~0ull) return;
         if (bits_ == 2)
-            CAPS_LAUNCH((first_lcp_kernel<idx_t, 2>), 1, 64, be_, (const uint32_t*)P_, n_, prev_sa, (const idx_t*)res_.sa,
+            CAPS_LAUNCH((first_lcp_kernel<idx_t, 2>), 1, 64, be_, (const uint32_t*)P_, n_, prev_sa, (const idx_t*)dSA_,
                         static_cast<idx_t*>(dLCP));
         else
-            CAPS_LAUNCH((first_lcp_kernel<idx_t, 8>), 1, 64, be_, (const uint32_t*)P_, n_, prev_sa, (const idx_t*)res_.sa,
+            CAPS_LAUNCH((first_lcp_kernel<idx_t, 8>), 1, 64, be_, (const uint32_t*)P_, n_, prev_sa, (const idx_t*)dSA_,
                         static_cast<idx_t*>(dLCP));
         be_.sync();
     }
@@ -289,9 +287,11 @@ private:
     uint32_t* P_ = nullptr;
     uint32_t* present_ = nullptr;
     uint8_t* lut_ = nullptr;
-    ElemBuf<idx_t> A_, B_, SA_, SB_, A2_, B2_, cur_, oth_, res_;
+    ElemBuf<idx_t> A_, B_, SA_, SB_, A2_, B2_, cur_, oth_;
+    idx_t* dSA_ = nullptr;
+    TileDesc *tdesc_ = nullptr, *tdesc2_ = nullptr;
     SegBufs seg1_, segS_, seg2_;
-    uint64_t *pkey_ = nullptr, *sizes_ = nullptr, *lstart_ = nullptr, *splits_ = nullptr, *splits2_ = nullptr, *desc_ = nullptr;
+    uint64_t *pkey_ = nullptr, *sizes_ = nullptr, *lstart_ = nullptr, *desc_ = nullptr;
     idx_t *psa_ = nullptr, *Pm_ = nullptr, *ruler_ = nullptr;
     double ms_phase1_ = 0, ms_pivots_ = 0, ms_collate_ = 0, ms_phase2_ = 0;
 
@@ -325,11 +325,11 @@ private:
         owned_.clear();
     }
     template <int BITS>
-    ElemBuf<idx_t> sort(const SegBufs& s, uint32_t n_tiles, uint64_t max_len, bool from_text, ElemBuf<idx_t> a, ElemBuf<idx_t> b,
-                        uint64_t n_elems, uint64_t text_base)
+    SortResult<idx_t> sort(const SegBufs& s, uint32_t n_tiles, uint64_t max_len, bool from_text, ElemBuf<idx_t> a, ElemBuf<idx_t> b,
+                           uint64_t n_elems, uint64_t text_base, bool need_lcp, bool skip_finished)
     {
-        return segmented_sort<idx_t, BITS>(be_, P_, n_, splits_, s, n_tiles, max_len, from_text, a, b, n_elems, nullptr, nullptr,
-                                           nullptr, text_base);
+        return segmented_sort<idx_t, BITS>(be_, P_, n_, tdesc_, s, n_tiles, max_len, from_text, a, b, n_elems, need_lcp,
+                                           skip_finished, nullptr, nullptr, text_base);
     }
 };
 

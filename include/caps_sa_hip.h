@@ -114,11 +114,20 @@ int caps_sa_hip_sort_suffixes_u32(const char* T, uint64_t n, const uint32_t* idx
 int caps_sa_hip_sort_suffixes_u64(const char* T, uint64_t n, const uint64_t* idx, uint64_t cnt,
                                   uint64_t* out_sa, uint64_t* out_lcp, int device);
 
+/* sort_partition over every partition (src/Suffix_Array.cpp:388-404): independent sorts of
+ * the G consecutive segments [seg_start[g], seg_start[g+1]) of the suffix list idx (seg_start:
+ * host u64[G+1], seg_start[0] = 0, seg_start[G] = cnt).  out_lcp at a segment head is the lcp
+ * with the last suffix of the previous non-empty segment (cpp:431-447); out_lcp[0] = 0. */
+int caps_sa_hip_sort_segments_u32(const char* T, uint64_t n, const uint32_t* idx, uint64_t cnt,
+                                  const uint64_t* seg_start, uint64_t G, uint32_t* out_sa, uint32_t* out_lcp, int device);
+int caps_sa_hip_sort_segments_u64(const char* T, uint64_t n, const uint64_t* idx, uint64_t cnt,
+                                  const uint64_t* seg_start, uint64_t G, uint64_t* out_sa, uint64_t* out_lcp, int device);
+
 /* merge (src/Suffix_Array.cpp:48-109): X, Y sorted suffix runs with their LCP arrays ->
  * Z (len_x + len_y) and LCP_z. */
 int caps_sa_hip_merge_u32(const char* T, uint64_t n, const uint32_t* X, uint64_t len_x, const uint32_t* Y,
                           uint64_t len_y, const uint32_t* LCP_x, const uint32_t* LCP_y, uint32_t* Z,
-                          uint32_t* LCP_z, int device);
+                          uint32_t* LCP_z, int device);   /* LCP_x/LCP_y: accepted, not needed (keys) */
 int caps_sa_hip_merge_u64(const char* T, uint64_t n, const uint64_t* X, uint64_t len_x, const uint64_t* Y,
                           uint64_t len_y, const uint64_t* LCP_x, const uint64_t* LCP_y, uint64_t* Z,
                           uint64_t* LCP_z, int device);

@@ -48,6 +48,7 @@ public:
     void d2h(void* h, const void* d, size_t bytes) { std::memcpy(h, d, bytes); }
     void d2d(void* d, const void* s, size_t bytes) { std::memmove(d, s, bytes); }
     void sync() {}
+    uint32_t persistent_blocks() { return 3; }     // small on purpose: exercises the tile loop
     void check_launch(const char*) {}
 };
 

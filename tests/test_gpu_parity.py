@@ -216,3 +216,29 @@ def test_sharded_driver_single_rank_rccl(L):
         assert torch.equal(SA, SA1) and torch.equal(LCP, LCP1)
     finally:
         dist.destroy_process_group()
+
+
+def _check_segments(LIB, oracle, T, idx, seg):
+    sa, lcp = LIB.sort_segments(T, idx, seg)
+    prev_last = None
+    for g in range(len(seg) - 1):
+        a, b = int(seg[g]), int(seg[g + 1])
+        if a == b:
+            continue
+        so, lo = oracle.merge_sort(T, idx[a:b])
+        assert np.array_equal(sa[a:b], so), f"segment {g}"
+        exp = lo.copy()
+        exp[0] = 0 if prev_last is None else oracle.lcp(T, prev_last, int(so[0]))
+        assert np.array_equal(lcp[a:b], exp), f"segment {g} lcp"
+        prev_last = int(so[-1])
+
+
+def test_segmented_sort_mixed_lengths(L, oracle):
+    """Segments of 0, 1, <1 tile, exactly 1/2/3/5/8 tiles (+-1): finished segments sit out later
+    passes and end in different ping-pong buffers (parity of passes_for(len))."""
+    rs = np.random.RandomState(8)
+    T = rs.choice(DNA, size=200000)
+    lens = [5000, 0, 1, 4096, 4097, 0, 8192, 8193, 12288, 3, 20480, 20481, 32768, 100, 0, 16385, 7]
+    seg = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    idx = rs.permutation(200000)[:int(seg[-1])].astype(np.uint32)
+    _check_segments(L, oracle, T, idx, seg)
