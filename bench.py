@@ -141,7 +141,8 @@ def main():
                 "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "avg_launch_ms": avg_ms, "launches_per_step": launches / args.steps,
                 "algorithmic_bytes_per_launch": alg_bytes,
-                "moved_bytes_per_launch_incl_keys": (4 * w + 16) * (elems / launches)}
+                # what a pass really streams: key + index read and written (LCPs only in a segment's last pass)
+                "moved_bytes_per_launch_incl_keys": 2 * (8 + w) * (elems / launches)}
     last = stats[-1]
     phases = {k: last[k] for k in ("ms_total", "ms_pack", "ms_sort_subarrays", "ms_select_pivots", "ms_locate_pivots",
                                    "ms_partition", "ms_merge_partitions", "ms_boundary_lcp", "ms_output",

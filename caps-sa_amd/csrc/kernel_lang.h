@@ -25,8 +25,10 @@
 #include <cstring>
 #define HD inline
 #define DEV_INLINE inline
+#define HD_NOINLINE
 #define GLOBAL_FN static void
 #define LAUNCH_BOUNDS(n)
+#define LAUNCH_BOUNDS2(n, w)
 namespace caps { struct EmulCtx { uint32_t block_idx, grid_dim, block_dim; }; }
 #define KCTX const caps::EmulCtx& kctx_,
 #define K_BLOCK_IDX (kctx_.block_idx)
@@ -50,8 +52,10 @@ static inline uint32_t caps_bswap32(uint32_t x) { return __builtin_bswap32(x); }
 #include <hip/hip_runtime.h>
 #define HD __host__ __device__ __forceinline__
 #define DEV_INLINE __device__ __forceinline__
+#define HD_NOINLINE __host__ __device__ __attribute__((noinline))
 #define GLOBAL_FN __global__ void
 #define LAUNCH_BOUNDS(n) __launch_bounds__(n)
+#define LAUNCH_BOUNDS2(n, w) __launch_bounds__(n, w)   /* w = min waves per SIMD = blocks/CU * n / 256 */
 #define KCTX
 #define K_BLOCK_IDX (blockIdx.x)
 #define K_GRID_DIM (gridDim.x)

@@ -27,9 +27,14 @@
 
 namespace caps {
 
-constexpr uint32_t TILE_E = 4096;      // elements per tile (one workgroup)
+constexpr uint32_t TILE_E = 8192;      // elements per tile (one workgroup)
 constexpr uint32_t TILE_NT = 1024;     // threads per tile workgroup (16 waves)
 constexpr uint32_t TILE_EPT = TILE_E / TILE_NT;
+// One 1024-thread workgroup per CU (LDS: 96 KiB of keys + indices at 32-bit indices, 128 KiB at
+// 64-bit): 4 waves per SIMD, i.e. a budget of 128 VGPRs -- room for the registers that hold the
+// prefetched next tile next to 8 binary searches advanced in lockstep.
+#define TILE_WAVES_PER_SIMD 4
+constexpr uint32_t LOCK_K = 4;         // binary searches a thread advances in lockstep
 
 // Segment/tile descriptor shared by the tile-granular kernels.
 struct SegDesc {
@@ -250,6 +255,32 @@ GLOBAL_FN LAUNCH_BOUNDS(256) tile_map_kernel(KCTX const uint32_t* __restrict__ t
     }
 }
 
+
+// K independent lower-bound searches over LDS-resident (key, sa) runs, advanced in lockstep
+// so that the K dependent LDS reads of one step are in flight together (a single search is a
+// chain of ~12 dependent ds_read latencies).  lo[k] < hi[k] delimits search k; on return
+// lo[k] = index of the first element of [lo, hi) that is not < (key[k], sa[k]).
+template <typename idx_t, int BITS, int K>
+DEV_INLINE void lockstep_lower_bound(const uint32_t* __restrict__ P, uint64_t n, const uint64_t* skey, const idx_t* ssa,
+                                     const uint64_t (&key)[K], const idx_t (&sa)[K], uint32_t (&lo)[K], uint32_t (&hi)[K])
+{
+    bool any = true;
+    while (any) {
+        any = false;
+        UNROLL
+        for (int k = 0; k < K; ++k) {
+            if (lo[k] < hi[k]) {
+                const uint32_t mid = (lo[k] + hi[k]) >> 1;
+                const uint64_t mk = skey[mid];
+                bool less = mk < key[k];
+                if (mk == key[k]) less = suffix_less<BITS>(P, n, mk, (uint64_t)ssa[mid], key[k], (uint64_t)sa[k]);
+                if (less) lo[k] = mid + 1; else hi[k] = mid;
+                any |= lo[k] < hi[k];
+            }
+        }
+    }
+}
+
 // ----------------------------------------------------------------------------------
 // a4/a5: tile sort -- one workgroup sorts up to TILE_E suffixes in LDS and emits the
 // sorted run with its LCP array (reference: merge_sort, src/Suffix_Array.cpp:112-129,
@@ -263,10 +294,10 @@ GLOBAL_FN LAUNCH_BOUNDS(256) tile_map_kernel(KCTX const uint32_t* __restrict__ t
 // by a binary search in the sibling run (rank merge): no divergent serial merge,
 // ragged runs need no padding.  LCPs are produced once, at the end, from adjacent
 // keys (text only on equal keys).
-// LDS: 4096 x (8 + sizeof(idx_t)) = 48/64 KiB -> two workgroups (32 waves) per CU.
+// LDS: 8192 x (8 + sizeof(idx_t)) = 96/128 KiB -> one workgroup (16 waves) per CU.
 // ----------------------------------------------------------------------------------
 template <typename idx_t, int BITS, bool FROM_TEXT>
-GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) tile_sort_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
+GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
                                                   uint64_t text_base, uint32_t lcp_mode, const uint64_t* in_key,
                                                   const idx_t* in_sa, uint64_t* out_key, idx_t* out_sa, idx_t* out_lcp)
 {
@@ -306,25 +337,33 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) tile_sort_kernel(KCTX SegDesc sd, const uint32_
     for (uint32_t R = 1; R < cnt; R <<= 1) {
         PAR(tid) {
             UNROLL
-            for (uint32_t k = 0; k < TILE_EPT; ++k) {
-                const uint32_t e = tid + k * TILE_NT;
-                if (e < cnt) {
-                    const uint64_t key = skey[e];
-                    const idx_t sa = ssa[e];
-                    const uint32_t run = e / R;
-                    const uint32_t own_start = run * R;
-                    uint32_t sib_start = (run ^ 1u) * R;
-                    if (sib_start > cnt) sib_start = cnt;
-                    const uint32_t sib_end = sib_start + R < cnt ? sib_start + R : cnt;
-                    uint32_t lo = sib_start, hi = sib_end;       // #sibling elements < (key, sa)
-                    while (lo < hi) {
-                        const uint32_t mid = (lo + hi) >> 1;
-                        if (suffix_less<BITS>(P, n, skey[mid], (uint64_t)ssa[mid], key, (uint64_t)sa)) lo = mid + 1;
-                        else hi = mid;
+            for (uint32_t g = 0; g < TILE_EPT; g += LOCK_K) {            // LOCK_K searches in lockstep
+                uint64_t key[LOCK_K];
+                idx_t sa[LOCK_K];
+                uint32_t lo[LOCK_K], hi[LOCK_K], dbase[LOCK_K];
+                UNROLL
+                for (uint32_t k = 0; k < LOCK_K; ++k) {
+                    const uint32_t e = tid + (g + k) * TILE_NT;
+                    key[k] = 0;
+                    sa[k] = 0;
+                    lo[k] = hi[k] = dbase[k] = 0;
+                    if (e < cnt) {
+                        key[k] = skey[e];
+                        sa[k] = ssa[e];
+                        const uint32_t run = e / R;
+                        uint32_t sib_start = (run ^ 1u) * R;
+                        if (sib_start > cnt) sib_start = cnt;
+                        lo[k] = sib_start;                               // #sibling elements < (key, sa)
+                        hi[k] = sib_start + R < cnt ? sib_start + R : cnt;
+                        dbase[k] = (run & ~1u) * R + (e - run * R) - sib_start;
                     }
-                    TL(rk, tid, k) = key;
-                    TL(rs, tid, k) = sa;
-                    TL(rd, tid, k) = (run & ~1u) * R + (e - own_start) + (lo - sib_start);
+                }
+                lockstep_lower_bound<idx_t, BITS, LOCK_K>(P, n, skey, ssa, key, sa, lo, hi);
+                UNROLL
+                for (uint32_t k = 0; k < LOCK_K; ++k) {
+                    TL(rk, tid, g + k) = key[k];
+                    TL(rs, tid, g + k) = sa[k];
+                    TL(rd, tid, g + k) = dbase[k] + lo[k];
                 }
             }
         }
@@ -459,7 +498,7 @@ GLOBAL_FN LAUNCH_BOUNDS(256) merge_partition_kernel(KCTX SegDesc sd, const uint3
 }
 
 template <typename idx_t, int BITS>
-GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) merge_pass_kernel(KCTX const TileDesc* __restrict__ desc, uint32_t n_tiles,
+GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) merge_pass_kernel(KCTX const TileDesc* __restrict__ desc, uint32_t n_tiles,
                                                    const uint32_t* __restrict__ P, uint64_t n,
                                                    const uint64_t* __restrict__ in_key, const idx_t* __restrict__ in_sa,
                                                    uint64_t* __restrict__ out_key, idx_t* __restrict__ out_sa,
@@ -516,22 +555,32 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) merge_pass_kernel(KCTX const TileDesc* __restri
         }
         PAR(tid) {
             UNROLL
-            for (uint32_t k = 0; k < TILE_EPT; ++k) {
-                const uint32_t x = tid + k * TILE_NT;
-                if (x < cnt) {
-                    const uint64_t key = skey[x];
-                    const uint64_t sa = (uint64_t)ssa[x];
-                    const bool fromA = x < na;
-                    uint32_t lo = fromA ? na : 0u, hi = fromA ? cnt : na;
-                    const uint32_t base = lo;
-                    while (lo < hi) {                           // #elements of the other piece < (key, sa)
-                        const uint32_t mid = (lo + hi) >> 1;
-                        if (suffix_less<BITS>(P, n, skey[mid], (uint64_t)ssa[mid], key, sa)) lo = mid + 1;
-                        else hi = mid;
+            for (uint32_t g = 0; g < TILE_EPT; g += LOCK_K) {            // LOCK_K searches in lockstep
+                uint64_t key[LOCK_K];
+                idx_t sa[LOCK_K];
+                uint32_t lo[LOCK_K], hi[LOCK_K];
+                UNROLL
+                for (uint32_t k = 0; k < LOCK_K; ++k) {
+                    const uint32_t x = tid + (g + k) * TILE_NT;
+                    key[k] = 0;
+                    sa[k] = 0;
+                    lo[k] = hi[k] = 0;
+                    if (x < cnt) {
+                        key[k] = skey[x];
+                        sa[k] = ssa[x];
+                        const bool fromA = x < na;
+                        lo[k] = fromA ? na : 0u;                         // #elements of the other piece < (key, sa)
+                        hi[k] = fromA ? cnt : na;
                     }
-                    TL(rk, tid, k) = key;
-                    TL(rs, tid, k) = (idx_t)sa;
-                    TL(rd, tid, k) = (fromA ? x : x - na) + (lo - base);
+                }
+                lockstep_lower_bound<idx_t, BITS, LOCK_K>(P, n, skey, ssa, key, sa, lo, hi);
+                UNROLL
+                for (uint32_t k = 0; k < LOCK_K; ++k) {
+                    // slot = own rank + rank in the other piece = (x - na) + lo for both pieces
+                    // (from A: x + (lo - na); from B: (x - na) + lo; unsigned wrap-around is fine)
+                    TL(rk, tid, g + k) = key[k];
+                    TL(rs, tid, g + k) = sa[k];
+                    TL(rd, tid, g + k) = (tid + (g + k) * TILE_NT) - na + lo[k];
                 }
             }
         }

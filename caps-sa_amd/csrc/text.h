@@ -75,13 +75,13 @@ HD uint64_t pair_lcp(const uint32_t* __restrict__ P, uint64_t n, uint64_t ka, ui
     return deep_lcp<BITS>(P, n, a, b, TextTraits<BITS>::KCH);
 }
 
-// Strict total order on suffixes: true iff suffix a sorts before suffix b.
-// (a == b -> false.)  Shorter suffix first when one is a prefix of the other.
+// Order of two distinct suffixes whose KEYS are equal: continue in 64-bit windows of the
+// packed text (the rare path on low-LCP texts, the common one on repeats).  Inlined: a call
+// inside the merge kernels would force the registers that hold the prefetched next tile to
+// be spilled for the whole rank phase.
 template <int BITS>
-HD bool suffix_less(const uint32_t* __restrict__ P, uint64_t n, uint64_t ka, uint64_t a, uint64_t kb, uint64_t b)
+HD bool suffix_less_tie(const uint32_t* __restrict__ P, uint64_t n, uint64_t a, uint64_t b)
 {
-    if (ka != kb) return ka < kb;
-    if (a == b) return false;
     constexpr uint32_t KCH = TextTraits<BITS>::KCH;
     const uint64_t maxlen = n - (a > b ? a : b);
     for (uint64_t l = KCH; l < maxlen; l += KCH) {
@@ -89,6 +89,16 @@ HD bool suffix_less(const uint32_t* __restrict__ P, uint64_t n, uint64_t ka, uin
         if (wa != wb) return wa < wb;
     }
     return a > b;
+}
+
+// Strict total order on suffixes: true iff suffix a sorts before suffix b.
+// (a == b -> false.)  Shorter suffix first when one is a prefix of the other.
+template <int BITS>
+HD bool suffix_less(const uint32_t* __restrict__ P, uint64_t n, uint64_t ka, uint64_t a, uint64_t kb, uint64_t b)
+{
+    if (ka != kb) return ka < kb;
+    if (a == b) return false;
+    return suffix_less_tie<BITS>(P, n, a, b);
 }
 
 }  // namespace caps
