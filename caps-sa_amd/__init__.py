@@ -17,7 +17,8 @@ import numpy as np
 from ._binding import CapsLib, CapsSaError, Stats, Shard, ShardInfo, EXPORTS  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcaps_sa_hip.so")
+# CAPS_SA_LIB selects a tuning variant built by `make variant` (benchmarking only).
+LIB_PATH = os.environ.get("CAPS_SA_LIB") or os.path.join(_HERE, "libcaps_sa_hip.so")
 _lib: CapsLib | None = None
 
 

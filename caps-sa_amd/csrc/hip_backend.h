@@ -64,14 +64,15 @@ public:
     void d2h(void* h, const void* d, size_t bytes) { if (bytes) CAPS_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, stream)); }
     void d2d(void* d, const void* s, size_t bytes) { if (bytes) CAPS_HIP(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, stream)); }
     void sync() { CAPS_HIP(hipStreamSynchronize(stream)); }
-    // Grid of the persistent kernels: two 1024-thread workgroups per CU (LDS and thread limits).
+    // Grid of the persistent kernels: as many workgroups as are resident at once
+    // (CAPS_TILE_WAVES waves per SIMD = CAPS_TILE_WAVES * 256 / CAPS_TILE_NT workgroups per CU).
     uint32_t persistent_blocks()
     {
         if (!pblocks_) {
             int dev = 0, cus = 0;
             CAPS_HIP(hipGetDevice(&dev));
             CAPS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-            pblocks_ = (uint32_t)(cus > 0 ? cus : 256) * 2;
+            pblocks_ = (uint32_t)(cus > 0 ? cus : 256) * (CAPS_TILE_WAVES * 256 / CAPS_TILE_NT);
         }
         return pblocks_;
     }

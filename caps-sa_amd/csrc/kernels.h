@@ -27,14 +27,31 @@
 
 namespace caps {
 
-constexpr uint32_t TILE_E = 8192;      // elements per tile (one workgroup)
-constexpr uint32_t TILE_NT = 1024;     // threads per tile workgroup (16 waves)
+// Tile geometry (compile-time; -DCAPS_TILE_E=... etc. build the variants compared in
+// profiles/).  Default: 4096-element tiles, 1024 threads, two workgroups per CU
+// (LDS 48 KiB at 32-bit indices, 64 KiB at 64-bit; 8 waves per SIMD => 64 VGPRs).
+#ifndef CAPS_TILE_E
+#define CAPS_TILE_E 4096
+#endif
+#ifndef CAPS_TILE_NT
+#define CAPS_TILE_NT 1024
+#endif
+#ifndef CAPS_TILE_WAVES
+#define CAPS_TILE_WAVES 8          /* min waves per SIMD = workgroups per CU * CAPS_TILE_NT / 256 */
+#endif
+#ifndef CAPS_LOCK_K
+#define CAPS_LOCK_K 4              /* binary searches one thread advances in lockstep */
+#endif
+constexpr uint32_t TILE_E = CAPS_TILE_E;       // elements per tile (one workgroup)
+constexpr uint32_t TILE_NT = CAPS_TILE_NT;     // threads per tile workgroup
 constexpr uint32_t TILE_EPT = TILE_E / TILE_NT;
-// One 1024-thread workgroup per CU (LDS: 96 KiB of keys + indices at 32-bit indices, 128 KiB at
-// 64-bit): 4 waves per SIMD, i.e. a budget of 128 VGPRs -- room for the registers that hold the
-// prefetched next tile next to 8 binary searches advanced in lockstep.
-#define TILE_WAVES_PER_SIMD 4
-constexpr uint32_t LOCK_K = 4;         // binary searches a thread advances in lockstep
+constexpr uint32_t LOCK_K = CAPS_LOCK_K < TILE_EPT ? CAPS_LOCK_K : TILE_EPT;
+#define TILE_WAVES_PER_SIMD CAPS_TILE_WAVES
+#ifdef CAPS_NO_WAVES_BOUND   /* experiment: let the compiler pick the register budget */
+#undef LAUNCH_BOUNDS2
+#define LAUNCH_BOUNDS2(n, w) LAUNCH_BOUNDS(n)
+#endif
+static_assert(TILE_E % TILE_NT == 0 && TILE_EPT % LOCK_K == 0, "tile geometry");
 
 // Segment/tile descriptor shared by the tile-granular kernels.
 struct SegDesc {
@@ -256,30 +273,44 @@ GLOBAL_FN LAUNCH_BOUNDS(256) tile_map_kernel(KCTX const uint32_t* __restrict__ t
 }
 
 
-// K independent lower-bound searches over LDS-resident (key, sa) runs, advanced in lockstep
-// so that the K dependent LDS reads of one step are in flight together (a single search is a
-// chain of ~12 dependent ds_read latencies).  lo[k] < hi[k] delimits search k; on return
-// lo[k] = index of the first element of [lo, hi) that is not < (key[k], sa[k]).
+// K independent lower-bound searches over LDS-resident sorted (key, sa) runs:
+// on return lo[k] = lo[k] + #{elements of [lo[k], hi[k]) that are < (key[k], sa[k])}.
+//
+// The hot part is branch-free and runs a FIXED number of steps (log2(top), top = a power of
+// two > the longest range, block-uniform): step s probes element lo + s - 1 and advances by
+// s when it is smaller.  The K probes of a step are independent, so their LDS reads are in
+// flight together.  Only keys are compared there (equal key = "not smaller"); a suffix whose
+// key also occurs in the range finishes with the exact comparator over the remaining
+// candidates -- never on random DNA, routinely on repeats.
 template <typename idx_t, int BITS, int K>
-DEV_INLINE void lockstep_lower_bound(const uint32_t* __restrict__ P, uint64_t n, const uint64_t* skey, const idx_t* ssa,
-                                     const uint64_t (&key)[K], const idx_t (&sa)[K], uint32_t (&lo)[K], uint32_t (&hi)[K])
+DEV_INLINE void multi_lower_bound(const uint32_t* __restrict__ P, uint64_t n, const uint64_t* skey, const idx_t* ssa,
+                                  const uint64_t (&key)[K], const idx_t (&sa)[K], uint32_t (&lo)[K], const uint32_t (&hi)[K],
+                                  uint32_t top)
 {
-    bool any = true;
-    while (any) {
-        any = false;
+    for (uint32_t s = top >> 1; s >= 1; s >>= 1) {
         UNROLL
         for (int k = 0; k < K; ++k) {
-            if (lo[k] < hi[k]) {
-                const uint32_t mid = (lo[k] + hi[k]) >> 1;
-                const uint64_t mk = skey[mid];
-                bool less = mk < key[k];
-                if (mk == key[k]) less = suffix_less<BITS>(P, n, mk, (uint64_t)ssa[mid], key[k], (uint64_t)sa[k]);
-                if (less) lo[k] = mid + 1; else hi[k] = mid;
-                any |= lo[k] < hi[k];
+            const uint32_t idx = lo[k] + s - 1;
+            const uint64_t mk = skey[idx < TILE_E ? idx : TILE_E - 1];
+            if (idx < hi[k] && mk < key[k]) lo[k] += s;
+        }
+    }
+    UNROLL
+    for (int k = 0; k < K; ++k) {
+        if (lo[k] < hi[k] && skey[lo[k]] == key[k]) {              // key tie: exact order among [lo, hi)
+            uint32_t a = lo[k], b = hi[k];
+            while (a < b) {
+                const uint32_t mid = (a + b) >> 1;
+                if (suffix_less<BITS>(P, n, skey[mid], (uint64_t)ssa[mid], key[k], (uint64_t)sa[k])) a = mid + 1;
+                else b = mid;
             }
+            lo[k] = a;
         }
     }
 }
+
+// smallest power of two strictly greater than x (x < 2^31)
+HD uint32_t pow2_above(uint32_t x) { return 1u << (32 - (x ? __builtin_clz(x) : 32)); }
 
 // ----------------------------------------------------------------------------------
 // a4/a5: tile sort -- one workgroup sorts up to TILE_E suffixes in LDS and emits the
@@ -294,7 +325,7 @@ DEV_INLINE void lockstep_lower_bound(const uint32_t* __restrict__ P, uint64_t n,
 // by a binary search in the sibling run (rank merge): no divergent serial merge,
 // ragged runs need no padding.  LCPs are produced once, at the end, from adjacent
 // keys (text only on equal keys).
-// LDS: 8192 x (8 + sizeof(idx_t)) = 96/128 KiB -> one workgroup (16 waves) per CU.
+// LDS: TILE_E x (8 + sizeof(idx_t)).
 // ----------------------------------------------------------------------------------
 template <typename idx_t, int BITS, bool FROM_TEXT>
 GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
@@ -358,7 +389,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
                         dbase[k] = (run & ~1u) * R + (e - run * R) - sib_start;
                     }
                 }
-                lockstep_lower_bound<idx_t, BITS, LOCK_K>(P, n, skey, ssa, key, sa, lo, hi);
+                multi_lower_bound<idx_t, BITS, LOCK_K>(P, n, skey, ssa, key, sa, lo, hi, 2 * R);
                 UNROLL
                 for (uint32_t k = 0; k < LOCK_K; ++k) {
                     TL(rk, tid, g + k) = key[k];
@@ -528,6 +559,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) merge_pass_kernel(KCTX co
     }
     while (true) {
         const uint32_t na = d.na, cnt = d.na + d.nb;
+        const uint32_t top = pow2_above(d.na > d.nb ? d.na : d.nb);      // search depth of this tile
         PAR(tid) {
             UNROLL
             for (uint32_t k = 0; k < TILE_EPT; ++k) {
@@ -573,7 +605,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) merge_pass_kernel(KCTX co
                         hi[k] = fromA ? cnt : na;
                     }
                 }
-                lockstep_lower_bound<idx_t, BITS, LOCK_K>(P, n, skey, ssa, key, sa, lo, hi);
+                multi_lower_bound<idx_t, BITS, LOCK_K>(P, n, skey, ssa, key, sa, lo, hi, top);
                 UNROLL
                 for (uint32_t k = 0; k < LOCK_K; ++k) {
                     // slot = own rank + rank in the other piece = (x - na) + lo for both pieces
