@@ -226,14 +226,16 @@ int sort_suffixes(const char* T, uint64_t n, const idx_t* idx, uint64_t cnt, idx
         const uint32_t g = (uint32_t)((cnt + 255) / 256);
         if (t.bits == 2) {
             CAPS_LAUNCH((make_keys_kernel<idx_t, 2>), g, 256, be, (const uint32_t*)t.P, (const idx_t*)a.sa, cnt, a.key);
-            SortResult<idx_t> r = segmented_sort<idx_t, 2>(be, t.P, n, desc, s, tiles_of(cnt), cnt, false, a, b, cnt, true, false,
-                                                           nullptr, nullptr);
-            finalize<idx_t, 2>(be, t.P, n, s, tiles_of(cnt), r, osa, olcp);
+            SortOpts o;
+            o.need_lcp = true;
+            SortResult<idx_t> r = segmented_sort<idx_t, 2>(be, t.P, n, desc, s, tiles_of(cnt), cnt, a, b, cnt, o);
+            finalize<idx_t, 2>(be, t.P, n, r, osa, olcp);
         } else {
             CAPS_LAUNCH((make_keys_kernel<idx_t, 8>), g, 256, be, (const uint32_t*)t.P, (const idx_t*)a.sa, cnt, a.key);
-            SortResult<idx_t> r = segmented_sort<idx_t, 8>(be, t.P, n, desc, s, tiles_of(cnt), cnt, false, a, b, cnt, true, false,
-                                                           nullptr, nullptr);
-            finalize<idx_t, 8>(be, t.P, n, s, tiles_of(cnt), r, osa, olcp);
+            SortOpts o;
+            o.need_lcp = true;
+            SortResult<idx_t> r = segmented_sort<idx_t, 8>(be, t.P, n, desc, s, tiles_of(cnt), cnt, a, b, cnt, o);
+            finalize<idx_t, 8>(be, t.P, n, r, osa, olcp);
         }
         be.d2h(out_sa, osa, cnt * sizeof(idx_t));
         be.d2h(out_lcp, olcp, cnt * sizeof(idx_t));
@@ -283,14 +285,18 @@ int sort_segments(const char* T, uint64_t n, const idx_t* idx, uint64_t cnt, con
         const uint32_t g = (uint32_t)((cnt + 255) / 256);
         if (t.bits == 2) {
             CAPS_LAUNCH((make_keys_kernel<idx_t, 2>), g, 256, be, (const uint32_t*)t.P, (const idx_t*)a.sa, cnt, a.key);
-            SortResult<idx_t> r = segmented_sort<idx_t, 2>(be, t.P, n, desc, s, (uint32_t)n_tiles, max_len, false, a, b, cnt, true,
-                                                           true, nullptr, nullptr);
-            finalize<idx_t, 2>(be, t.P, n, s, (uint32_t)n_tiles, r, osa, olcp);
+            SortOpts o;
+            o.need_lcp = true;
+            o.skip_finished = true;
+            SortResult<idx_t> r = segmented_sort<idx_t, 2>(be, t.P, n, desc, s, (uint32_t)n_tiles, max_len, a, b, cnt, o);
+            finalize<idx_t, 2>(be, t.P, n, r, osa, olcp);
         } else {
             CAPS_LAUNCH((make_keys_kernel<idx_t, 8>), g, 256, be, (const uint32_t*)t.P, (const idx_t*)a.sa, cnt, a.key);
-            SortResult<idx_t> r = segmented_sort<idx_t, 8>(be, t.P, n, desc, s, (uint32_t)n_tiles, max_len, false, a, b, cnt, true,
-                                                           true, nullptr, nullptr);
-            finalize<idx_t, 8>(be, t.P, n, s, (uint32_t)n_tiles, r, osa, olcp);
+            SortOpts o;
+            o.need_lcp = true;
+            o.skip_finished = true;
+            SortResult<idx_t> r = segmented_sort<idx_t, 8>(be, t.P, n, desc, s, (uint32_t)n_tiles, max_len, a, b, cnt, o);
+            finalize<idx_t, 8>(be, t.P, n, r, osa, olcp);
         }
         be.d2h(out_sa, osa, cnt * sizeof(idx_t));
         be.d2h(out_lcp, olcp, cnt * sizeof(idx_t));

@@ -45,6 +45,11 @@ namespace caps { struct EmulCtx { uint32_t block_idx, grid_dim, block_dim; }; }
 #define ATOMIC_ADD_U64(ptr, v) (*(ptr) += (v))
 #define ATOMIC_ADD_LDS_U64(ptr, v) (*(ptr) += (v))
 #define ATOMIC_MAX_U64(ptr, v) (*(ptr) = std::max<uint64_t>(*(ptr), (v)))
+static inline uint32_t caps_fetch_add_u32(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
+static inline uint64_t caps_fetch_add_u64(uint64_t* p, uint64_t v) { const uint64_t o = *p; *p = o + v; return o; }
+#define FETCH_ADD_U32(ptr, v) caps_fetch_add_u32((ptr), (v))      /* returns the old value */
+#define FETCH_ADD_U64(ptr, v) caps_fetch_add_u64((ptr), (v))
+static inline uint64_t caps_umul64hi(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
 static inline int caps_clz64(uint64_t x) { return __builtin_clzll(x); }
 static inline uint32_t caps_bswap32(uint32_t x) { return __builtin_bswap32(x); }
 #else
@@ -70,6 +75,9 @@ static inline uint32_t caps_bswap32(uint32_t x) { return __builtin_bswap32(x); }
 #define ATOMIC_ADD_U64(ptr, v) atomicAdd((unsigned long long*)(ptr), (unsigned long long)(v))
 #define ATOMIC_ADD_LDS_U64(ptr, v) atomicAdd((unsigned long long*)(ptr), (unsigned long long)(v))
 #define ATOMIC_MAX_U64(ptr, v) atomicMax((unsigned long long*)(ptr), (unsigned long long)(v))
+#define FETCH_ADD_U32(ptr, v) atomicAdd((ptr), (v))                 /* returns the old value (LDS or global) */
+#define FETCH_ADD_U64(ptr, v) ((uint64_t)atomicAdd((unsigned long long*)(ptr), (unsigned long long)(v)))
+static __device__ __forceinline__ uint64_t caps_umul64hi(uint64_t a, uint64_t b) { return __umul64hi(a, b); }
 static __host__ __device__ __forceinline__ int caps_clz64(uint64_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __clzll((long long)x);

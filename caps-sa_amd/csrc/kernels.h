@@ -714,6 +714,217 @@ GLOBAL_FN LAUNCH_BOUNDS(256) finalize_kernel(KCTX SegDesc sd, const uint32_t* __
 }
 
 // ----------------------------------------------------------------------------------
+// Bucketing inside a sort (a4/a10): before the tile sort, every segment longer than a tile
+// is split by KEY RANGE into B = ceil(len / BUCKET_TARGET) buckets; bucket(key) is a
+// monotone map of the key (linear interpolation between the segment's smallest and largest
+// possible key), so the buckets are consecutive slices of the sorted segment and become the
+// segments of the tile sort.  On keys that are roughly uniform inside their range (random
+// DNA: exactly) every bucket fits one tile and the segment needs NO merge pass -- two
+// streaming passes (count, scatter) replace log2(len / TILE_E) merge passes.  Buckets that
+// come out larger than a tile (skewed or repetitive text) are finished by the LCP-merge
+// passes, which only touch those buckets (skip_finished).
+//
+//   bucket_plan_kernel     per segment: B, range normalisation (kmin, shift, Bq)
+//   bucket_count_kernel    per element: ++count[bucket]      (LDS histogram per tile when B <= BUCKET_LDS)
+//   bucket_scatter_kernel  per element: slot = start[bucket] + cursor[bucket]++  (same aggregation)
+//   unify_kernel           copies the (few) buckets whose last pass ended in the other ping-pong
+//                          buffer back, for consumers that index a segment as one array
+// ----------------------------------------------------------------------------------
+constexpr uint32_t BUCKET_TARGET = (TILE_E * 5) / 8;   // mean bucket size: leaves 37 % headroom in a tile
+constexpr uint32_t BUCKET_LDS = 4096;                  // buckets per segment the LDS histogram can hold
+
+struct BucketParams {        // per parent segment
+    uint64_t kmin;           // smallest key of the segment's range
+    uint64_t bq;             // bucket = mulhi((key - kmin) << shift, bq), clamped to B - 1
+    uint32_t shift;
+    uint32_t B;
+};
+
+DEV_INLINE uint32_t bucket_of(const BucketParams& bp, uint64_t key)
+{
+    if (bp.B <= 1) return 0;
+    if (key <= bp.kmin) return 0;
+    const uint64_t d = key - bp.kmin;
+    if (bp.shift && (d >> (64 - bp.shift))) return bp.B - 1;          // above the nominal range
+    const uint64_t b = caps_umul64hi(d << bp.shift, bp.bq);
+    return b < bp.B ? (uint32_t)b : bp.B - 1;
+}
+
+// range_mode 0: keys span the whole 64-bit range (subarrays of text positions);
+// range_mode 1: segment g holds keys in [pkey[g-1], pkey[g]] (partitions between pivots).
+GLOBAL_FN LAUNCH_BOUNDS(256) bucket_plan_kernel(KCTX const uint64_t* __restrict__ seg_start, uint32_t G, uint32_t range_mode,
+                                                const uint64_t* __restrict__ pkey, uint32_t enable,
+                                                BucketParams* __restrict__ bp, uint64_t* __restrict__ segB)
+{
+    PAR(tid) {
+        const uint32_t g = K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (g < G) {
+            const uint64_t len = seg_start[g + 1] - seg_start[g];
+            uint64_t kmin = 0, kmax = ~0ull;
+            if (range_mode == 1) {
+                if (g > 0) kmin = pkey[g - 1];
+                if (g + 1 < G) kmax = pkey[g];
+            }
+            uint32_t B = 1;
+            if (enable && len > TILE_E && kmax > kmin) B = (uint32_t)((len + BUCKET_TARGET - 1) / BUCKET_TARGET);
+            BucketParams q;
+            q.kmin = kmin;
+            q.B = B;
+            const uint64_t range = kmax - kmin;
+            q.shift = range ? (uint32_t)caps_clz64(range) : 0u;
+            const double rs = (double)(range << q.shift) + 1.0;                 // in [2^63, 2^64]
+            const double f = (double)B * 18446744073709551616.0 / rs;           // in [B, 2B]
+            q.bq = (uint64_t)f;
+            bp[g] = q;
+            segB[g] = B;
+        }
+    }
+}
+
+// Key of element i of a segment array: cut from the packed text (phase 1: element i of the
+// array is text position text_base + i) or read from the key array.
+template <typename idx_t, int BITS, bool FROM_TEXT>
+DEV_INLINE uint64_t elem_key(const uint32_t* __restrict__ P, uint64_t text_base, const uint64_t* __restrict__ in_key, uint64_t i)
+{
+    if (FROM_TEXT) return window64<BITS>(P, text_base + i);
+    return in_key[i];
+}
+
+template <typename idx_t, int BITS, bool FROM_TEXT>
+GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_count_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t text_base,
+                                                     const uint64_t* __restrict__ in_key, const BucketParams* __restrict__ bps,
+                                                     const uint64_t* __restrict__ bstart, uint64_t* __restrict__ count)
+{
+    const uint32_t b = K_BLOCK_IDX;
+    if (b >= sd.tile_off[sd.G]) return;
+    const uint32_t g = sd.tile_seg[b];
+    const TileInfo t = tile_info(sd, b);
+    const uint64_t start = t.s0 + (uint64_t)t.tl * TILE_E;
+    const uint32_t cnt = (uint32_t)(t.s1 - start < TILE_E ? t.s1 - start : TILE_E);
+    const BucketParams bp = bps[g];
+    const uint64_t b0 = bstart[g];
+    SHARED_ARRAY(uint32_t, hist, BUCKET_LDS);
+    if (bp.B == 1) {                                   // the segment is its own bucket
+        PAR(tid) { if (tid == 0) ATOMIC_ADD_U64(&count[b0], (uint64_t)cnt); }
+        return;
+    }
+    const bool lds = bp.B <= BUCKET_LDS;
+    if (lds) {
+        PAR(tid) { for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM) hist[i] = 0; }
+        SYNC();
+    }
+    PAR(tid) {
+        UNROLL
+        for (uint32_t k = 0; k < TILE_EPT; ++k) {
+            const uint32_t e = tid + k * TILE_NT;
+            if (e < cnt) {
+                const uint32_t bk = bucket_of(bp, elem_key<idx_t, BITS, FROM_TEXT>(P, text_base, in_key, start + e));
+                if (lds) FETCH_ADD_U32(&hist[bk], 1u);
+                else ATOMIC_ADD_U64(&count[b0 + bk], 1ull);
+            }
+        }
+    }
+    if (lds) {
+        SYNC();
+        PAR(tid) {
+            for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM)
+                if (hist[i]) ATOMIC_ADD_U64(&count[b0 + i], (uint64_t)hist[i]);
+        }
+    }
+}
+
+// sub_start[NB+1] = exclusive scan of count (absolute element offsets of the buckets);
+// cursor[NB] starts at 0.
+template <typename idx_t, int BITS, bool FROM_TEXT>
+GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t text_base,
+                                                       const uint64_t* __restrict__ in_key, const idx_t* __restrict__ in_sa,
+                                                       const BucketParams* __restrict__ bps, const uint64_t* __restrict__ bstart,
+                                                       const uint64_t* __restrict__ sub_start, uint32_t* __restrict__ cursor,
+                                                       uint64_t* __restrict__ out_key, idx_t* __restrict__ out_sa)
+{
+    const uint32_t b = K_BLOCK_IDX;
+    if (b >= sd.tile_off[sd.G]) return;
+    const uint32_t g = sd.tile_seg[b];
+    const TileInfo t = tile_info(sd, b);
+    const uint64_t start = t.s0 + (uint64_t)t.tl * TILE_E;
+    const uint32_t cnt = (uint32_t)(t.s1 - start < TILE_E ? t.s1 - start : TILE_E);
+    const BucketParams bp = bps[g];
+    const uint64_t b0 = bstart[g];
+    SHARED_ARRAY(uint32_t, hist, BUCKET_LDS);
+    TL_DECL(uint64_t, rk, TILE_EPT);
+    TL_DECL(idx_t, rs, TILE_EPT);
+    TL_DECL(uint32_t, rb, TILE_EPT);      // bucket
+    TL_DECL(uint32_t, rr, TILE_EPT);      // rank inside (tile, bucket) or inside the bucket
+    const bool lds = bp.B > 1 && bp.B <= BUCKET_LDS;
+    if (lds) {
+        PAR(tid) { for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM) hist[i] = 0; }
+        SYNC();
+    }
+    PAR(tid) {
+        UNROLL
+        for (uint32_t k = 0; k < TILE_EPT; ++k) {
+            const uint32_t e = tid + k * TILE_NT;
+            if (e < cnt) {
+                const uint64_t key = elem_key<idx_t, BITS, FROM_TEXT>(P, text_base, in_key, start + e);
+                const idx_t sa = FROM_TEXT ? (idx_t)(text_base + start + e) : in_sa[start + e];
+                uint32_t bk = 0, r;
+                if (bp.B == 1) r = (uint32_t)(start - t.s0) + e;             // identity: the segment is its own bucket
+                else {
+                    bk = bucket_of(bp, key);
+                    r = lds ? FETCH_ADD_U32(&hist[bk], 1u) : FETCH_ADD_U32(&cursor[b0 + bk], 1u);
+                }
+                TL(rk, tid, k) = key;
+                TL(rs, tid, k) = sa;
+                TL(rb, tid, k) = bk;
+                TL(rr, tid, k) = r;
+            }
+        }
+    }
+    if (lds) {
+        SYNC();
+        PAR(tid) {                                         // one global cursor bump per (tile, non-empty bucket)
+            for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM) {
+                const uint32_t c = hist[i];
+                if (c) hist[i] = FETCH_ADD_U32(&cursor[b0 + i], c);
+            }
+        }
+        SYNC();
+    }
+    PAR(tid) {
+        UNROLL
+        for (uint32_t k = 0; k < TILE_EPT; ++k) {
+            const uint32_t e = tid + k * TILE_NT;
+            if (e < cnt) {
+                const uint32_t bk = TL(rb, tid, k);
+                const uint64_t dst = sub_start[b0 + bk] + (lds ? hist[bk] : 0u) + TL(rr, tid, k);
+                out_key[dst] = TL(rk, tid, k);
+                out_sa[dst] = TL(rs, tid, k);
+            }
+        }
+    }
+}
+
+// Moves every bucket whose data ended in ping-pong buffer 1 (odd number of merge passes) back
+// into buffer 0, so that a parent segment is one sorted array again.
+template <typename idx_t>
+GLOBAL_FN LAUNCH_BOUNDS(256) unify_kernel(KCTX SegDesc sd, const uint64_t* __restrict__ key1, const idx_t* __restrict__ sa1,
+                                          uint64_t* __restrict__ key0, idx_t* __restrict__ sa0)
+{
+    const uint32_t b = K_BLOCK_IDX;
+    if (b >= sd.tile_off[sd.G]) return;
+    const TileInfo t = tile_info(sd, b);
+    if ((passes_for(t.s1 - t.s0) & 1u) == 0) return;
+    const uint64_t start = t.s0 + (uint64_t)t.tl * TILE_E;
+    const uint32_t cnt = (uint32_t)(t.s1 - start < TILE_E ? t.s1 - start : TILE_E);
+    PAR(tid) {
+        for (uint32_t e = tid; e < cnt; e += K_BLOCK_DIM) {
+            key0[start + e] = key1[start + e];
+            sa0[start + e] = sa1[start + e];
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------
 // a6: samples and pivots (reference: sample_pivots/select_pivots, cpp:187-222).
 // Unlike the reference's truncated gap (cpp:191: the top of every subarray is never
 // sampled), sample k sits at the CENTRE of the k-th of ppp equal slices of the

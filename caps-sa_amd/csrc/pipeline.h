@@ -61,6 +61,19 @@ struct SegBufs {
 
 constexpr uint32_t kMaxPasses = 96;
 
+// Scratch of the bucketing stage of one sort (kernels.h "Bucketing inside a sort").
+struct BucketBufs {
+    BucketParams* params = nullptr;   // [G]
+    uint64_t* segB = nullptr;         // [G]    buckets per parent segment
+    uint64_t* bstart = nullptr;       // [G+1]  exclusive scan of segB
+    uint64_t* count = nullptr;        // [nb_cap] elements per bucket
+    uint32_t* cursor = nullptr;       // [nb_cap]
+    SegBufs sub;                      // the buckets as segments (G = nb_cap, trailing ones empty)
+    uint32_t nb_cap = 0;
+    uint64_t tile_cap = 0;
+    static uint32_t bucket_bound(uint64_t n_elems, uint32_t G) { return (uint32_t)(n_elems / BUCKET_TARGET + G + 1); }
+};
+
 template <typename idx_t> struct Plan {
     uint64_t n = 0;
     uint32_t p = 0;          // effective subproblem count (0/1 -> single segment)
@@ -76,6 +89,7 @@ template <typename idx_t> struct Plan {
     uint64_t* sizes = nullptr;
     SegBufs seg1, seg2, segS;
     TileDesc* desc = nullptr;        // [tile_cap] per-pass tile descriptors
+    BucketBufs bk;                   // bucketing scratch (shared by phase 1 and phase 2)
     uint64_t* pass_elems = nullptr;  // [kMaxPasses] elements merged by each timed pass
     uint32_t* present = nullptr;     // [8]
     uint8_t* lut = nullptr;          // [256]
@@ -107,7 +121,9 @@ Plan<idx_t> make_plan(uint64_t n, uint64_t p_arg, char* base)
     const bool split = pl.p >= 2;
     const uint32_t p = split ? pl.p : 1;
     pl.m = split ? (uint64_t)p * pl.ppp : 0;
-    pl.tile_cap = nn / TILE_E + p + 2;
+    pl.bk.nb_cap = BucketBufs::bucket_bound(nn, p);
+    pl.bk.tile_cap = nn / TILE_E + pl.bk.nb_cap + 2;
+    pl.tile_cap = pl.bk.tile_cap;
     pl.P = ar.take<uint32_t>(packed_words(nn, 8));
     for (ElemBuf<idx_t>* b : {&pl.A, &pl.B}) {
         b->key = ar.take<uint64_t>(nn);
@@ -137,6 +153,12 @@ Plan<idx_t> make_plan(uint64_t n, uint64_t p_arg, char* base)
         segs(pl.segS, 1, pl.m / TILE_E + 3);
     }
     pl.desc = ar.take<TileDesc>(pl.tile_cap + 1);
+    pl.bk.params = ar.take<BucketParams>(p);
+    pl.bk.segB = ar.take<uint64_t>(p);
+    pl.bk.bstart = ar.take<uint64_t>((size_t)p + 1);
+    pl.bk.count = ar.take<uint64_t>(pl.bk.nb_cap);
+    pl.bk.cursor = ar.take<uint32_t>(pl.bk.nb_cap);
+    segs(pl.bk.sub, pl.bk.nb_cap, pl.bk.tile_cap);
     pl.pass_elems = ar.take<uint64_t>(kMaxPasses);
     pl.present = ar.take<uint32_t>(8);
     pl.lut = ar.take<uint8_t>(256);
@@ -209,7 +231,10 @@ template <typename idx_t> struct SortResult {
     ElemBuf<idx_t> buf[2];
     uint32_t passes = 0;
     bool skip_finished = false;
-    ElemBuf<idx_t> uniform() const { return buf[passes & 1]; }      // valid when !skip_finished
+    bool unified = false;                                             // everything was gathered into buf[0]
+    SegBufs segs;                                                     // the segments that were sorted (buckets, if bucketed)
+    uint32_t n_tiles = 0;
+    ElemBuf<idx_t> uniform() const { return unified ? buf[0] : buf[passes & 1]; }   // valid when unified or !skip_finished
     PingPong<idx_t> pingpong() const
     {
         PingPong<idx_t> pp;
@@ -218,55 +243,123 @@ template <typename idx_t> struct SortResult {
     }
 };
 
-// Sort every segment: tile sort (in place on `cur`; FROM_TEXT: cut from the packed text)
-// + merge passes ping-ponging between cur and oth.
-//   need_lcp       LCPs are emitted by the step that completes each segment
-//   skip_finished  segments that are already one run sit out the remaining passes
+// Options of one segmented sort.
+struct SortOpts {
+    bool from_text = false;       // elements are consecutive text positions (keys cut from the packed text)
+    uint64_t text_base = 0;       // element i of the arrays = text position text_base + i
+    bool need_lcp = false;        // emit LCPs (by the step that completes each segment)
+    bool skip_finished = false;   // finished segments sit out later passes (result spread over both buffers)
+    const BucketBufs* bk = nullptr;   // non-null: split long segments into key-range buckets first
+    uint32_t range_mode = 0;      // bucket_plan_kernel: 0 full key range, 1 between pivots
+    const uint64_t* pkey = nullptr;
+    bool unify = false;           // gather the result into buf[0] (consumers that index whole segments)
+    KernelClock* tile_clock = nullptr;
+    KernelClock* merge_clock = nullptr;
+    uint64_t* pass_counters = nullptr;
+};
+
+// Sort every segment of `s`:  [bucket split]  ->  tile sort  ->  LCP-merge passes.
+//   not bucketed: input (unless from_text) is in `cur`, sorted in place, passes ping-pong cur <-> oth;
+//   bucketed:     input (unless from_text) is in `cur`, scattered by bucket into `oth`, which then
+//                 plays the role of `cur`; the buckets become the segments (result.segs).
+// n_tiles / max_len describe `s` (host-known for phase 1 and the samples, read back for phase 2).
 template <typename idx_t, int BITS>
-SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, TileDesc* desc, const SegBufs& s,
-                                 uint32_t n_tiles, uint64_t max_len, bool from_text, ElemBuf<idx_t> cur, ElemBuf<idx_t> oth,
-                                 uint64_t n_elems, bool need_lcp, bool skip_finished, KernelClock* tile_clock,
-                                 KernelClock* merge_clock, uint64_t text_base = 0, uint64_t* pass_counters = nullptr)
+SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, TileDesc* desc, const SegBufs& s, uint32_t n_tiles,
+                                 uint64_t max_len, ElemBuf<idx_t> cur, ElemBuf<idx_t> oth, uint64_t n_elems, const SortOpts& o)
 {
     SortResult<idx_t> r;
     r.buf[0] = cur;
     r.buf[1] = oth;
-    r.skip_finished = skip_finished;
+    r.skip_finished = o.skip_finished;
+    r.segs = s;
+    r.n_tiles = n_tiles;
     if (n_tiles == 0) return r;
-    const SegDesc sd = s.desc();
-    const uint32_t lcp_mode = need_lcp ? 1u : 0u;
+    bool from_text = o.from_text;
+    SegBufs segs = s;
+    bool skip = o.skip_finished;
+    if (o.bk && max_len > TILE_E) {
+        const BucketBufs& bk = *o.bk;
+        const SegDesc psd = s.desc();
+        CAPS_LAUNCH(bucket_plan_kernel, (s.G + 255) / 256, 256, be, (const uint64_t*)s.seg_start, s.G, o.range_mode, o.pkey, 1u,
+                    bk.params, bk.segB);
+        CAPS_LAUNCH(scan_sizes_kernel, 1, 1024, be, (const uint64_t*)bk.segB, s.G, bk.bstart);
+        be.memset(bk.count, 0, (size_t)bk.nb_cap * sizeof(uint64_t));
+        be.memset(bk.cursor, 0, (size_t)bk.nb_cap * sizeof(uint32_t));
+        ElemBuf<idx_t> dst = from_text ? cur : oth;
+        if (from_text) {
+            CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, psd, P, o.text_base, (const uint64_t*)nullptr,
+                        (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, bk.count);
+            CAPS_LAUNCH(scan_sizes_kernel, 1, 1024, be, (const uint64_t*)bk.count, bk.nb_cap, bk.sub.seg_start);
+            CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, psd, P, o.text_base, (const uint64_t*)nullptr,
+                        (const idx_t*)nullptr, (const BucketParams*)bk.params, (const uint64_t*)bk.bstart,
+                        (const uint64_t*)bk.sub.seg_start, bk.cursor, dst.key, dst.sa);
+        } else {
+            CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, psd, P, (uint64_t)0, (const uint64_t*)cur.key,
+                        (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, bk.count);
+            CAPS_LAUNCH(scan_sizes_kernel, 1, 1024, be, (const uint64_t*)bk.count, bk.nb_cap, bk.sub.seg_start);
+            CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, psd, P, (uint64_t)0, (const uint64_t*)cur.key,
+                        (const idx_t*)cur.sa, (const BucketParams*)bk.params, (const uint64_t*)bk.bstart,
+                        (const uint64_t*)bk.sub.seg_start, bk.cursor, dst.key, dst.sa);
+            std::swap(cur, oth);                         // the scattered copy is the working buffer now
+            r.buf[0] = cur;
+            r.buf[1] = oth;
+        }
+        // the buckets are the segments from here on (trailing unused ones are empty)
+        segs = bk.sub;
+        segs.G = bk.nb_cap;
+        prepare_segments(be, segs, bk.tile_cap);
+        uint64_t out2[2];
+        be.d2h(out2, segs.out2, sizeof out2);
+        be.sync();
+        n_tiles = (uint32_t)out2[0];
+        max_len = out2[1];
+        from_text = false;
+        skip = true;
+        r.skip_finished = true;
+        r.segs = segs;
+        r.n_tiles = n_tiles;
+    }
+    const SegDesc sd = segs.desc();
+    const uint32_t lcp_mode = o.need_lcp ? 1u : 0u;
     BackendEvent t0 = be.record();
     if (from_text)
-        CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, sd, P, n, text_base, lcp_mode,
+        CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, sd, P, n, o.text_base, lcp_mode,
                     (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp);
     else
         CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode,
                     (const uint64_t*)cur.key, (const idx_t*)cur.sa, cur.key, cur.sa, cur.lcp);
     BackendEvent t1 = be.record();
-    if (tile_clock) { tile_clock->spans.push_back({t0, t1}); tile_clock->elems.push_back(n_elems); }
+    if (o.tile_clock) { o.tile_clock->spans.push_back({t0, t1}); o.tile_clock->elems.push_back(n_elems); }
     const uint32_t grid = n_tiles < be.persistent_blocks() ? n_tiles : be.persistent_blocks();
+    ElemBuf<idx_t> a = cur, b = oth;
     for (uint64_t R = TILE_E; R < max_len; R *= 2) {
-        CAPS_LAUNCH((merge_partition_kernel<idx_t, BITS>), (n_tiles + 255) / 256, 256, be, sd, P, n, R, ~0ull,
-                    skip_finished ? 1u : 0u, lcp_mode, (const uint64_t*)cur.key, (const idx_t*)cur.sa, desc,
-                    pass_counters ? pass_counters + r.passes : (uint64_t*)nullptr);
+        CAPS_LAUNCH((merge_partition_kernel<idx_t, BITS>), (n_tiles + 255) / 256, 256, be, sd, P, n, R, ~0ull, skip ? 1u : 0u,
+                    lcp_mode, (const uint64_t*)a.key, (const idx_t*)a.sa, desc,
+                    o.pass_counters ? o.pass_counters + r.passes : (uint64_t*)nullptr);
         BackendEvent m0 = be.record();
         CAPS_LAUNCH((merge_pass_kernel<idx_t, BITS>), grid, TILE_NT, be, (const TileDesc*)desc, n_tiles, P, n,
-                    (const uint64_t*)cur.key, (const idx_t*)cur.sa, oth.key, oth.sa, oth.lcp);
+                    (const uint64_t*)a.key, (const idx_t*)a.sa, b.key, b.sa, b.lcp);
         BackendEvent m1 = be.record();
-        if (merge_clock) { merge_clock->spans.push_back({m0, m1}); merge_clock->elems.push_back(n_elems); }
-        std::swap(cur, oth);
+        if (o.merge_clock) { o.merge_clock->spans.push_back({m0, m1}); o.merge_clock->elems.push_back(n_elems); }
+        std::swap(a, b);
         ++r.passes;
+    }
+    if (o.unify && r.skip_finished && r.passes) {
+        CAPS_LAUNCH((unify_kernel<idx_t>), n_tiles, 256, be, sd, (const uint64_t*)r.buf[1].key, (const idx_t*)r.buf[1].sa,
+                    r.buf[0].key, r.buf[0].sa);
+        r.unified = true;
+    } else if (o.unify && r.skip_finished) {
+        r.unified = true;                                 // no pass ran: everything is in buf[0]
     }
     return r;
 }
 
 // Gather SA/LCP of a sorted segment set into the caller's arrays + segment-head LCPs (a11).
 template <typename idx_t, int BITS>
-void finalize(Backend& be, const uint32_t* P, uint64_t n, const SegBufs& s, uint32_t n_tiles, const SortResult<idx_t>& r,
-              idx_t* dSA, idx_t* dLCP)
+void finalize(Backend& be, const uint32_t* P, uint64_t n, const SortResult<idx_t>& r, idx_t* dSA, idx_t* dLCP)
 {
-    if (n_tiles == 0) return;
-    CAPS_LAUNCH((finalize_kernel<idx_t, BITS>), n_tiles, 256, be, s.desc(), P, n, r.pingpong(), r.skip_finished ? 1u : 0u,
+    if (r.n_tiles == 0) return;
+    CAPS_LAUNCH((finalize_kernel<idx_t, BITS>), r.n_tiles, 256, be, r.segs.desc(), P, n, r.pingpong(), r.skip_finished ? 1u : 0u,
                 r.passes & 1u, dSA, dLCP);
 }
 
@@ -297,16 +390,18 @@ private:
     KernelClock tile_clock_;
     uint32_t pass_base_ = 0;
 
+    // timed: the full-size sorts (phase 1, phase 2) feed the kernel clocks of caps_sa_stats;
+    // their passes count the elements they really move in pl_.pass_elems[pass_base_ ...]
     template <int BITS>
-    SortResult<idx_t> seg_sort(const SegBufs& s, uint32_t n_tiles, uint64_t max_len, bool from_text, ElemBuf<idx_t> cur,
-                               ElemBuf<idx_t> oth, uint64_t n_elems, bool need_lcp, bool skip_finished, bool timed)
+    SortResult<idx_t> seg_sort(const SegBufs& s, uint32_t n_tiles, uint64_t max_len, ElemBuf<idx_t> cur, ElemBuf<idx_t> oth,
+                               uint64_t n_elems, SortOpts o, bool timed)
     {
-        // timed: the full-size sorts (phase 1, phase 2) feed the kernel clocks of caps_sa_stats;
-        // their passes count the elements they really move in pl_.pass_elems[pass_base_ ...]
-        uint64_t* counters = timed ? pl_.pass_elems + pass_base_ : nullptr;
-        SortResult<idx_t> r = segmented_sort<idx_t, BITS>(be_, pl_.P, pl_.n, pl_.desc, s, n_tiles, max_len, from_text, cur, oth,
-                                                          n_elems, need_lcp, skip_finished, timed ? &tile_clock_ : nullptr,
-                                                          timed ? &merge_clock_ : nullptr, 0, counters);
+        if (timed) {
+            o.tile_clock = &tile_clock_;
+            o.merge_clock = &merge_clock_;
+            o.pass_counters = pl_.pass_elems + pass_base_;
+        }
+        SortResult<idx_t> r = segmented_sort<idx_t, BITS>(be_, pl_.P, pl_.n, pl_.desc, s, n_tiles, max_len, cur, oth, n_elems, o);
         if (timed) pass_base_ += r.passes;
         return r;
     }
@@ -327,10 +422,14 @@ private:
             // samplesort degenerates to ONE segment: tile sort + merge passes over [0, n).
             CAPS_LAUNCH(uniform_segments_kernel, 1, 256, be_, pl_.seg1.seg_start, 1u, n, n);
             prepare_segments(pl_.seg1, tiles_of(n));
-            SortResult<idx_t> r = seg_sort<BITS>(pl_.seg1, tiles_of(n), n, true, pl_.A, pl_.B, n, true, false, true);
+            SortOpts o;
+            o.from_text = true;
+            o.need_lcp = true;
+            o.bk = &pl_.bk;                     // one segment: bucket it by key range too
+            SortResult<idx_t> r = seg_sort<BITS>(pl_.seg1, tiles_of(n), n, pl_.A, pl_.B, n, o, true);
             passes1 = r.passes;
             e2 = e3 = e4 = e5 = e6 = be_.record();
-            finalize<idx_t, BITS>(be_, pl_.P, n, pl_.seg1, tiles_of(n), r, dSA, dLCP);
+            finalize<idx_t, BITS>(be_, pl_.P, n, r, dSA, dLCP);
             e7 = be_.record();
         } else {
             const uint64_t s = n / p, last = s + n % p;
@@ -339,7 +438,11 @@ private:
             CAPS_LAUNCH(uniform_segments_kernel, (p + 256) / 256, 256, be_, pl_.seg1.seg_start, p, s, n);
             const uint32_t n_tiles1 = (p - 1) * tiles_of(s) + tiles_of(last);
             prepare_segments(pl_.seg1, n_tiles1);
-            SortResult<idx_t> r1 = seg_sort<BITS>(pl_.seg1, n_tiles1, last, true, pl_.A, pl_.B, n, false, false, true);
+            SortOpts o1;
+            o1.from_text = true;
+            o1.bk = &pl_.bk;                    // keys of a subarray span the whole key range
+            o1.unify = true;                    // sample / locate / collate index subarrays as arrays
+            SortResult<idx_t> r1 = seg_sort<BITS>(pl_.seg1, n_tiles1, last, pl_.A, pl_.B, n, o1, true);
             passes1 = r1.passes;
             ElemBuf<idx_t> cur = r1.uniform();
             ElemBuf<idx_t> oth = cur.key == pl_.A.key ? pl_.B : pl_.A;
@@ -351,7 +454,7 @@ private:
                         pl_.ppp, (const uint64_t*)cur.key, (const idx_t*)cur.sa, pl_.SA_.key, pl_.SA_.sa);
             CAPS_LAUNCH(uniform_segments_kernel, 1, 256, be_, pl_.segS.seg_start, 1u, m, m);
             prepare_segments(pl_.segS, tiles_of(m));
-            SortResult<idx_t> rs = seg_sort<BITS>(pl_.segS, tiles_of(m), m, false, pl_.SA_, pl_.SB_, m, false, false, false);
+            SortResult<idx_t> rs = seg_sort<BITS>(pl_.segS, tiles_of(m), m, pl_.SA_, pl_.SB_, m, SortOpts(), false);
             passesS = rs.passes;
             ElemBuf<idx_t> smp = rs.uniform();
             CAPS_LAUNCH((pick_pivots_kernel<idx_t>), (p + 255) / 256, 256, be_, (const uint64_t*)smp.key, (const idx_t*)smp.sa,
@@ -381,12 +484,18 @@ private:
             e5 = be_.record();
 
             // ---- phase 2 (a10): sort every partition; a partition's last step emits its LCPs
-            SortResult<idx_t> r2 = seg_sort<BITS>(pl_.seg2, n_tiles2, max_part, false, oth, cur, n, true, true, true);
+            SortOpts o2;
+            o2.need_lcp = true;
+            o2.skip_finished = true;
+            o2.bk = &pl_.bk;                    // partition j holds keys in [pivot j-1, pivot j]
+            o2.range_mode = 1;
+            o2.pkey = pl_.pkey;
+            SortResult<idx_t> r2 = seg_sort<BITS>(pl_.seg2, n_tiles2, max_part, oth, cur, n, o2, true);
             passes2 = r2.passes;
             e6 = be_.record();
 
             // ---- gather SA/LCP + partition-boundary LCPs (a11)
-            finalize<idx_t, BITS>(be_, pl_.P, n, pl_.seg2, n_tiles2, r2, dSA, dLCP);
+            finalize<idx_t, BITS>(be_, pl_.P, n, r2, dSA, dLCP);
             e7 = be_.record();
         }
         uint64_t pass_elems[kMaxPasses];

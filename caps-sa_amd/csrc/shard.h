@@ -240,10 +240,10 @@ public:
             std::swap(tdesc_, tdesc2_);
             if (bits_ == 2) {
                 SortResult<idx_t> r = sort<2>(seg2_, n_tiles2_, max_len2_, false, A2_, B2_, recv_total_, 0, true, true);
-                finalize<idx_t, 2>(be_, P_, n_, seg2_, n_tiles2_, r, static_cast<idx_t*>(dSA), static_cast<idx_t*>(dLCP));
+                finalize<idx_t, 2>(be_, P_, n_, r, static_cast<idx_t*>(dSA), static_cast<idx_t*>(dLCP));
             } else {
                 SortResult<idx_t> r = sort<8>(seg2_, n_tiles2_, max_len2_, false, A2_, B2_, recv_total_, 0, true, true);
-                finalize<idx_t, 8>(be_, P_, n_, seg2_, n_tiles2_, r, static_cast<idx_t*>(dSA), static_cast<idx_t*>(dLCP));
+                finalize<idx_t, 8>(be_, P_, n_, r, static_cast<idx_t*>(dSA), static_cast<idx_t*>(dLCP));
             }
             std::swap(tdesc_, tdesc2_);
             dSA_ = static_cast<idx_t*>(dSA);
@@ -328,8 +328,12 @@ private:
     SortResult<idx_t> sort(const SegBufs& s, uint32_t n_tiles, uint64_t max_len, bool from_text, ElemBuf<idx_t> a, ElemBuf<idx_t> b,
                            uint64_t n_elems, uint64_t text_base, bool need_lcp, bool skip_finished)
     {
-        return segmented_sort<idx_t, BITS>(be_, P_, n_, tdesc_, s, n_tiles, max_len, from_text, a, b, n_elems, need_lcp,
-                                           skip_finished, nullptr, nullptr, text_base);
+        SortOpts o;
+        o.from_text = from_text;
+        o.text_base = text_base;
+        o.need_lcp = need_lcp;
+        o.skip_finished = skip_finished;
+        return segmented_sort<idx_t, BITS>(be_, P_, n_, tdesc_, s, n_tiles, max_len, a, b, n_elems, o);
     }
 };
 
