@@ -31,6 +31,7 @@
 #define LAUNCH_BOUNDS2(n, w)
 namespace caps { struct EmulCtx { uint32_t block_idx, grid_dim, block_dim; }; }
 #define KCTX const caps::EmulCtx& kctx_,
+#define KCTX_PASS kctx_,
 #define K_BLOCK_IDX (kctx_.block_idx)
 #define K_GRID_DIM (kctx_.grid_dim)
 #define K_BLOCK_DIM (kctx_.block_dim)
@@ -48,6 +49,7 @@ namespace caps { struct EmulCtx { uint32_t block_idx, grid_dim, block_dim; }; }
 static inline uint32_t caps_fetch_add_u32(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
 static inline uint64_t caps_fetch_add_u64(uint64_t* p, uint64_t v) { const uint64_t o = *p; *p = o + v; return o; }
 #define FETCH_ADD_U32(ptr, v) caps_fetch_add_u32((ptr), (v))      /* returns the old value */
+#define BLOCK_MINMAX_U64(pmin, pmax, mn, mx) do { if ((mn) < *(pmin)) *(pmin) = (mn); if ((mx) > *(pmax)) *(pmax) = (mx); } while (0)
 #define FETCH_ADD_U64(ptr, v) caps_fetch_add_u64((ptr), (v))
 static inline uint64_t caps_umul64hi(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
 static inline int caps_clz64(uint64_t x) { return __builtin_clzll(x); }
@@ -62,6 +64,7 @@ static inline uint32_t caps_bswap32(uint32_t x) { return __builtin_bswap32(x); }
 #define LAUNCH_BOUNDS(n) __launch_bounds__(n)
 #define LAUNCH_BOUNDS2(n, w) __launch_bounds__(n, w)   /* w = min waves per SIMD = blocks/CU * n / 256 */
 #define KCTX
+#define KCTX_PASS
 #define K_BLOCK_IDX (blockIdx.x)
 #define K_GRID_DIM (gridDim.x)
 #define K_BLOCK_DIM (blockDim.x)
@@ -76,6 +79,21 @@ static inline uint32_t caps_bswap32(uint32_t x) { return __builtin_bswap32(x); }
 #define ATOMIC_ADD_LDS_U64(ptr, v) atomicAdd((unsigned long long*)(ptr), (unsigned long long)(v))
 #define ATOMIC_MAX_U64(ptr, v) atomicMax((unsigned long long*)(ptr), (unsigned long long)(v))
 #define FETCH_ADD_U32(ptr, v) atomicAdd((ptr), (v))                 /* returns the old value (LDS or global) */
+// min/max of a per-thread value over the workgroup into two LDS words: wave64 butterfly with
+// shuffles, then one LDS atomic per wave.
+static __device__ __forceinline__ void caps_block_minmax_u64(uint64_t* pmin, uint64_t* pmax, uint64_t mn, uint64_t mx)
+{
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint64_t a = __shfl_xor(mn, d, 64), b = __shfl_xor(mx, d, 64);
+        mn = a < mn ? a : mn;
+        mx = b > mx ? b : mx;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin((unsigned long long*)pmin, (unsigned long long)mn);
+        atomicMax((unsigned long long*)pmax, (unsigned long long)mx);
+    }
+}
+#define BLOCK_MINMAX_U64(pmin, pmax, mn, mx) caps_block_minmax_u64((pmin), (pmax), (mn), (mx))
 #define FETCH_ADD_U64(ptr, v) ((uint64_t)atomicAdd((unsigned long long*)(ptr), (unsigned long long)(v)))
 static __device__ __forceinline__ uint64_t caps_umul64hi(uint64_t a, uint64_t b) { return __umul64hi(a, b); }
 static __host__ __device__ __forceinline__ int caps_clz64(uint64_t x) {

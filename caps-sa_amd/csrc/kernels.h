@@ -52,6 +52,7 @@ constexpr uint32_t LOCK_K = CAPS_LOCK_K < TILE_EPT ? CAPS_LOCK_K : TILE_EPT;
 #define LAUNCH_BOUNDS2(n, w) LAUNCH_BOUNDS(n)
 #endif
 static_assert(TILE_E % TILE_NT == 0 && TILE_EPT % LOCK_K == 0, "tile geometry");
+constexpr uint32_t TILE_BINS_ = TILE_E / 2;   // bins of the in-LDS bucket sort of one tile
 
 // Segment/tile descriptor shared by the tile-granular kernels.
 struct SegDesc {
@@ -312,6 +313,64 @@ DEV_INLINE void multi_lower_bound(const uint32_t* __restrict__ P, uint64_t n, co
 // smallest power of two strictly greater than x (x < 2^31)
 HD uint32_t pow2_above(uint32_t x) { return 1u << (32 - (x ? __builtin_clz(x) : 32)); }
 
+struct BucketParams {        // per parent segment
+    uint64_t kmin;           // smallest key of the segment's range
+    uint64_t bq;             // bucket = mulhi((key - kmin) << shift, bq), clamped to B - 1
+    uint32_t shift;
+    uint32_t B;
+};
+
+DEV_INLINE uint32_t bucket_of(const BucketParams& bp, uint64_t key)
+{
+    if (bp.B <= 1) return 0;
+    if (key <= bp.kmin) return 0;
+    const uint64_t d = key - bp.kmin;
+    if (bp.shift && (d >> (64 - bp.shift))) return bp.B - 1;          // above the nominal range
+    const uint64_t b = caps_umul64hi(d << bp.shift, bp.bq);
+    return b < bp.B ? (uint32_t)b : bp.B - 1;
+}
+
+
+// Exclusive scan of the TILE_BINS bin counts of a tile, in place; hist[TILE_BINS] = total.
+// gfx950: every thread owns TILE_BINS / TILE_NT consecutive bins; wave64 shuffle scan of the
+// per-thread sums, wave totals combined through LDS (two barriers).
+DEV_INLINE void block_exclusive_scan_bins(KCTX uint32_t* hist)
+{
+#ifdef CAPS_EMUL
+    (void)kctx_;
+    uint32_t run = 0;
+    for (uint32_t i = 0; i < TILE_BINS_; ++i) { const uint32_t c = hist[i]; hist[i] = run; run += c; }
+    hist[TILE_BINS_] = run;
+#else
+    constexpr uint32_t BPT = TILE_BINS_ / TILE_NT;
+    static_assert(BPT >= 1 && BPT * TILE_NT == TILE_BINS_, "bins per thread");
+    __shared__ uint32_t wave_tot[TILE_NT / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t v[BPT], sum = 0;
+    UNROLL
+    for (uint32_t i = 0; i < BPT; ++i) { v[i] = hist[tid * BPT + i]; sum += v[i]; }
+    uint32_t x = sum;
+    UNROLL
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d, 64);
+        if ((int)lane >= d) x += y;
+    }
+    if (lane == 63) wave_tot[wv] = x;
+    __syncthreads();
+    uint32_t run = x - sum;
+    for (uint32_t w = 0; w < wv; ++w) run += wave_tot[w];
+    UNROLL
+    for (uint32_t i = 0; i < BPT; ++i) { hist[tid * BPT + i] = run; run += v[i]; }
+    if (tid == TILE_NT - 1) hist[TILE_BINS_] = run;
+    __syncthreads();
+#endif
+}
+
+// Bins of the in-LDS bucket sort of one tile, and the bin occupancy above which the tile
+// falls back to the merge levels.
+constexpr uint32_t TILE_BINS = TILE_BINS_;
+constexpr uint32_t TILE_BIN_LIMIT = 24;
+
 // ----------------------------------------------------------------------------------
 // a4/a5: tile sort -- one workgroup sorts up to TILE_E suffixes in LDS and emits the
 // sorted run with its LCP array (reference: merge_sort, src/Suffix_Array.cpp:112-129,
@@ -344,28 +403,135 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
 
     SHARED_ARRAY(uint64_t, skey, TILE_E);
     SHARED_ARRAY(idx_t, ssa, TILE_E);
+    SHARED_ARRAY(uint32_t, hist, TILE_BINS + 1);
+    SHARED_ARRAY(uint64_t, kmm, 2);          // min / max key of the tile
+    SHARED_ARRAY(uint32_t, flag, 1);         // a bin overflowed: use the merge levels instead
     TL_DECL(uint64_t, rk, TILE_EPT);
     TL_DECL(idx_t, rs, TILE_EPT);
     TL_DECL(uint32_t, rd, TILE_EPT);
+    TL_DECL(uint32_t, rb, TILE_EPT);
 
     PAR(tid) {
+        if (tid == 0) { kmm[0] = ~0ull; kmm[1] = 0; flag[0] = 0; }
+        for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0;
         UNROLL
         for (uint32_t k = 0; k < TILE_EPT; ++k) {
             const uint32_t e = tid + k * TILE_NT;
             if (e < cnt) {
+                uint64_t key;
+                idx_t sa;
                 if (FROM_TEXT) {
-                    skey[e] = window64<BITS>(P, text_base + start + e);
-                    ssa[e] = (idx_t)(text_base + start + e);
+                    key = window64<BITS>(P, text_base + start + e);
+                    sa = (idx_t)(text_base + start + e);
                 } else {
-                    skey[e] = in_key[start + e];
-                    ssa[e] = in_sa[start + e];
+                    key = in_key[start + e];
+                    sa = in_sa[start + e];
                 }
+                TL(rk, tid, k) = key;
+                TL(rs, tid, k) = sa;
+                skey[e] = key;                   // input order: what the merge levels start from
+                ssa[e] = sa;
             }
         }
     }
     SYNC();
 
-    for (uint32_t R = 1; R < cnt; R <<= 1) {
+    // ---- fast path: interpolation bucket sort in LDS ---------------------------------
+    // bin = monotone linear map of the key onto TILE_BINS bins between the tile's smallest
+    // and largest key; a counting sort by bin (LDS histogram + scan) places every element
+    // next to the few others of its bin, and a short exact scan of its own bin fixes the
+    // order.  ~100 VALU instructions per suffix instead of ~1000 for the merge levels.
+    // Taken when no bin holds more than TILE_BIN_LIMIT elements (always on keys that are
+    // roughly uniform in their range: random DNA, buckets of the bucketing stage).
+    PAR(tid) {
+        uint64_t mn = ~0ull, mx = 0;
+        UNROLL
+        for (uint32_t k = 0; k < TILE_EPT; ++k) {
+            const uint32_t e = tid + k * TILE_NT;
+            if (e < cnt) {
+                const uint64_t key = TL(rk, tid, k);
+                mn = key < mn ? key : mn;
+                mx = key > mx ? key : mx;
+            }
+        }
+        BLOCK_MINMAX_U64(&kmm[0], &kmm[1], mn, mx);
+    }
+    SYNC();
+    BucketParams tb;                                   // block-uniform
+    {
+        const uint64_t kmin = kmm[0], kmax = kmm[1];
+        const uint64_t range = kmax > kmin ? kmax - kmin : 0;
+        tb.kmin = kmin;
+        tb.B = TILE_BINS;
+        tb.shift = range ? (uint32_t)caps_clz64(range) : 0u;
+        tb.bq = (uint64_t)((double)TILE_BINS * 18446744073709551616.0 / ((double)(range << tb.shift) + 1.0));
+    }
+    bool fast = cnt > 1 && kmm[1] > kmm[0];
+    if (fast) {
+        PAR(tid) {
+            UNROLL
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                const uint32_t e = tid + k * TILE_NT;
+                if (e < cnt) {
+                    const uint32_t bin = bucket_of(tb, TL(rk, tid, k));
+                    const uint32_t r = FETCH_ADD_U32(&hist[bin], 1u);
+                    if (r >= TILE_BIN_LIMIT) flag[0] = 1;
+                    TL(rb, tid, k) = bin;
+                    TL(rd, tid, k) = r;
+                }
+            }
+        }
+        SYNC();
+        fast = flag[0] == 0;
+    }
+    if (fast) {
+        block_exclusive_scan_bins(KCTX_PASS hist);         // hist[b] = first slot of bin b, hist[TILE_BINS] = cnt
+        PAR(tid) {
+            UNROLL
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                const uint32_t e = tid + k * TILE_NT;
+                if (e < cnt) {
+                    const uint32_t slot = hist[TL(rb, tid, k)] + TL(rd, tid, k);
+                    skey[slot] = TL(rk, tid, k);
+                    ssa[slot] = TL(rs, tid, k);
+                    TL(rd, tid, k) = slot;
+                }
+            }
+        }
+        SYNC();
+        PAR(tid) {
+            UNROLL
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                const uint32_t e = tid + k * TILE_NT;
+                if (e < cnt) {
+                    const uint32_t bin = TL(rb, tid, k), slot = TL(rd, tid, k);
+                    const uint32_t bs = hist[bin], be = hist[bin + 1];
+                    const uint64_t key = TL(rk, tid, k);
+                    const uint64_t sa = (uint64_t)TL(rs, tid, k);
+                    uint32_t less = 0;                        // members of my bin that sort before me
+                    for (uint32_t j = bs; j < be; ++j)
+                        if (j != slot && suffix_less<BITS>(P, n, skey[j], (uint64_t)ssa[j], key, sa)) ++less;
+                    TL(rd, tid, k) = bs + less;
+                }
+            }
+        }
+        SYNC();
+        PAR(tid) {
+            UNROLL
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                const uint32_t e = tid + k * TILE_NT;
+                if (e < cnt) {
+                    const uint32_t d = TL(rd, tid, k);
+                    skey[d] = TL(rk, tid, k);
+                    ssa[d] = TL(rs, tid, k);
+                }
+            }
+        }
+        SYNC();
+    }
+
+    // ---- general path: bottom-up rank-merge levels (skewed / repetitive keys) -----------
+    for (uint32_t R = 1; !fast && R < cnt; R <<= 1) {
         PAR(tid) {
             UNROLL
             for (uint32_t g = 0; g < TILE_EPT; g += LOCK_K) {            // LOCK_K searches in lockstep
@@ -732,23 +898,6 @@ GLOBAL_FN LAUNCH_BOUNDS(256) finalize_kernel(KCTX SegDesc sd, const uint32_t* __
 // ----------------------------------------------------------------------------------
 constexpr uint32_t BUCKET_TARGET = (TILE_E * 5) / 8;   // mean bucket size: leaves 37 % headroom in a tile
 constexpr uint32_t BUCKET_LDS = 4096;                  // buckets per segment the LDS histogram can hold
-
-struct BucketParams {        // per parent segment
-    uint64_t kmin;           // smallest key of the segment's range
-    uint64_t bq;             // bucket = mulhi((key - kmin) << shift, bq), clamped to B - 1
-    uint32_t shift;
-    uint32_t B;
-};
-
-DEV_INLINE uint32_t bucket_of(const BucketParams& bp, uint64_t key)
-{
-    if (bp.B <= 1) return 0;
-    if (key <= bp.kmin) return 0;
-    const uint64_t d = key - bp.kmin;
-    if (bp.shift && (d >> (64 - bp.shift))) return bp.B - 1;          // above the nominal range
-    const uint64_t b = caps_umul64hi(d << bp.shift, bp.bq);
-    return b < bp.B ? (uint32_t)b : bp.B - 1;
-}
 
 // range_mode 0: keys span the whole 64-bit range (subarrays of text positions);
 // range_mode 1: segment g holds keys in [pkey[g-1], pkey[g]] (partitions between pivots).
