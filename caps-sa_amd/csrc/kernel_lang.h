@@ -46,6 +46,7 @@ namespace caps { struct EmulCtx { uint32_t block_idx, grid_dim, block_dim; }; }
 #define ATOMIC_ADD_U64(ptr, v) (*(ptr) += (v))
 #define ATOMIC_ADD_LDS_U64(ptr, v) (*(ptr) += (v))
 #define ATOMIC_MAX_U64(ptr, v) (*(ptr) = std::max<uint64_t>(*(ptr), (v)))
+#define ATOMIC_MAX_LDS_U64(ptr, v) (*(ptr) = std::max<uint64_t>(*(ptr), (v)))
 static inline uint32_t caps_fetch_add_u32(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
 static inline uint64_t caps_fetch_add_u64(uint64_t* p, uint64_t v) { const uint64_t o = *p; *p = o + v; return o; }
 #define FETCH_ADD_U32(ptr, v) caps_fetch_add_u32((ptr), (v))      /* returns the old value */
@@ -78,6 +79,7 @@ static inline uint32_t caps_bswap32(uint32_t x) { return __builtin_bswap32(x); }
 #define ATOMIC_ADD_U64(ptr, v) atomicAdd((unsigned long long*)(ptr), (unsigned long long)(v))
 #define ATOMIC_ADD_LDS_U64(ptr, v) atomicAdd((unsigned long long*)(ptr), (unsigned long long)(v))
 #define ATOMIC_MAX_U64(ptr, v) atomicMax((unsigned long long*)(ptr), (unsigned long long)(v))
+#define ATOMIC_MAX_LDS_U64(ptr, v) atomicMax((unsigned long long*)(ptr), (unsigned long long)(v))
 #define FETCH_ADD_U32(ptr, v) atomicAdd((ptr), (v))                 /* returns the old value (LDS or global) */
 // min/max of a per-thread value over the workgroup into two LDS words: wave64 butterfly with
 // shuffles, then one LDS atomic per wave.

@@ -257,6 +257,89 @@ GLOBAL_FN LAUNCH_BOUNDS(1024) seg_prepare_kernel(KCTX const uint64_t* __restrict
     }
 }
 
+// ---- multi-workgroup exclusive scan (segment counts in the millions: the buckets) ------
+// block_scan_kernel: workgroup b scans its chunk of SCAN_CHUNK inputs (exclusive, local) and
+// records the chunk total; the totals are scanned by scan_sizes_kernel; add_offsets_kernel
+// adds them back and writes the grand total to out[n].
+constexpr uint32_t SCAN_CHUNK = 4096;
+
+template <typename OutT>
+GLOBAL_FN LAUNCH_BOUNDS(1024) block_scan_kernel(KCTX const uint64_t* __restrict__ in, uint64_t n, OutT* __restrict__ out,
+                                                uint64_t* __restrict__ sums)
+{
+    const uint64_t base = (uint64_t)K_BLOCK_IDX * SCAN_CHUNK;
+#ifdef CAPS_EMUL
+    uint64_t run = 0;
+    for (uint32_t i = 0; i < SCAN_CHUNK && base + i < n; ++i) { const uint64_t v = in[base + i]; out[base + i] = (OutT)run; run += v; }
+    sums[K_BLOCK_IDX] = run;
+#else
+    __shared__ uint64_t wave_tot[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint64_t v[4], sum = 0;
+    UNROLL
+    for (uint32_t i = 0; i < 4; ++i) {
+        const uint64_t idx = base + (uint64_t)tid * 4 + i;
+        v[i] = idx < n ? in[idx] : 0;
+        sum += v[i];
+    }
+    uint64_t x = sum;
+    UNROLL
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t y = __shfl_up(x, d, 64);
+        if ((int)lane >= d) x += y;
+    }
+    if (lane == 63) wave_tot[wv] = x;
+    __syncthreads();
+    uint64_t run = x - sum;
+    for (uint32_t w = 0; w < wv; ++w) run += wave_tot[w];
+    UNROLL
+    for (uint32_t i = 0; i < 4; ++i) {
+        const uint64_t idx = base + (uint64_t)tid * 4 + i;
+        if (idx < n) out[idx] = (OutT)run;
+        run += v[i];
+    }
+    if (tid == 1023) sums[blockIdx.x] = run;
+#endif
+}
+
+template <typename OutT>
+GLOBAL_FN LAUNCH_BOUNDS(1024) add_offsets_kernel(KCTX OutT* __restrict__ out, uint64_t n, const uint64_t* __restrict__ offs,
+                                                 uint32_t n_chunks)
+{
+    const uint64_t base = (uint64_t)K_BLOCK_IDX * SCAN_CHUNK;
+    const uint64_t off = offs[K_BLOCK_IDX];
+    PAR(tid) {
+        for (uint32_t i = tid; i < SCAN_CHUNK; i += K_BLOCK_DIM)
+            if (base + i < n) out[base + i] = (OutT)((uint64_t)out[base + i] + off);
+        if (K_BLOCK_IDX == 0 && tid == 0) out[n] = (OutT)offs[n_chunks];
+    }
+}
+
+// cnt[g] = ceil(len_g / TILE_E); out2[1] = max len (out2 zeroed before the launch).
+GLOBAL_FN LAUNCH_BOUNDS(256) tile_count_kernel(KCTX const uint64_t* __restrict__ seg_start, uint32_t G, uint64_t* __restrict__ cnt,
+                                               uint64_t* __restrict__ out2)
+{
+    SHARED_ARRAY(uint64_t, mx, 1);
+    PAR(tid) { if (tid == 0) mx[0] = 0; }
+    SYNC();
+    PAR(tid) {
+        const uint64_t g = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (g < G) {
+            const uint64_t len = seg_start[g + 1] - seg_start[g];
+            cnt[g] = (len + TILE_E - 1) / TILE_E;
+            if (len) ATOMIC_MAX_LDS_U64(&mx[0], len);
+        }
+    }
+    SYNC();
+    PAR(tid) { if (tid == 0 && mx[0]) ATOMIC_MAX_U64(&out2[1], mx[0]); }
+}
+
+// out2[0] = tile_off[G] (number of tiles), for the host read-back.
+GLOBAL_FN LAUNCH_BOUNDS(64) tile_total_kernel(KCTX const uint32_t* __restrict__ tile_off, uint32_t G, uint64_t* __restrict__ out2)
+{
+    PAR(tid) { if (tid == 0 && K_BLOCK_IDX == 0) out2[0] = tile_off[G]; }
+}
+
 // tile_seg[b] = the segment g with tile_off[g] <= b < tile_off[g+1].
 GLOBAL_FN LAUNCH_BOUNDS(256) tile_map_kernel(KCTX const uint32_t* __restrict__ tile_off, uint32_t G, uint32_t* __restrict__ tile_seg)
 {
@@ -897,7 +980,7 @@ GLOBAL_FN LAUNCH_BOUNDS(256) finalize_kernel(KCTX SegDesc sd, const uint32_t* __
 //                          buffer back, for consumers that index a segment as one array
 // ----------------------------------------------------------------------------------
 constexpr uint32_t BUCKET_TARGET = (TILE_E * 5) / 8;   // mean bucket size: leaves 37 % headroom in a tile
-constexpr uint32_t BUCKET_LDS = 4096;                  // buckets per segment the LDS histogram can hold
+constexpr uint32_t BUCKET_LDS = TILE_BINS_;            // buckets per segment the LDS histogram can hold
 
 // range_mode 0: keys span the whole 64-bit range (subarrays of text positions);
 // range_mode 1: segment g holds keys in [pkey[g-1], pkey[g]] (partitions between pivots).
@@ -983,7 +1066,10 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_count_kernel(KCTX SegDesc sd, const uint
 }
 
 // sub_start[NB+1] = exclusive scan of count (absolute element offsets of the buckets);
-// cursor[NB] starts at 0.
+// cursor[NB] starts at 0.  Per tile: LDS histogram of its elements' buckets; one global
+// cursor bump per (tile, non-empty bucket); the tile is then re-ordered by bucket in LDS so
+// that consecutive lanes write consecutive slots (a bucket receives a run of consecutive
+// elements from every tile instead of 64 scattered 8-byte stores per wave instruction).
 template <typename idx_t, int BITS, bool FROM_TEXT>
 GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t text_base,
                                                        const uint64_t* __restrict__ in_key, const idx_t* __restrict__ in_sa,
@@ -999,14 +1085,18 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
     const uint32_t cnt = (uint32_t)(t.s1 - start < TILE_E ? t.s1 - start : TILE_E);
     const BucketParams bp = bps[g];
     const uint64_t b0 = bstart[g];
-    SHARED_ARRAY(uint32_t, hist, BUCKET_LDS);
+    SHARED_ARRAY(uint32_t, hist, TILE_BINS + 1);          // counts -> exclusive prefix inside the tile
+    SHARED_ARRAY(uint64_t, obase, TILE_BINS);             // global slot of the tile's first element of bucket i, minus its prefix
+    SHARED_ARRAY(uint64_t, skey, TILE_E);
+    SHARED_ARRAY(idx_t, ssa, TILE_E);
+    SHARED_ARRAY(uint16_t, sbk, TILE_E);
     TL_DECL(uint64_t, rk, TILE_EPT);
     TL_DECL(idx_t, rs, TILE_EPT);
     TL_DECL(uint32_t, rb, TILE_EPT);      // bucket
     TL_DECL(uint32_t, rr, TILE_EPT);      // rank inside (tile, bucket) or inside the bucket
     const bool lds = bp.B > 1 && bp.B <= BUCKET_LDS;
     if (lds) {
-        PAR(tid) { for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM) hist[i] = 0; }
+        PAR(tid) { for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0; }
         SYNC();
     }
     PAR(tid) {
@@ -1029,25 +1119,52 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
             }
         }
     }
-    if (lds) {
-        SYNC();
-        PAR(tid) {                                         // one global cursor bump per (tile, non-empty bucket)
-            for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM) {
-                const uint32_t c = hist[i];
-                if (c) hist[i] = FETCH_ADD_U32(&cursor[b0 + i], c);
+    if (!lds) {                                            // one bucket, or too many for the LDS histogram
+        PAR(tid) {
+            UNROLL
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                const uint32_t e = tid + k * TILE_NT;
+                if (e < cnt) {
+                    const uint64_t dst = sub_start[b0 + TL(rb, tid, k)] + TL(rr, tid, k);
+                    out_key[dst] = TL(rk, tid, k);
+                    out_sa[dst] = TL(rs, tid, k);
+                }
             }
         }
-        SYNC();
+        return;
     }
+    SYNC();
+    PAR(tid) {                                             // one global cursor bump per (tile, non-empty bucket)
+        for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM) {
+            const uint32_t c = hist[i];
+            obase[i] = c ? sub_start[b0 + i] + FETCH_ADD_U32(&cursor[b0 + i], c) : 0;
+        }
+    }
+    SYNC();
+    block_exclusive_scan_bins(KCTX_PASS hist);             // hist[i] = position of bucket i inside the re-ordered tile
     PAR(tid) {
+        for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM) obase[i] -= hist[i];
         UNROLL
         for (uint32_t k = 0; k < TILE_EPT; ++k) {
             const uint32_t e = tid + k * TILE_NT;
             if (e < cnt) {
                 const uint32_t bk = TL(rb, tid, k);
-                const uint64_t dst = sub_start[b0 + bk] + (lds ? hist[bk] : 0u) + TL(rr, tid, k);
-                out_key[dst] = TL(rk, tid, k);
-                out_sa[dst] = TL(rs, tid, k);
+                const uint32_t q = hist[bk] + TL(rr, tid, k);
+                skey[q] = TL(rk, tid, k);
+                ssa[q] = TL(rs, tid, k);
+                sbk[q] = (uint16_t)bk;
+            }
+        }
+    }
+    SYNC();
+    PAR(tid) {
+        UNROLL
+        for (uint32_t k = 0; k < TILE_EPT; ++k) {
+            const uint32_t q = tid + k * TILE_NT;
+            if (q < cnt) {
+                const uint64_t dst = obase[sbk[q]] + q;
+                out_key[dst] = skey[q];
+                out_sa[dst] = ssa[q];
             }
         }
     }
@@ -1183,11 +1300,42 @@ GLOBAL_FN LAUNCH_BOUNDS(64) partition_sizes_kernel(KCTX const idx_t* __restrict_
 // Collate: move every element of sorted subarray g to its slot in its partition
 // (reference: the p^2 memcpy's at cpp:343-358).  Element x of subarray g belongs to
 // partition j with Pm[g][j] <= x < Pm[g][j+1]; slot = part_start[j] + ruler[g][j] + (x - Pm[g][j]).
-// Reads are coalesced; writes land in runs of consecutive slots.  Only (key, sa) move:
-// phase 2 rebuilds the LCPs (the reference resets run-head LCPs here, cpp:356).
+// collate_plan_kernel finds the partition of every tile's first element; collate_kernel stages
+// the slice of the subarray's Pm row that its tile spans (with the slot bases) in LDS and
+// resolves every element there.  Reads are coalesced; writes land in runs of consecutive
+// slots.  Only (key, sa) move: phase 2 rebuilds the LCPs (the reference resets run-head LCPs
+// here, cpp:356).
+constexpr uint32_t COLLATE_ROW = TILE_E + 2;     // row entries a tile can span without empty partitions in between
+
+template <typename idx_t>
+DEV_INLINE uint32_t partition_of(const idx_t* __restrict__ row, uint32_t p, uint64_t x)
+{
+    uint32_t lo = 0, hi = p;                                     // j = #{j' in [1,p] : row[j'] <= x}
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if ((uint64_t)row[mid + 1] <= x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+template <typename idx_t>
+GLOBAL_FN LAUNCH_BOUNDS(256) collate_plan_kernel(KCTX SegDesc sd, uint32_t p, const idx_t* __restrict__ Pm,
+                                                 uint32_t* __restrict__ first_part)
+{
+    PAR(tid) {
+        const uint64_t b = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (b < sd.tile_off[sd.G]) {
+            const uint32_t g = sd.tile_seg[b];
+            const TileInfo t = tile_info(sd, (uint32_t)b);
+            first_part[b] = partition_of<idx_t>(Pm + (uint64_t)g * (p + 1), p, (uint64_t)t.tl * TILE_E);
+        }
+    }
+}
+
 template <typename idx_t>
 GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) collate_kernel(KCTX SegDesc sd, uint32_t p, const idx_t* __restrict__ Pm,
                                                 const idx_t* __restrict__ ruler, const uint64_t* __restrict__ part_start,
+                                                const uint32_t* __restrict__ first_part,
                                                 const uint64_t* __restrict__ in_key, const idx_t* __restrict__ in_sa,
                                                 uint64_t* __restrict__ out_key, idx_t* __restrict__ out_sa)
 {
@@ -1195,22 +1343,46 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) collate_kernel(KCTX SegDesc sd, uint32_t p, con
     if (b >= sd.tile_off[sd.G]) return;
     const uint32_t g = sd.tile_seg[b];
     const TileInfo t = tile_info(sd, b);
-    const uint64_t start = t.s0 + (uint64_t)t.tl * TILE_E;
+    const uint64_t x0 = (uint64_t)t.tl * TILE_E;                  // index of the tile's first element in the subarray
+    const uint64_t start = t.s0 + x0;
     const uint32_t cnt = (uint32_t)(t.s1 - start < TILE_E ? t.s1 - start : TILE_E);
     const idx_t* row = Pm + (uint64_t)g * (p + 1);
+    const uint32_t j0 = first_part[b];
+    // last partition the tile touches: the next tile's first one, or p - 1 at the end of the subarray
+    const bool last_tile = start + cnt >= t.s1;
+    const uint32_t j1 = last_tile ? p - 1 : first_part[b + 1];
+    const uint32_t ns = j1 - j0 + 1;                               // partitions spanned
+    SHARED_ARRAY(idx_t, lrow, COLLATE_ROW);                        // row[j0 .. j1 + 1]
+    SHARED_ARRAY(uint64_t, lbase, COLLATE_ROW);                    // slot of (partition j, x = 0)
+    const bool staged = ns + 1 <= COLLATE_ROW;
+    if (staged) {
+        PAR(tid) {
+            for (uint32_t k = tid; k <= ns; k += K_BLOCK_DIM) {
+                const uint32_t j = j0 + k;
+                lrow[k] = row[j];
+                if (k < ns) lbase[k] = part_start[j] + (uint64_t)ruler[(uint64_t)g * p + j] - (uint64_t)row[j];
+            }
+        }
+        SYNC();
+    }
     PAR(tid) {
         UNROLL
         for (uint32_t k = 0; k < TILE_EPT; ++k) {
             const uint32_t e = tid + k * TILE_NT;
             if (e < cnt) {
-                const uint64_t x = (uint64_t)t.tl * TILE_E + e;      // index inside the subarray
-                uint32_t lo = 0, hi = p;                             // j = #{j' in [1,p] : row[j'] <= x}
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if ((uint64_t)row[mid + 1] <= x) lo = mid + 1; else hi = mid;
+                const uint64_t x = x0 + e;
+                uint64_t dst;
+                if (staged) {
+                    uint32_t lo = 0, hi = ns - 1;                 // largest k with lrow[k] <= x  (lrow[0] <= x0 <= x)
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi + 1) >> 1;
+                        if ((uint64_t)lrow[mid] <= x) lo = mid; else hi = mid - 1;
+                    }
+                    dst = lbase[lo] + x;
+                } else {
+                    const uint32_t j = partition_of<idx_t>(row, p, x);
+                    dst = part_start[j] + (uint64_t)ruler[(uint64_t)g * p + j] + (x - (uint64_t)row[j]);
                 }
-                const uint32_t j = lo;
-                const uint64_t dst = part_start[j] + (uint64_t)ruler[(uint64_t)g * p + j] + (x - (uint64_t)row[j]);
                 out_key[dst] = in_key[start + e];
                 out_sa[dst] = in_sa[start + e];
             }

@@ -68,6 +68,7 @@ struct BucketBufs {
     uint64_t* bstart = nullptr;       // [G+1]  exclusive scan of segB
     uint64_t* count = nullptr;        // [nb_cap] elements per bucket
     uint32_t* cursor = nullptr;       // [nb_cap]
+    uint64_t* scan_tmp = nullptr;     // [2 * (nb_cap / SCAN_CHUNK + 2)]
     SegBufs sub;                      // the buckets as segments (G = nb_cap, trailing ones empty)
     uint32_t nb_cap = 0;
     uint64_t tile_cap = 0;
@@ -158,6 +159,7 @@ Plan<idx_t> make_plan(uint64_t n, uint64_t p_arg, char* base)
     pl.bk.bstart = ar.take<uint64_t>((size_t)p + 1);
     pl.bk.count = ar.take<uint64_t>(pl.bk.nb_cap);
     pl.bk.cursor = ar.take<uint32_t>(pl.bk.nb_cap);
+    pl.bk.scan_tmp = ar.take<uint64_t>(2 * ((size_t)pl.bk.nb_cap / SCAN_CHUNK + 2));
     segs(pl.bk.sub, pl.bk.nb_cap, pl.bk.tile_cap);
     pl.pass_elems = ar.take<uint64_t>(kMaxPasses);
     pl.present = ar.take<uint32_t>(8);
@@ -215,10 +217,36 @@ inline int prepare_text(Backend& be, const uint8_t* dT, uint64_t n, uint32_t* P,
     return bits;
 }
 
-inline void prepare_segments(Backend& be, const SegBufs& s, uint64_t tile_bound)
+// out[0..G] = exclusive scan of in[0..G) (out[G] = total).  Small inputs: one workgroup;
+// large ones (the buckets): chunked scan over many workgroups.  tmp: u64[G / SCAN_CHUNK + 2] x 2.
+template <typename OutT>
+inline void device_exclusive_scan(Backend& be, const uint64_t* in, uint32_t G, OutT* out, uint64_t* tmp)
+{
+    const uint32_t chunks = (G + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    uint64_t* sums = tmp;
+    uint64_t* offs = tmp + chunks + 1;
+    CAPS_LAUNCH((block_scan_kernel<OutT>), chunks ? chunks : 1, 1024, be, in, (uint64_t)G, out, sums);
+    CAPS_LAUNCH(scan_sizes_kernel, 1, 1024, be, (const uint64_t*)sums, chunks, offs);
+    CAPS_LAUNCH((add_offsets_kernel<OutT>), chunks ? chunks : 1, 1024, be, out, (uint64_t)G, (const uint64_t*)offs, chunks);
+}
+
+#ifdef CAPS_EMUL
+constexpr uint32_t kSmallScan = 48;        // tiny, so that the CPU logic tests reach the chunked scan
+#else
+constexpr uint32_t kSmallScan = 32768;
+#endif
+
+inline void prepare_segments(Backend& be, const SegBufs& s, uint64_t tile_bound, uint64_t* big_tmp = nullptr,
+                             uint64_t* big_cnt = nullptr)
 {
     be.memset(s.out2, 0, 2 * sizeof(uint64_t));
-    CAPS_LAUNCH(seg_prepare_kernel, 1, 1024, be, (const uint64_t*)s.seg_start, s.G, s.tile_off, s.out2);
+    if (s.G <= kSmallScan || !big_tmp) {
+        CAPS_LAUNCH(seg_prepare_kernel, 1, 1024, be, (const uint64_t*)s.seg_start, s.G, s.tile_off, s.out2);
+    } else {
+        CAPS_LAUNCH(tile_count_kernel, (s.G + 255) / 256, 256, be, (const uint64_t*)s.seg_start, s.G, big_cnt, s.out2);
+        device_exclusive_scan<uint32_t>(be, big_cnt, s.G, s.tile_off, big_tmp);
+        CAPS_LAUNCH(tile_total_kernel, 1, 64, be, (const uint32_t*)s.tile_off, s.G, s.out2);
+    }
     const uint32_t grid = (uint32_t)((tile_bound + 255) / 256);
     CAPS_LAUNCH(tile_map_kernel, grid ? grid : 1, 256, be, (const uint32_t*)s.tile_off, s.G, s.tile_seg);
 }
@@ -289,14 +317,14 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         if (from_text) {
             CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, psd, P, o.text_base, (const uint64_t*)nullptr,
                         (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, bk.count);
-            CAPS_LAUNCH(scan_sizes_kernel, 1, 1024, be, (const uint64_t*)bk.count, bk.nb_cap, bk.sub.seg_start);
+            device_exclusive_scan<uint64_t>(be, bk.count, bk.nb_cap, bk.sub.seg_start, bk.scan_tmp);
             CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, psd, P, o.text_base, (const uint64_t*)nullptr,
                         (const idx_t*)nullptr, (const BucketParams*)bk.params, (const uint64_t*)bk.bstart,
                         (const uint64_t*)bk.sub.seg_start, bk.cursor, dst.key, dst.sa);
         } else {
             CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, psd, P, (uint64_t)0, (const uint64_t*)cur.key,
                         (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, bk.count);
-            CAPS_LAUNCH(scan_sizes_kernel, 1, 1024, be, (const uint64_t*)bk.count, bk.nb_cap, bk.sub.seg_start);
+            device_exclusive_scan<uint64_t>(be, bk.count, bk.nb_cap, bk.sub.seg_start, bk.scan_tmp);
             CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, psd, P, (uint64_t)0, (const uint64_t*)cur.key,
                         (const idx_t*)cur.sa, (const BucketParams*)bk.params, (const uint64_t*)bk.bstart,
                         (const uint64_t*)bk.sub.seg_start, bk.cursor, dst.key, dst.sa);
@@ -307,7 +335,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         // the buckets are the segments from here on (trailing unused ones are empty)
         segs = bk.sub;
         segs.G = bk.nb_cap;
-        prepare_segments(be, segs, bk.tile_cap);
+        prepare_segments(be, segs, bk.tile_cap, bk.scan_tmp, bk.count);    // count[] is free again: reuse as scratch
         uint64_t out2[2];
         be.d2h(out2, segs.out2, sizeof out2);
         be.sync();
@@ -475,9 +503,12 @@ private:
             prepare_segments(pl_.seg2, n / TILE_E + p + 1);
             uint64_t out2[2];
             be_.d2h(out2, pl_.seg2.out2, sizeof out2);
+            uint32_t* first_part = reinterpret_cast<uint32_t*>(pl_.desc);      // [n_tiles1], the tile descriptors are idle here
+            CAPS_LAUNCH((collate_plan_kernel<idx_t>), (n_tiles1 + 255) / 256, 256, be_, pl_.seg1.desc(), p, (const idx_t*)pl_.Pm,
+                        first_part);
             CAPS_LAUNCH((collate_kernel<idx_t>), n_tiles1, TILE_NT, be_, pl_.seg1.desc(), p, (const idx_t*)pl_.Pm,
-                        (const idx_t*)pl_.ruler, (const uint64_t*)pl_.seg2.seg_start, (const uint64_t*)cur.key,
-                        (const idx_t*)cur.sa, oth.key, oth.sa);
+                        (const idx_t*)pl_.ruler, (const uint64_t*)pl_.seg2.seg_start, (const uint32_t*)first_part,
+                        (const uint64_t*)cur.key, (const idx_t*)cur.sa, oth.key, oth.sa);
             be_.sync();                                   // out2 = {#tiles, largest partition}
             const uint32_t n_tiles2 = (uint32_t)out2[0];
             max_part = out2[1];

@@ -186,9 +186,13 @@ public:
         // local collate: partition-major == destination-major
         CAPS_LAUNCH(scan_sizes_kernel, 1, 1024, be_, (const uint64_t*)sizes_, p_, lstart_);
         if (G_)
+        {
+            uint32_t* first_part = reinterpret_cast<uint32_t*>(tdesc_);        // [n_tiles1_], idle between the sorts
+            CAPS_LAUNCH((collate_plan_kernel<idx_t>), (n_tiles1_ + 255) / 256, 256, be_, seg1_.desc(), p_, (const idx_t*)Pm_, first_part);
             CAPS_LAUNCH((collate_kernel<idx_t>), n_tiles1_, TILE_NT, be_, seg1_.desc(), p_, (const idx_t*)Pm_, (const idx_t*)ruler_,
-                        (const uint64_t*)lstart_, (const uint64_t*)cur_.key, (const idx_t*)cur_.sa,
+                        (const uint64_t*)lstart_, (const uint32_t*)first_part, (const uint64_t*)cur_.key, (const idx_t*)cur_.sa,
                         static_cast<uint64_t*>(d_send_keys), static_cast<idx_t*>(d_send_sa));
+        }
 
         // phase-2 storage and descriptors (sizes are known exactly now)
         A2_ = elems(recv_total_);
