@@ -44,6 +44,11 @@ class Stats(ctypes.Structure):
         ("tile_sort_ms", ctypes.c_double),
         ("tile_sort_launches", ctypes.c_uint64),
         ("tile_sort_elems", ctypes.c_uint64),
+        ("bucket_scatter_ms", ctypes.c_double),
+        ("bucket_scatter_launches", ctypes.c_uint64),
+        ("bucket_scatter_elems", ctypes.c_uint64),
+        ("bucket_count_ms", ctypes.c_double),
+        ("collate_ms", ctypes.c_double),
     ]
 
     def as_dict(self) -> dict:

@@ -983,9 +983,11 @@ constexpr uint32_t BUCKET_TARGET = (TILE_E * 5) / 8;   // mean bucket size: leav
 constexpr uint32_t BUCKET_LDS = TILE_BINS_;            // buckets per segment the LDS histogram can hold
 
 // range_mode 0: keys span the whole 64-bit range (subarrays of text positions);
-// range_mode 1: segment g holds keys in [pkey[g-1], pkey[g]] (partitions between pivots).
+// range_mode 1: segment g is partition j = part_off + g of part_total and holds keys in
+// [pkey[j-1], pkey[j]] (partitions between pivots; a shard owns a slice of the partitions).
 GLOBAL_FN LAUNCH_BOUNDS(256) bucket_plan_kernel(KCTX const uint64_t* __restrict__ seg_start, uint32_t G, uint32_t range_mode,
-                                                const uint64_t* __restrict__ pkey, uint32_t enable,
+                                                const uint64_t* __restrict__ pkey, uint32_t part_off, uint32_t part_total,
+                                                uint32_t enable,
                                                 BucketParams* __restrict__ bp, uint64_t* __restrict__ segB)
 {
     PAR(tid) {
@@ -993,9 +995,10 @@ GLOBAL_FN LAUNCH_BOUNDS(256) bucket_plan_kernel(KCTX const uint64_t* __restrict_
         if (g < G) {
             const uint64_t len = seg_start[g + 1] - seg_start[g];
             uint64_t kmin = 0, kmax = ~0ull;
-            if (range_mode == 1) {
-                if (g > 0) kmin = pkey[g - 1];
-                if (g + 1 < G) kmax = pkey[g];
+            if (range_mode == 1) {                   // segment g is partition part_off + g of part_total
+                const uint32_t j = part_off + g;
+                if (j > 0) kmin = pkey[j - 1];
+                if (j + 1 < part_total) kmax = pkey[j];
             }
             uint32_t B = 1;
             if (enable && len > TILE_E && kmax > kmin) B = (uint32_t)((len + BUCKET_TARGET - 1) / BUCKET_TARGET);

@@ -280,9 +280,12 @@ struct SortOpts {
     const BucketBufs* bk = nullptr;   // non-null: split long segments into key-range buckets first
     uint32_t range_mode = 0;      // bucket_plan_kernel: 0 full key range, 1 between pivots
     const uint64_t* pkey = nullptr;
+    uint32_t part_off = 0, part_total = 0;    // range_mode 1: segment g = partition part_off + g of part_total
     bool unify = false;           // gather the result into buf[0] (consumers that index whole segments)
     KernelClock* tile_clock = nullptr;
     KernelClock* merge_clock = nullptr;
+    KernelClock* scatter_clock = nullptr;
+    KernelClock* count_clock = nullptr;
     uint64_t* pass_counters = nullptr;
 };
 
@@ -308,26 +311,39 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
     if (o.bk && max_len > TILE_E) {
         const BucketBufs& bk = *o.bk;
         const SegDesc psd = s.desc();
-        CAPS_LAUNCH(bucket_plan_kernel, (s.G + 255) / 256, 256, be, (const uint64_t*)s.seg_start, s.G, o.range_mode, o.pkey, 1u,
+        CAPS_LAUNCH(bucket_plan_kernel, (s.G + 255) / 256, 256, be, (const uint64_t*)s.seg_start, s.G, o.range_mode, o.pkey, o.part_off,
+                    o.part_total ? o.part_total : s.G, 1u,
                     bk.params, bk.segB);
         CAPS_LAUNCH(scan_sizes_kernel, 1, 1024, be, (const uint64_t*)bk.segB, s.G, bk.bstart);
         be.memset(bk.count, 0, (size_t)bk.nb_cap * sizeof(uint64_t));
         be.memset(bk.cursor, 0, (size_t)bk.nb_cap * sizeof(uint32_t));
         ElemBuf<idx_t> dst = from_text ? cur : oth;
         if (from_text) {
+            BackendEvent c0 = be.record();
             CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, psd, P, o.text_base, (const uint64_t*)nullptr,
                         (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, bk.count);
+            BackendEvent c1 = be.record();
             device_exclusive_scan<uint64_t>(be, bk.count, bk.nb_cap, bk.sub.seg_start, bk.scan_tmp);
+            BackendEvent s0 = be.record();
             CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, psd, P, o.text_base, (const uint64_t*)nullptr,
                         (const idx_t*)nullptr, (const BucketParams*)bk.params, (const uint64_t*)bk.bstart,
                         (const uint64_t*)bk.sub.seg_start, bk.cursor, dst.key, dst.sa);
+            BackendEvent s1 = be.record();
+            if (o.count_clock) { o.count_clock->spans.push_back({c0, c1}); o.count_clock->elems.push_back(n_elems); }
+            if (o.scatter_clock) { o.scatter_clock->spans.push_back({s0, s1}); o.scatter_clock->elems.push_back(n_elems); }
         } else {
+            BackendEvent c0 = be.record();
             CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, psd, P, (uint64_t)0, (const uint64_t*)cur.key,
                         (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, bk.count);
+            BackendEvent c1 = be.record();
             device_exclusive_scan<uint64_t>(be, bk.count, bk.nb_cap, bk.sub.seg_start, bk.scan_tmp);
+            BackendEvent s0 = be.record();
             CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, psd, P, (uint64_t)0, (const uint64_t*)cur.key,
                         (const idx_t*)cur.sa, (const BucketParams*)bk.params, (const uint64_t*)bk.bstart,
                         (const uint64_t*)bk.sub.seg_start, bk.cursor, dst.key, dst.sa);
+            BackendEvent s1 = be.record();
+            if (o.count_clock) { o.count_clock->spans.push_back({c0, c1}); o.count_clock->elems.push_back(n_elems); }
+            if (o.scatter_clock) { o.scatter_clock->spans.push_back({s0, s1}); o.scatter_clock->elems.push_back(n_elems); }
             std::swap(cur, oth);                         // the scattered copy is the working buffer now
             r.buf[0] = cur;
             r.buf[1] = oth;
@@ -416,6 +432,9 @@ private:
     int bits_ = 0;
     KernelClock merge_clock_;
     KernelClock tile_clock_;
+    KernelClock scatter_clock_;
+    KernelClock count_clock_;
+    KernelClock collate_clock_;
     uint32_t pass_base_ = 0;
 
     // timed: the full-size sorts (phase 1, phase 2) feed the kernel clocks of caps_sa_stats;
@@ -427,6 +446,8 @@ private:
         if (timed) {
             o.tile_clock = &tile_clock_;
             o.merge_clock = &merge_clock_;
+            o.scatter_clock = &scatter_clock_;
+            o.count_clock = &count_clock_;
             o.pass_counters = pl_.pass_elems + pass_base_;
         }
         SortResult<idx_t> r = segmented_sort<idx_t, BITS>(be_, pl_.P, pl_.n, pl_.desc, s, n_tiles, max_len, cur, oth, n_elems, o);
@@ -504,11 +525,15 @@ private:
             uint64_t out2[2];
             be_.d2h(out2, pl_.seg2.out2, sizeof out2);
             uint32_t* first_part = reinterpret_cast<uint32_t*>(pl_.desc);      // [n_tiles1], the tile descriptors are idle here
+            BackendEvent k0 = be_.record();
             CAPS_LAUNCH((collate_plan_kernel<idx_t>), (n_tiles1 + 255) / 256, 256, be_, pl_.seg1.desc(), p, (const idx_t*)pl_.Pm,
                         first_part);
             CAPS_LAUNCH((collate_kernel<idx_t>), n_tiles1, TILE_NT, be_, pl_.seg1.desc(), p, (const idx_t*)pl_.Pm,
                         (const idx_t*)pl_.ruler, (const uint64_t*)pl_.seg2.seg_start, (const uint32_t*)first_part,
                         (const uint64_t*)cur.key, (const idx_t*)cur.sa, oth.key, oth.sa);
+            BackendEvent k1 = be_.record();
+            collate_clock_.spans.push_back({k0, k1});
+            collate_clock_.elems.push_back(n);
             be_.sync();                                   // out2 = {#tiles, largest partition}
             const uint32_t n_tiles2 = (uint32_t)out2[0];
             max_part = out2[1];
@@ -560,6 +585,10 @@ private:
             };
             sum(merge_clock_, &st->merge_pass_ms, &st->merge_pass_launches, &st->merge_pass_elems);
             sum(tile_clock_, &st->tile_sort_ms, &st->tile_sort_launches, &st->tile_sort_elems);
+            uint64_t dummy_l = 0, dummy_e = 0;
+            sum(scatter_clock_, &st->bucket_scatter_ms, &st->bucket_scatter_launches, &st->bucket_scatter_elems);
+            sum(count_clock_, &st->bucket_count_ms, &dummy_l, &dummy_e);
+            sum(collate_clock_, &st->collate_ms, &dummy_l, &dummy_e);
             st->merge_pass_elems = 0;                      // elements the timed passes really merged
             for (uint32_t i = 0; i < pass_base_ && i < kMaxPasses; ++i) st->merge_pass_elems += pass_elems[i];
         }

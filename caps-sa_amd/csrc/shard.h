@@ -74,7 +74,8 @@ public:
             ruler_ = get<idx_t>((size_t)(G_ ? G_ : 1) * p_);
             sizes_ = get<uint64_t>(p_);
             lstart_ = get<uint64_t>((size_t)p_ + 1);
-            const uint64_t a = local_n_ / TILE_E + G_ + 3, b = m_total_ / TILE_E + 3;
+            bk1_ = buckets(local_n_, G_ ? G_ : 1);
+            const uint64_t a = bk1_.tile_cap + 3, b = m_total_ / TILE_E + 3;
             tdesc_ = get<TileDesc>(a > b ? a : b);
         } catch (...) {
             release();
@@ -102,8 +103,8 @@ public:
             const uint64_t last = local_n_ - (uint64_t)(G_ - 1) * s_;
             n_tiles1_ = (G_ - 1) * tiles_of(s_) + tiles_of(last);
             prepare_segments(be_, seg1_, n_tiles1_);
-            cur_ = (bits_ == 2 ? sort<2>(seg1_, n_tiles1_, last, true, A_, B_, local_n_, text_base_, false, false)
-                               : sort<8>(seg1_, n_tiles1_, last, true, A_, B_, local_n_, text_base_, false, false)).uniform();
+            cur_ = (bits_ == 2 ? sort<2>(seg1_, n_tiles1_, last, true, A_, B_, local_n_, text_base_, false, false, &bk1_, true)
+                               : sort<8>(seg1_, n_tiles1_, last, true, A_, B_, local_n_, text_base_, false, false, &bk1_, true)).uniform();
             oth_ = cur_.key == A_.key ? B_ : A_;
             CAPS_LAUNCH((sample_kernel<idx_t>), (uint32_t)((m_local_ + 255) / 256), 256, be_, (const uint64_t*)seg1_.seg_start, G_,
                         ppp_, (const uint64_t*)cur_.key, (const idx_t*)cur_.sa, static_cast<uint64_t*>(d_sample_keys),
@@ -199,7 +200,8 @@ public:
         B2_ = elems(recv_total_);
         seg2_ = segs(G2_ ? G2_ : 1, recv_total_ / TILE_E + G2_ + 2);
         seg2_.G = G2_;
-        tdesc2_ = get<TileDesc>(recv_total_ / TILE_E + G2_ + 3);
+        bk2_ = buckets(recv_total_, G2_ ? G2_ : 1);
+        tdesc2_ = get<TileDesc>(bk2_.tile_cap + 3);
         std::vector<uint64_t> st((size_t)G2_ + 1, 0);
         max_len2_ = 0;
         n_tiles2_ = 0;
@@ -243,10 +245,10 @@ public:
             prepare_segments(be_, seg2_, n_tiles2_);
             std::swap(tdesc_, tdesc2_);
             if (bits_ == 2) {
-                SortResult<idx_t> r = sort<2>(seg2_, n_tiles2_, max_len2_, false, A2_, B2_, recv_total_, 0, true, true);
+                SortResult<idx_t> r = sort<2>(seg2_, n_tiles2_, max_len2_, false, A2_, B2_, recv_total_, 0, true, true, &bk2_, false, true);
                 finalize<idx_t, 2>(be_, P_, n_, r, static_cast<idx_t*>(dSA), static_cast<idx_t*>(dLCP));
             } else {
-                SortResult<idx_t> r = sort<8>(seg2_, n_tiles2_, max_len2_, false, A2_, B2_, recv_total_, 0, true, true);
+                SortResult<idx_t> r = sort<8>(seg2_, n_tiles2_, max_len2_, false, A2_, B2_, recv_total_, 0, true, true, &bk2_, false, true);
                 finalize<idx_t, 8>(be_, P_, n_, r, static_cast<idx_t*>(dSA), static_cast<idx_t*>(dLCP));
             }
             std::swap(tdesc_, tdesc2_);
@@ -293,6 +295,7 @@ private:
     uint8_t* lut_ = nullptr;
     ElemBuf<idx_t> A_, B_, SA_, SB_, A2_, B2_, cur_, oth_;
     idx_t* dSA_ = nullptr;
+    BucketBufs bk1_, bk2_;
     TileDesc *tdesc_ = nullptr, *tdesc2_ = nullptr;
     SegBufs seg1_, segS_, seg2_;
     uint64_t *pkey_ = nullptr, *sizes_ = nullptr, *lstart_ = nullptr, *desc_ = nullptr;
@@ -330,14 +333,37 @@ private:
     }
     template <int BITS>
     SortResult<idx_t> sort(const SegBufs& s, uint32_t n_tiles, uint64_t max_len, bool from_text, ElemBuf<idx_t> a, ElemBuf<idx_t> b,
-                           uint64_t n_elems, uint64_t text_base, bool need_lcp, bool skip_finished)
+                           uint64_t n_elems, uint64_t text_base, bool need_lcp, bool skip_finished, const BucketBufs* bk = nullptr,
+                           bool unify = false, bool between_pivots = false)
     {
         SortOpts o;
+        if (between_pivots) {                     // owned partitions jlo_ .. jhi_-1 of p_
+            o.range_mode = 1;
+            o.pkey = pkey_;
+            o.part_off = jlo_;
+            o.part_total = p_;
+        }
         o.from_text = from_text;
         o.text_base = text_base;
         o.need_lcp = need_lcp;
         o.skip_finished = skip_finished;
+        o.bk = bk;
+        o.unify = unify;
         return segmented_sort<idx_t, BITS>(be_, P_, n_, tdesc_, s, n_tiles, max_len, a, b, n_elems, o);
+    }
+    BucketBufs buckets(uint64_t n_elems, uint32_t G)
+    {
+        BucketBufs k;
+        k.nb_cap = BucketBufs::bucket_bound(n_elems ? n_elems : 1, G);
+        k.tile_cap = (n_elems ? n_elems : 1) / TILE_E + k.nb_cap + 2;
+        k.params = get<BucketParams>(G);
+        k.segB = get<uint64_t>(G);
+        k.bstart = get<uint64_t>((size_t)G + 1);
+        k.count = get<uint64_t>(k.nb_cap);
+        k.cursor = get<uint32_t>(k.nb_cap);
+        k.scan_tmp = get<uint64_t>(2 * ((size_t)k.nb_cap / SCAN_CHUNK + 2));
+        k.sub = segs(k.nb_cap, k.tile_cap);
+        return k;
     }
 };
 

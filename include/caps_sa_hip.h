@@ -59,6 +59,10 @@ typedef struct caps_sa_stats {
     /* the two tile-granular kernels, summed over their launches in this build */
     double merge_pass_ms;  uint64_t merge_pass_launches;  uint64_t merge_pass_elems;
     double tile_sort_ms;   uint64_t tile_sort_launches;   uint64_t tile_sort_elems;
+    /* bucketing (count + scatter kernels) and collate, same convention */
+    double bucket_scatter_ms; uint64_t bucket_scatter_launches; uint64_t bucket_scatter_elems;
+    double bucket_count_ms;
+    double collate_ms;
 } caps_sa_stats;
 
 int caps_sa_hip_device_count(void);
