@@ -449,6 +449,18 @@ DEV_INLINE void block_exclusive_scan_bins(KCTX uint32_t* hist)
 #endif
 }
 
+// Final destination of a sort whose result is THE suffix / LCP array (phase 2): SA and LCP slots
+// of the caller plus, per sorted segment, its first and last (key, sa) -- the boundary records
+// from which head_lcp_kernel computes the LCP at every segment head (a11).
+template <typename idx_t> struct FinalOut {
+    idx_t* sa = nullptr;
+    idx_t* lcp = nullptr;
+    uint64_t* first_key = nullptr;
+    uint64_t* last_key = nullptr;
+    idx_t* first_sa = nullptr;
+    idx_t* last_sa = nullptr;
+};
+
 // Bins of the in-LDS bucket sort of one tile, and the bin occupancy above which the tile
 // falls back to the merge levels.
 constexpr uint32_t TILE_BINS = TILE_BINS_;
@@ -472,10 +484,12 @@ constexpr uint32_t TILE_BIN_LIMIT = 24;
 template <typename idx_t, int BITS, bool FROM_TEXT>
 GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
                                                   uint64_t text_base, uint32_t lcp_mode, const uint64_t* in_key,
-                                                  const idx_t* in_sa, uint64_t* out_key, idx_t* out_sa, idx_t* out_lcp)
+                                                  const idx_t* in_sa, uint64_t* out_key, idx_t* out_sa, idx_t* out_lcp,
+                                                  FinalOut<idx_t> fin)
 {
     const uint32_t b = K_BLOCK_IDX;
     if (b >= sd.tile_off[sd.G]) return;
+    const uint32_t g = sd.tile_seg[b];
     const TileInfo t = tile_info(sd, b);
     const uint64_t start = t.s0 + (uint64_t)t.tl * TILE_E;
     const uint32_t cnt = (uint32_t)(t.s1 - start < TILE_E ? t.s1 - start : TILE_E);
@@ -483,6 +497,9 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
     // LCPs are only needed from the sort that completes a segment: lcp_mode 0 = never,
     // 1 = when the whole segment is this tile (otherwise its final merge pass emits them).
     const bool with_lcp = lcp_mode != 0 && (t.s1 - t.s0) <= TILE_E;
+    // fin.sa != null: a segment completed here goes straight to the caller's SA / LCP arrays
+    // (its head LCP is filled in by head_lcp_kernel from the boundary records).
+    const bool direct = with_lcp && fin.sa != nullptr;
 
     SHARED_ARRAY(uint64_t, skey, TILE_E);
     SHARED_ARRAY(idx_t, ssa, TILE_E);
@@ -669,12 +686,17 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
             if (e < cnt) {
                 const uint64_t key = skey[e];
                 const idx_t sa = ssa[e];
-                out_key[start + e] = key;
-                out_sa[start + e] = sa;
-                if (with_lcp) {
-                    uint64_t l = 0;
-                    if (e) l = pair_lcp<BITS>(P, n, skey[e - 1], (uint64_t)ssa[e - 1], key, (uint64_t)sa);
-                    out_lcp[start + e] = (idx_t)l;
+                uint64_t l = 0;
+                if (with_lcp && e) l = pair_lcp<BITS>(P, n, skey[e - 1], (uint64_t)ssa[e - 1], key, (uint64_t)sa);
+                if (direct) {
+                    fin.sa[start + e] = sa;
+                    fin.lcp[start + e] = (idx_t)l;
+                    if (e == 0) { fin.first_key[g] = key; fin.first_sa[g] = sa; }
+                    if (e == cnt - 1) { fin.last_key[g] = key; fin.last_sa[g] = sa; }
+                } else {
+                    out_key[start + e] = key;
+                    out_sa[start + e] = sa;
+                    if (with_lcp) out_lcp[start + e] = (idx_t)l;
                 }
             }
         }
@@ -932,22 +954,28 @@ template <typename idx_t> struct PingPong {
 template <typename idx_t, int BITS>
 GLOBAL_FN LAUNCH_BOUNDS(256) finalize_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n, PingPong<idx_t> pp,
                                              uint32_t skip_finished, uint32_t uniform_sel, idx_t* __restrict__ dSA,
-                                             idx_t* __restrict__ dLCP)
+                                             idx_t* __restrict__ dLCP, FinalOut<idx_t> fin)
 {
     const uint32_t b = K_BLOCK_IDX;
     if (b >= sd.tile_off[sd.G]) return;
     const uint32_t g = sd.tile_seg[b];
     const TileInfo t = tile_info(sd, b);
+    const uint64_t seglen = t.s1 - t.s0;
+    // with boundary records (fin): segments completed by the tile sort are already in place
+    if (fin.sa != nullptr && seglen <= TILE_E) return;
     const uint64_t start = t.s0 + (uint64_t)t.tl * TILE_E;
     const uint32_t cnt = (uint32_t)(t.s1 - start < TILE_E ? t.s1 - start : TILE_E);
-    const uint32_t sel = skip_finished ? (passes_for(t.s1 - t.s0) & 1u) : uniform_sel;
+    const uint32_t sel = skip_finished ? (passes_for(seglen) & 1u) : uniform_sel;
     const idx_t* __restrict__ src_sa = pp.sa[sel];
     const idx_t* __restrict__ src_lcp = pp.lcp[sel];
     PAR(tid) {
         for (uint32_t e = tid; e < cnt; e += K_BLOCK_DIM) {
             dSA[start + e] = src_sa[start + e];
             uint64_t l = (uint64_t)src_lcp[start + e];
-            if (e == 0 && t.tl == 0 && start > 0) {
+            if (fin.sa != nullptr) {
+                if (e == 0 && t.tl == 0) { fin.first_key[g] = pp.key[sel][start]; fin.first_sa[g] = src_sa[start]; }
+                if (start + e == t.s1 - 1) { fin.last_key[g] = pp.key[sel][start + e]; fin.last_sa[g] = src_sa[start + e]; }
+            } else if (e == 0 && t.tl == 0 && start > 0) {
                 // head of segment g: predecessor = last element of the nearest non-empty segment below
                 uint32_t h = g;
                 while (h > 0 && sd.seg_start[h] == sd.seg_start[h - 1]) --h;      // skip empty ones
@@ -958,6 +986,26 @@ GLOBAL_FN LAUNCH_BOUNDS(256) finalize_kernel(KCTX SegDesc sd, const uint32_t* __
                                    (uint64_t)src_sa[start]);
             }
             dLCP[start + e] = (idx_t)l;
+        }
+    }
+}
+
+// a11 with boundary records: LCP at the head of every non-empty segment but the first =
+// lcp(last suffix of the nearest non-empty segment below, first suffix of this one).
+template <typename idx_t, int BITS>
+GLOBAL_FN LAUNCH_BOUNDS(256) head_lcp_kernel(KCTX const uint32_t* __restrict__ P, uint64_t n, const uint64_t* __restrict__ seg_start,
+                                             uint32_t G, FinalOut<idx_t> fin)
+{
+    PAR(tid) {
+        const uint64_t g = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (g < G && g > 0) {
+            const uint64_t at = seg_start[g];
+            if (seg_start[g + 1] > at && at > 0) {
+                uint64_t h = g - 1;
+                while (seg_start[h + 1] == seg_start[h]) --h;             // at > 0: a non-empty one exists below
+                fin.lcp[at] = (idx_t)pair_lcp<BITS>(P, n, fin.last_key[h], (uint64_t)fin.last_sa[h], fin.first_key[g],
+                                                    (uint64_t)fin.first_sa[g]);
+            }
         }
     }
 }
@@ -1016,19 +1064,19 @@ GLOBAL_FN LAUNCH_BOUNDS(256) bucket_plan_kernel(KCTX const uint64_t* __restrict_
     }
 }
 
-// Key of element i of a segment array: cut from the packed text (phase 1: element i of the
-// array is text position text_base + i) or read from the key array.
-template <typename idx_t, int BITS, bool FROM_TEXT>
-DEV_INLINE uint64_t elem_key(const uint32_t* __restrict__ P, uint64_t text_base, const uint64_t* __restrict__ in_key, uint64_t i)
-{
-    if (FROM_TEXT) return window64<BITS>(P, text_base + i);
-    return in_key[i];
-}
+// Keys of a tile of consecutive text positions are cut from a copy of the tile's slice of the
+// packed text in LDS (one coalesced read of ~1 KiB) instead of three dependent global loads
+// per suffix.  TEXT_WIN words cover TILE_E positions + one key + alignment slack for BITS = 8.
+constexpr uint32_t TEXT_WIN = TILE_E / 4 + 24;
+
+// word index (in P) of the first staged word for a tile whose first text position is pos0
+template <int BITS> HD uint64_t text_win_base(uint64_t pos0) { return pos0 / TextTraits<BITS>::CPW; }
 
 template <typename idx_t, int BITS, bool FROM_TEXT>
-GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_count_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t text_base,
-                                                     const uint64_t* __restrict__ in_key, const BucketParams* __restrict__ bps,
-                                                     const uint64_t* __restrict__ bstart, uint64_t* __restrict__ count)
+GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_count_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n_words,
+                                                     uint64_t text_base, const uint64_t* __restrict__ in_key,
+                                                     const BucketParams* __restrict__ bps, const uint64_t* __restrict__ bstart,
+                                                     uint64_t* __restrict__ count)
 {
     const uint32_t b = K_BLOCK_IDX;
     if (b >= sd.tile_off[sd.G]) return;
@@ -1039,21 +1087,27 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_count_kernel(KCTX SegDesc sd, const uint
     const BucketParams bp = bps[g];
     const uint64_t b0 = bstart[g];
     SHARED_ARRAY(uint32_t, hist, BUCKET_LDS);
+    SHARED_ARRAY(uint32_t, twin, FROM_TEXT ? TEXT_WIN : 1);
     if (bp.B == 1) {                                   // the segment is its own bucket
         PAR(tid) { if (tid == 0) ATOMIC_ADD_U64(&count[b0], (uint64_t)cnt); }
         return;
     }
     const bool lds = bp.B <= BUCKET_LDS;
-    if (lds) {
-        PAR(tid) { for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM) hist[i] = 0; }
-        SYNC();
+    const uint64_t w0 = text_win_base<BITS>(text_base + start);
+    PAR(tid) {
+        if (lds) for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM) hist[i] = 0;
+        if (FROM_TEXT)
+            for (uint32_t i = tid; i < TEXT_WIN; i += K_BLOCK_DIM) twin[i] = w0 + i < n_words ? P[w0 + i] : 0u;
     }
+    SYNC();
     PAR(tid) {
         UNROLL
         for (uint32_t k = 0; k < TILE_EPT; ++k) {
             const uint32_t e = tid + k * TILE_NT;
             if (e < cnt) {
-                const uint32_t bk = bucket_of(bp, elem_key<idx_t, BITS, FROM_TEXT>(P, text_base, in_key, start + e));
+                const uint64_t key = FROM_TEXT ? window64<BITS>(twin, text_base + start + e - w0 * TextTraits<BITS>::CPW)
+                                               : in_key[start + e];
+                const uint32_t bk = bucket_of(bp, key);
                 if (lds) FETCH_ADD_U32(&hist[bk], 1u);
                 else ATOMIC_ADD_U64(&count[b0 + bk], 1ull);
             }
@@ -1074,8 +1128,9 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_count_kernel(KCTX SegDesc sd, const uint
 // that consecutive lanes write consecutive slots (a bucket receives a run of consecutive
 // elements from every tile instead of 64 scattered 8-byte stores per wave instruction).
 template <typename idx_t, int BITS, bool FROM_TEXT>
-GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t text_base,
-                                                       const uint64_t* __restrict__ in_key, const idx_t* __restrict__ in_sa,
+GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n_words,
+                                                       uint64_t text_base, const uint64_t* __restrict__ in_key,
+                                                       const idx_t* __restrict__ in_sa,
                                                        const BucketParams* __restrict__ bps, const uint64_t* __restrict__ bstart,
                                                        const uint64_t* __restrict__ sub_start, uint32_t* __restrict__ cursor,
                                                        uint64_t* __restrict__ out_key, idx_t* __restrict__ out_sa)
@@ -1098,8 +1153,15 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
     TL_DECL(uint32_t, rb, TILE_EPT);      // bucket
     TL_DECL(uint32_t, rr, TILE_EPT);      // rank inside (tile, bucket) or inside the bucket
     const bool lds = bp.B > 1 && bp.B <= BUCKET_LDS;
-    if (lds) {
-        PAR(tid) { for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0; }
+    // FROM_TEXT: the tile's slice of the packed text is staged in the (not yet used) key staging array
+    uint32_t* twin = reinterpret_cast<uint32_t*>(skey);
+    const uint64_t w0 = text_win_base<BITS>(text_base + start);
+    if (lds || FROM_TEXT) {
+        PAR(tid) {
+            if (lds) for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0;
+            if (FROM_TEXT)
+                for (uint32_t i = tid; i < TEXT_WIN; i += K_BLOCK_DIM) twin[i] = w0 + i < n_words ? P[w0 + i] : 0u;
+        }
         SYNC();
     }
     PAR(tid) {
@@ -1107,7 +1169,8 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
         for (uint32_t k = 0; k < TILE_EPT; ++k) {
             const uint32_t e = tid + k * TILE_NT;
             if (e < cnt) {
-                const uint64_t key = elem_key<idx_t, BITS, FROM_TEXT>(P, text_base, in_key, start + e);
+                const uint64_t key = FROM_TEXT ? window64<BITS>(twin, text_base + start + e - w0 * TextTraits<BITS>::CPW)
+                                               : in_key[start + e];
                 const idx_t sa = FROM_TEXT ? (idx_t)(text_base + start + e) : in_sa[start + e];
                 uint32_t bk = 0, r;
                 if (bp.B == 1) r = (uint32_t)(start - t.s0) + e;             // identity: the segment is its own bucket

@@ -69,6 +69,8 @@ struct BucketBufs {
     uint64_t* count = nullptr;        // [nb_cap] elements per bucket
     uint32_t* cursor = nullptr;       // [nb_cap]
     uint64_t* scan_tmp = nullptr;     // [2 * (nb_cap / SCAN_CHUNK + 2)]
+    uint64_t *first_key = nullptr, *last_key = nullptr;   // [nb_cap] boundary records of the sorted segments
+    void *first_sa = nullptr, *last_sa = nullptr;         // [nb_cap] idx_t
     SegBufs sub;                      // the buckets as segments (G = nb_cap, trailing ones empty)
     uint32_t nb_cap = 0;
     uint64_t tile_cap = 0;
@@ -160,6 +162,10 @@ Plan<idx_t> make_plan(uint64_t n, uint64_t p_arg, char* base)
     pl.bk.count = ar.take<uint64_t>(pl.bk.nb_cap);
     pl.bk.cursor = ar.take<uint32_t>(pl.bk.nb_cap);
     pl.bk.scan_tmp = ar.take<uint64_t>(2 * ((size_t)pl.bk.nb_cap / SCAN_CHUNK + 2));
+    pl.bk.first_key = ar.take<uint64_t>(pl.bk.nb_cap);
+    pl.bk.last_key = ar.take<uint64_t>(pl.bk.nb_cap);
+    pl.bk.first_sa = ar.take<idx_t>(pl.bk.nb_cap);
+    pl.bk.last_sa = ar.take<idx_t>(pl.bk.nb_cap);
     segs(pl.bk.sub, pl.bk.nb_cap, pl.bk.tile_cap);
     pl.pass_elems = ar.take<uint64_t>(kMaxPasses);
     pl.present = ar.take<uint32_t>(8);
@@ -262,6 +268,7 @@ template <typename idx_t> struct SortResult {
     bool unified = false;                                             // everything was gathered into buf[0]
     SegBufs segs;                                                     // the segments that were sorted (buckets, if bucketed)
     uint32_t n_tiles = 0;
+    FinalOut<idx_t> fin;                                              // direct final output (may be empty)
     ElemBuf<idx_t> uniform() const { return unified ? buf[0] : buf[passes & 1]; }   // valid when unified or !skip_finished
     PingPong<idx_t> pingpong() const
     {
@@ -282,6 +289,9 @@ struct SortOpts {
     const uint64_t* pkey = nullptr;
     uint32_t part_off = 0, part_total = 0;    // range_mode 1: segment g = partition part_off + g of part_total
     bool unify = false;           // gather the result into buf[0] (consumers that index whole segments)
+    void* final_sa = nullptr;     // non-null (with need_lcp): completed segments are written straight to the
+    void* final_lcp = nullptr;    //   caller's SA / LCP arrays; boundary records in `bnd` (6 arrays of G entries)
+    struct { uint64_t *first_key, *last_key; void *first_sa, *last_sa; } bnd = {nullptr, nullptr, nullptr, nullptr};
     KernelClock* tile_clock = nullptr;
     KernelClock* merge_clock = nullptr;
     KernelClock* scatter_clock = nullptr;
@@ -320,12 +330,12 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         ElemBuf<idx_t> dst = from_text ? cur : oth;
         if (from_text) {
             BackendEvent c0 = be.record();
-            CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, psd, P, o.text_base, (const uint64_t*)nullptr,
+            CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, psd, P, packed_words(n, BITS), o.text_base, (const uint64_t*)nullptr,
                         (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, bk.count);
             BackendEvent c1 = be.record();
             device_exclusive_scan<uint64_t>(be, bk.count, bk.nb_cap, bk.sub.seg_start, bk.scan_tmp);
             BackendEvent s0 = be.record();
-            CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, psd, P, o.text_base, (const uint64_t*)nullptr,
+            CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, psd, P, packed_words(n, BITS), o.text_base, (const uint64_t*)nullptr,
                         (const idx_t*)nullptr, (const BucketParams*)bk.params, (const uint64_t*)bk.bstart,
                         (const uint64_t*)bk.sub.seg_start, bk.cursor, dst.key, dst.sa);
             BackendEvent s1 = be.record();
@@ -333,12 +343,12 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
             if (o.scatter_clock) { o.scatter_clock->spans.push_back({s0, s1}); o.scatter_clock->elems.push_back(n_elems); }
         } else {
             BackendEvent c0 = be.record();
-            CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, psd, P, (uint64_t)0, (const uint64_t*)cur.key,
+            CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, psd, P, (uint64_t)0, (uint64_t)0, (const uint64_t*)cur.key,
                         (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, bk.count);
             BackendEvent c1 = be.record();
             device_exclusive_scan<uint64_t>(be, bk.count, bk.nb_cap, bk.sub.seg_start, bk.scan_tmp);
             BackendEvent s0 = be.record();
-            CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, psd, P, (uint64_t)0, (const uint64_t*)cur.key,
+            CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, psd, P, (uint64_t)0, (uint64_t)0, (const uint64_t*)cur.key,
                         (const idx_t*)cur.sa, (const BucketParams*)bk.params, (const uint64_t*)bk.bstart,
                         (const uint64_t*)bk.sub.seg_start, bk.cursor, dst.key, dst.sa);
             BackendEvent s1 = be.record();
@@ -365,13 +375,23 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
     }
     const SegDesc sd = segs.desc();
     const uint32_t lcp_mode = o.need_lcp ? 1u : 0u;
+    FinalOut<idx_t> fin;
+    if (o.need_lcp && o.final_sa) {
+        fin.sa = static_cast<idx_t*>(o.final_sa);
+        fin.lcp = static_cast<idx_t*>(o.final_lcp);
+        fin.first_key = o.bnd.first_key;
+        fin.last_key = o.bnd.last_key;
+        fin.first_sa = static_cast<idx_t*>(o.bnd.first_sa);
+        fin.last_sa = static_cast<idx_t*>(o.bnd.last_sa);
+    }
+    r.fin = fin;
     BackendEvent t0 = be.record();
     if (from_text)
         CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, sd, P, n, o.text_base, lcp_mode,
-                    (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp);
+                    (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin);
     else
         CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode,
-                    (const uint64_t*)cur.key, (const idx_t*)cur.sa, cur.key, cur.sa, cur.lcp);
+                    (const uint64_t*)cur.key, (const idx_t*)cur.sa, cur.key, cur.sa, cur.lcp, fin);
     BackendEvent t1 = be.record();
     if (o.tile_clock) { o.tile_clock->spans.push_back({t0, t1}); o.tile_clock->elems.push_back(n_elems); }
     const uint32_t grid = n_tiles < be.persistent_blocks() ? n_tiles : be.persistent_blocks();
@@ -399,12 +419,18 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
 }
 
 // Gather SA/LCP of a sorted segment set into the caller's arrays + segment-head LCPs (a11).
+// With boundary records (r.fin) only the segments that needed merge passes are still to be
+// copied; the heads are then fixed from the records.
 template <typename idx_t, int BITS>
 void finalize(Backend& be, const uint32_t* P, uint64_t n, const SortResult<idx_t>& r, idx_t* dSA, idx_t* dLCP)
 {
     if (r.n_tiles == 0) return;
-    CAPS_LAUNCH((finalize_kernel<idx_t, BITS>), r.n_tiles, 256, be, r.segs.desc(), P, n, r.pingpong(), r.skip_finished ? 1u : 0u,
-                r.passes & 1u, dSA, dLCP);
+    if (r.fin.sa == nullptr || r.passes > 0)
+        CAPS_LAUNCH((finalize_kernel<idx_t, BITS>), r.n_tiles, 256, be, r.segs.desc(), P, n, r.pingpong(), r.skip_finished ? 1u : 0u,
+                    r.passes & 1u, dSA, dLCP, r.fin);
+    if (r.fin.sa != nullptr)
+        CAPS_LAUNCH((head_lcp_kernel<idx_t, BITS>), (r.segs.G + 255) / 256, 256, be, P, n, (const uint64_t*)r.segs.seg_start, r.segs.G,
+                    r.fin);
 }
 
 template <typename idx_t> class Builder {
@@ -455,6 +481,16 @@ private:
         return r;
     }
     void prepare_segments(const SegBufs& s, uint64_t tile_bound) { ::caps::prepare_segments(be_, s, tile_bound); }
+    // completed segments go straight to the caller's arrays (boundary records live in pl_.bk)
+    void set_final(SortOpts& o, idx_t* dSA, idx_t* dLCP)
+    {
+        o.final_sa = dSA;
+        o.final_lcp = dLCP;
+        o.bnd.first_key = pl_.bk.first_key;
+        o.bnd.last_key = pl_.bk.last_key;
+        o.bnd.first_sa = pl_.bk.first_sa;
+        o.bnd.last_sa = pl_.bk.last_sa;
+    }
 
     template <int BITS>
     void run(idx_t* dSA, idx_t* dLCP, caps_sa_stats* st, BackendEvent e0, BackendEvent e1)
@@ -475,6 +511,7 @@ private:
             o.from_text = true;
             o.need_lcp = true;
             o.bk = &pl_.bk;                     // one segment: bucket it by key range too
+            set_final(o, dSA, dLCP);
             SortResult<idx_t> r = seg_sort<BITS>(pl_.seg1, tiles_of(n), n, pl_.A, pl_.B, n, o, true);
             passes1 = r.passes;
             e2 = e3 = e4 = e5 = e6 = be_.record();
@@ -546,6 +583,7 @@ private:
             o2.bk = &pl_.bk;                    // partition j holds keys in [pivot j-1, pivot j]
             o2.range_mode = 1;
             o2.pkey = pl_.pkey;
+            set_final(o2, dSA, dLCP);
             SortResult<idx_t> r2 = seg_sort<BITS>(pl_.seg2, n_tiles2, max_part, oth, cur, n, o2, true);
             passes2 = r2.passes;
             e6 = be_.record();

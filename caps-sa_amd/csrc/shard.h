@@ -362,6 +362,10 @@ private:
         k.count = get<uint64_t>(k.nb_cap);
         k.cursor = get<uint32_t>(k.nb_cap);
         k.scan_tmp = get<uint64_t>(2 * ((size_t)k.nb_cap / SCAN_CHUNK + 2));
+        k.first_key = get<uint64_t>(k.nb_cap);
+        k.last_key = get<uint64_t>(k.nb_cap);
+        k.first_sa = get<idx_t>(k.nb_cap);
+        k.last_sa = get<idx_t>(k.nb_cap);
         k.sub = segs(k.nb_cap, k.tile_cap);
         return k;
     }
