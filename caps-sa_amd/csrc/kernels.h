@@ -1072,52 +1072,56 @@ constexpr uint32_t TEXT_WIN = TILE_E / 4 + 24;
 // word index (in P) of the first staged word for a tile whose first text position is pos0
 template <int BITS> HD uint64_t text_win_base(uint64_t pos0) { return pos0 / TextTraits<BITS>::CPW; }
 
+// Persistent workgroups (a tile is little work: launching one workgroup per tile is bound by
+// the wave launch rate).
 template <typename idx_t, int BITS, bool FROM_TEXT>
 GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_count_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n_words,
                                                      uint64_t text_base, const uint64_t* __restrict__ in_key,
                                                      const BucketParams* __restrict__ bps, const uint64_t* __restrict__ bstart,
                                                      uint64_t* __restrict__ count)
 {
-    const uint32_t b = K_BLOCK_IDX;
-    if (b >= sd.tile_off[sd.G]) return;
-    const uint32_t g = sd.tile_seg[b];
-    const TileInfo t = tile_info(sd, b);
-    const uint64_t start = t.s0 + (uint64_t)t.tl * TILE_E;
-    const uint32_t cnt = (uint32_t)(t.s1 - start < TILE_E ? t.s1 - start : TILE_E);
-    const BucketParams bp = bps[g];
-    const uint64_t b0 = bstart[g];
     SHARED_ARRAY(uint32_t, hist, BUCKET_LDS);
     SHARED_ARRAY(uint32_t, twin, FROM_TEXT ? TEXT_WIN : 1);
-    if (bp.B == 1) {                                   // the segment is its own bucket
-        PAR(tid) { if (tid == 0) ATOMIC_ADD_U64(&count[b0], (uint64_t)cnt); }
-        return;
-    }
-    const bool lds = bp.B <= BUCKET_LDS;
-    const uint64_t w0 = text_win_base<BITS>(text_base + start);
-    PAR(tid) {
-        if (lds) for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM) hist[i] = 0;
-        if (FROM_TEXT)
-            for (uint32_t i = tid; i < TEXT_WIN; i += K_BLOCK_DIM) twin[i] = w0 + i < n_words ? P[w0 + i] : 0u;
-    }
-    SYNC();
-    PAR(tid) {
-        UNROLL
-        for (uint32_t k = 0; k < TILE_EPT; ++k) {
-            const uint32_t e = tid + k * TILE_NT;
-            if (e < cnt) {
-                const uint64_t key = FROM_TEXT ? window64<BITS>(twin, text_base + start + e - w0 * TextTraits<BITS>::CPW)
-                                               : in_key[start + e];
-                const uint32_t bk = bucket_of(bp, key);
-                if (lds) FETCH_ADD_U32(&hist[bk], 1u);
-                else ATOMIC_ADD_U64(&count[b0 + bk], 1ull);
-            }
+    const uint32_t n_tiles = sd.tile_off[sd.G];
+    for (uint32_t b = K_BLOCK_IDX; b < n_tiles; b += K_GRID_DIM) {
+        const uint32_t g = sd.tile_seg[b];
+        const TileInfo t = tile_info(sd, b);
+        const uint64_t start = t.s0 + (uint64_t)t.tl * TILE_E;
+        const uint32_t cnt = (uint32_t)(t.s1 - start < TILE_E ? t.s1 - start : TILE_E);
+        const BucketParams bp = bps[g];
+        const uint64_t b0 = bstart[g];
+        if (bp.B == 1) {                               // the segment is its own bucket
+            PAR(tid) { if (tid == 0) ATOMIC_ADD_U64(&count[b0], (uint64_t)cnt); }
+            continue;
         }
-    }
-    if (lds) {
+        const bool lds = bp.B <= BUCKET_LDS;
+        const uint64_t w0 = text_win_base<BITS>(text_base + start);
+        PAR(tid) {
+            if (lds) for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM) hist[i] = 0;
+            if (FROM_TEXT)
+                for (uint32_t i = tid; i < TEXT_WIN; i += K_BLOCK_DIM) twin[i] = w0 + i < n_words ? P[w0 + i] : 0u;
+        }
         SYNC();
         PAR(tid) {
-            for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM)
-                if (hist[i]) ATOMIC_ADD_U64(&count[b0 + i], (uint64_t)hist[i]);
+            UNROLL
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                const uint32_t e = tid + k * TILE_NT;
+                if (e < cnt) {
+                    const uint64_t key = FROM_TEXT ? window64<BITS>(twin, text_base + start + e - w0 * TextTraits<BITS>::CPW)
+                                                   : in_key[start + e];
+                    const uint32_t bk = bucket_of(bp, key);
+                    if (lds) FETCH_ADD_U32(&hist[bk], 1u);
+                    else ATOMIC_ADD_U64(&count[b0 + bk], 1ull);
+                }
+            }
+        }
+        SYNC();
+        if (lds) {
+            PAR(tid) {
+                for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM)
+                    if (hist[i]) ATOMIC_ADD_U64(&count[b0 + i], (uint64_t)hist[i]);
+            }
+            SYNC();
         }
     }
 }
@@ -1144,7 +1148,8 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
     const BucketParams bp = bps[g];
     const uint64_t b0 = bstart[g];
     SHARED_ARRAY(uint32_t, hist, TILE_BINS + 1);          // counts -> exclusive prefix inside the tile
-    SHARED_ARRAY(uint64_t, obase, TILE_BINS);             // global slot of the tile's first element of bucket i, minus its prefix
+    SHARED_ARRAY(idx_t, obase, TILE_BINS);                // global slot of the tile's first element of bucket i, minus its prefix
+                                                          // (idx_t: 72 KiB of LDS at 32-bit indices -> two workgroups per CU)
     SHARED_ARRAY(uint64_t, skey, TILE_E);
     SHARED_ARRAY(idx_t, ssa, TILE_E);
     SHARED_ARRAY(uint16_t, sbk, TILE_E);
@@ -1203,13 +1208,13 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
     PAR(tid) {                                             // one global cursor bump per (tile, non-empty bucket)
         for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM) {
             const uint32_t c = hist[i];
-            obase[i] = c ? sub_start[b0 + i] + FETCH_ADD_U32(&cursor[b0 + i], c) : 0;
+            obase[i] = c ? (idx_t)(sub_start[b0 + i] + FETCH_ADD_U32(&cursor[b0 + i], c)) : (idx_t)0;
         }
     }
     SYNC();
     block_exclusive_scan_bins(KCTX_PASS hist);             // hist[i] = position of bucket i inside the re-ordered tile
     PAR(tid) {
-        for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM) obase[i] -= hist[i];
+        for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM) obase[i] = (idx_t)(obase[i] - hist[i]);
         UNROLL
         for (uint32_t k = 0; k < TILE_EPT; ++k) {
             const uint32_t e = tid + k * TILE_NT;
@@ -1228,7 +1233,7 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
         for (uint32_t k = 0; k < TILE_EPT; ++k) {
             const uint32_t q = tid + k * TILE_NT;
             if (q < cnt) {
-                const uint64_t dst = obase[sbk[q]] + q;
+                const uint64_t dst = (uint64_t)(idx_t)(obase[sbk[q]] + (idx_t)q);
                 out_key[dst] = skey[q];
                 out_sa[dst] = ssa[q];
             }

@@ -328,9 +328,10 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         be.memset(bk.count, 0, (size_t)bk.nb_cap * sizeof(uint64_t));
         be.memset(bk.cursor, 0, (size_t)bk.nb_cap * sizeof(uint32_t));
         ElemBuf<idx_t> dst = from_text ? cur : oth;
+        const uint32_t pgrid = n_tiles < be.persistent_blocks() ? n_tiles : be.persistent_blocks();
         if (from_text) {
             BackendEvent c0 = be.record();
-            CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, psd, P, packed_words(n, BITS), o.text_base, (const uint64_t*)nullptr,
+            CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, true>), pgrid, TILE_NT, be, psd, P, packed_words(n, BITS), o.text_base, (const uint64_t*)nullptr,
                         (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, bk.count);
             BackendEvent c1 = be.record();
             device_exclusive_scan<uint64_t>(be, bk.count, bk.nb_cap, bk.sub.seg_start, bk.scan_tmp);
@@ -343,7 +344,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
             if (o.scatter_clock) { o.scatter_clock->spans.push_back({s0, s1}); o.scatter_clock->elems.push_back(n_elems); }
         } else {
             BackendEvent c0 = be.record();
-            CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, psd, P, (uint64_t)0, (uint64_t)0, (const uint64_t*)cur.key,
+            CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, false>), pgrid, TILE_NT, be, psd, P, (uint64_t)0, (uint64_t)0, (const uint64_t*)cur.key,
                         (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, bk.count);
             BackendEvent c1 = be.record();
             device_exclusive_scan<uint64_t>(be, bk.count, bk.nb_cap, bk.sub.seg_start, bk.scan_tmp);
