@@ -1027,7 +1027,10 @@ GLOBAL_FN LAUNCH_BOUNDS(256) head_lcp_kernel(KCTX const uint32_t* __restrict__ P
 //   unify_kernel           copies the (few) buckets whose last pass ended in the other ping-pong
 //                          buffer back, for consumers that index a segment as one array
 // ----------------------------------------------------------------------------------
-constexpr uint32_t BUCKET_TARGET = (TILE_E * 5) / 8;   // mean bucket size: leaves 37 % headroom in a tile
+#ifndef CAPS_BUCKET_EIGHTHS
+#define CAPS_BUCKET_EIGHTHS 7
+#endif
+constexpr uint32_t BUCKET_TARGET = (TILE_E * CAPS_BUCKET_EIGHTHS) / 8;   // mean bucket size (headroom for the spread of bucket sizes)
 constexpr uint32_t BUCKET_LDS = TILE_BINS_;            // buckets per segment the LDS histogram can hold
 
 // range_mode 0: keys span the whole 64-bit range (subarrays of text positions);
