@@ -86,8 +86,10 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    if world > 1:
-        import caps_sa_dist  # sharded path (one process per GPU, RCCL exchange)
+    if world > 1 or os.environ.get("CAPS_SA_FORCE_SHARDED") == "1":
+        # sharded path (one process per GPU, RCCL exchange); CAPS_SA_FORCE_SHARDED=1 runs it at world
+        # size 1 too (smoke test of the multi-GPU driver on a 1-GPU box)
+        import caps_sa_dist
         return caps_sa_dist.bench_main(args, rank, local_rank, world)
 
     if not torch.cuda.is_available():

@@ -117,7 +117,12 @@ def bench_main(args, rank: int, local_rank: int, world: int):
     from bench import WORKLOADS, make_text
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist.init_process_group("nccl", device_id=dev)
+    if world == 1 and "RANK" not in os.environ:          # forced single-rank run without torchrun
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    else:
+        dist.init_process_group("nccl", device_id=dev)
     L = caps_sa_amd.lib()
     n_bases, desc = WORKLOADS[args.workload]
     if args.bases:

@@ -242,3 +242,54 @@ def test_segmented_sort_mixed_lengths(L, oracle):
     seg = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
     idx = rs.permutation(200000)[:int(seg[-1])].astype(np.uint32)
     _check_segments(L, oracle, T, idx, seg)
+
+
+def test_cli_dump_matches_reference_digest(L, oracle, tmp_path):
+    """The C++ host side (caps-sa_amd/csrc/Suffix_Array.hpp + caps_sa_cli.cpp, the mirror of the
+    reference's src/main.cpp): same arguments, same remap, same dump bytes as the real reference."""
+    import hashlib
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "caps-sa_amd"), "caps_sa"])
+    exe = os.path.join(root, "caps-sa_amd", "caps_sa")
+    raw = oracle.gen_rand_seq(123, 100000)                     # file bytes incl. the trailing newline
+    inp, out = tmp_path / "in.txt", tmp_path / "out.bin"
+    inp.write_bytes(raw.tobytes())
+    subprocess.check_call([exe, str(inp), str(out), "64"])
+    assert hashlib.sha256(out.read_bytes()).hexdigest()[:16] == "24db5e1b31a804d4"   # SURVEY 8c
+    # --pretty-print: the text form of src/main.cpp:32-40 / chatgpt_baseline.py:40-42
+    small = tmp_path / "small.txt"
+    small.write_bytes(open(os.path.join(root, "tests", "golden", "simpletest2.input"), "rb").read())
+    txt = tmp_path / "small.out"
+    subprocess.check_call([exe, str(small), str(txt), "--pretty-print"])
+    lines = txt.read_text().strip().split("\n")
+    SA, LCP = oracle.build_sa_lcp(oracle.remap(small.read_bytes()))
+    assert lines[0].split() == [str(x) for x in SA.tolist()]
+    assert lines[1].split() == [str(x) for x in LCP.tolist()]
+
+
+def test_u64_device_resident_50m(L):
+    """64-bit index kernels at a size where every stage (bucketing, chunked scans) is exercised."""
+    import torch
+    n = 50_000_001
+    g = torch.Generator(device="cuda")
+    g.manual_seed(9)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda")
+    T = lut[torch.randint(0, 4, (n,), device="cuda", generator=g, dtype=torch.int64)]
+    SA = torch.empty(n, dtype=torch.int64, device="cuda")
+    LCP = torch.empty(n, dtype=torch.int64, device="cuda")
+    st = L.build_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr(), p=1000, idx_bits=64)
+    assert st["idx_bytes"] == 8
+    assert L.verify_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr(), idx_bits=64) == 0
+
+
+def test_skewed_and_texty_inputs_device(L, oracle):
+    """Keys far from uniform in their range: buckets overflow their tile and are finished by the
+    LCP-merge passes (skip_finished / unify / finalize-with-records paths)."""
+    rs = np.random.RandomState(21)
+    T = rs.choice(DNA, size=3_000_000, p=[0.7, 0.1, 0.1, 0.1])
+    st = _same(L, oracle, T, 50)
+    assert st["merge_passes_phase1"] + st["merge_passes_phase2"] > 0
+    letters = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz ", dtype=np.uint8)
+    _same(L, oracle, rs.choice(letters, size=2_000_000, p=np.r_[np.full(26, 0.03), 0.22]), 40)
