@@ -195,6 +195,16 @@ public:
                         static_cast<uint64_t*>(d_send_keys), static_cast<idx_t*>(d_send_sa));
         }
 
+        // the phase-1 arrays are dead once the send buffers are filled: give their memory back
+        // before the phase-2 arrays are allocated (peak = max of the two phases, not their sum)
+        be_.sync();
+        for (ElemBuf<idx_t>* eb : {&A_, &B_}) {
+            drop(eb->key); drop(eb->sa); drop(eb->lcp);
+            *eb = ElemBuf<idx_t>();
+        }
+        drop(Pm_); Pm_ = nullptr;
+        drop(ruler_); ruler_ = nullptr;
+        cur_ = oth_ = ElemBuf<idx_t>();
         // phase-2 storage and descriptors (sizes are known exactly now)
         A2_ = elems(recv_total_);
         B2_ = elems(recv_total_);
@@ -325,6 +335,12 @@ private:
         s.tile_seg = get<uint32_t>(cap);
         s.out2 = get<uint64_t>(2);
         return s;
+    }
+    void drop(void* p)
+    {
+        if (!p) return;
+        for (size_t i = 0; i < owned_.size(); ++i)
+            if (owned_[i] == p) { be_.free(p); owned_[i] = owned_.back(); owned_.pop_back(); return; }
     }
     void release()
     {
