@@ -15,6 +15,7 @@
 // sequence can be driven by the host emulation used in tests/emul (kernel_lang.h).
 #pragma once
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <stdexcept>
 #include <string>
@@ -315,6 +316,8 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
     r.segs = s;
     r.n_tiles = n_tiles;
     if (n_tiles == 0) return r;
+    const bool dbg = std::getenv("CAPS_SA_DEBUG") != nullptr;
+    auto mark = [&](const char* what) { if (dbg) { be.sync(); std::fprintf(stderr, "[sort] %s\n", what); } };
     bool from_text = o.from_text;
     SegBufs segs = s;
     bool skip = o.skip_finished;
@@ -325,6 +328,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
                     o.part_total ? o.part_total : s.G, 1u,
                     bk.params, bk.segB);
         CAPS_LAUNCH(scan_sizes_kernel, 1, 1024, be, (const uint64_t*)bk.segB, s.G, bk.bstart);
+        mark("bucket plan");
         be.memset(bk.count, 0, (size_t)bk.nb_cap * sizeof(uint64_t));
         be.memset(bk.cursor, 0, (size_t)bk.nb_cap * sizeof(uint32_t));
         ElemBuf<idx_t> dst = from_text ? cur : oth;
@@ -359,6 +363,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
             r.buf[0] = cur;
             r.buf[1] = oth;
         }
+        mark("bucket scatter");
         // the buckets are the segments from here on (trailing unused ones are empty)
         segs = bk.sub;
         segs.G = bk.nb_cap;
@@ -368,6 +373,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         be.sync();
         n_tiles = (uint32_t)out2[0];
         max_len = out2[1];
+        if (dbg) std::fprintf(stderr, "[sort] buckets: tiles %u max_len %llu\n", n_tiles, (unsigned long long)max_len);
         from_text = false;
         skip = true;
         r.skip_finished = true;
@@ -394,6 +400,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode,
                     (const uint64_t*)cur.key, (const idx_t*)cur.sa, cur.key, cur.sa, cur.lcp, fin);
     BackendEvent t1 = be.record();
+    mark("tile sort");
     if (o.tile_clock) { o.tile_clock->spans.push_back({t0, t1}); o.tile_clock->elems.push_back(n_elems); }
     const uint32_t grid = n_tiles < be.persistent_blocks() ? n_tiles : be.persistent_blocks();
     ElemBuf<idx_t> a = cur, b = oth;
@@ -408,6 +415,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         if (o.merge_clock) { o.merge_clock->spans.push_back({m0, m1}); o.merge_clock->elems.push_back(n_elems); }
         std::swap(a, b);
         ++r.passes;
+        mark("merge pass");
     }
     if (o.unify && r.skip_finished && r.passes) {
         CAPS_LAUNCH((unify_kernel<idx_t>), n_tiles, 256, be, sd, (const uint64_t*)r.buf[1].key, (const idx_t*)r.buf[1].sa,

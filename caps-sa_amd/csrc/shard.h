@@ -20,6 +20,8 @@
 // The collectives themselves are issued by the host driver (caps_sa_dist.py) with
 // torch.distributed; this class only runs kernels on the rank's stream.
 #pragma once
+#include <cstdio>
+#include <cstdlib>
 #include <memory>
 #include <numeric>
 
@@ -247,12 +249,17 @@ public:
 
     void phase2(const void* d_recv_keys, const void* d_recv_sa, void* dSA, void* dLCP) override
     {
+        const bool dbg = std::getenv("CAPS_SA_DEBUG") != nullptr;
+        auto mark = [&](const char* what) { if (dbg) { be_.sync(); std::fprintf(stderr, "[shard %d] phase2: %s\n", rank_, what); } };
         BackendEvent e0 = be_.record();
+        mark("start");
         if (recv_total_) {
             if (n_desc_)
                 CAPS_LAUNCH((regroup_kernel<idx_t>), n_desc_, 256, be_, (const uint64_t*)desc_, static_cast<const uint64_t*>(d_recv_keys),
                             static_cast<const idx_t*>(d_recv_sa), A2_.key, A2_.sa);
+            mark("regrouped");
             prepare_segments(be_, seg2_, n_tiles2_);
+            mark("segments prepared");
             std::swap(tdesc_, tdesc2_);
             if (bits_ == 2) {
                 SortResult<idx_t> r = sort<2>(seg2_, n_tiles2_, max_len2_, false, A2_, B2_, recv_total_, 0, true, true, &bk2_, false, true);
@@ -261,6 +268,7 @@ public:
                 SortResult<idx_t> r = sort<8>(seg2_, n_tiles2_, max_len2_, false, A2_, B2_, recv_total_, 0, true, true, &bk2_, false, true);
                 finalize<idx_t, 8>(be_, P_, n_, r, static_cast<idx_t*>(dSA), static_cast<idx_t*>(dLCP));
             }
+            mark("sorted + finalized");
             std::swap(tdesc_, tdesc2_);
             dSA_ = static_cast<idx_t*>(dSA);
         }

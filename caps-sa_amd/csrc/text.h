@@ -51,6 +51,7 @@ template <int BITS>
 HD uint64_t deep_lcp(const uint32_t* __restrict__ P, uint64_t n, uint64_t a, uint64_t b, uint64_t from)
 {
     constexpr uint32_t KCH = TextTraits<BITS>::KCH;
+    if (a >= n || b >= n) return 0;              // corrupt index: do not scan
     const uint64_t maxlen = n - (a > b ? a : b);
     uint64_t l = from;
     while (l < maxlen) {
@@ -83,6 +84,7 @@ template <int BITS>
 HD bool suffix_less_tie(const uint32_t* __restrict__ P, uint64_t n, uint64_t a, uint64_t b)
 {
     constexpr uint32_t KCH = TextTraits<BITS>::KCH;
+    if (a >= n || b >= n) return a > b;          // never loop on a corrupt index (keeps a bad input from hanging the GPU)
     const uint64_t maxlen = n - (a > b ? a : b);
     for (uint64_t l = KCH; l < maxlen; l += KCH) {
         const uint64_t wa = window64<BITS>(P, a + l), wb = window64<BITS>(P, b + l);

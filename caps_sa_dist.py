@@ -30,15 +30,61 @@ def _idx_dtype(idx_bits: int):
     return torch.int32 if idx_bits == 32 else torch.int64
 
 
-def _all_gather_var(t: torch.Tensor, counts: list[int]) -> torch.Tensor:
-    """all_gather of per-rank tensors of different lengths (pads to the longest)."""
+def _all_gather_var(t: torch.Tensor, counts: list[int], max_elems: int = 1 << 25) -> torch.Tensor:
+    """all_gather of per-rank tensors of different lengths, in rounds of at most max_elems
+    elements per rank (collective payloads are kept far below RCCL's safe message size)."""
     world = dist.get_world_size()
+    total = sum(counts)
+    out = torch.empty(total, dtype=t.dtype, device=t.device)
+    offs = [sum(counts[:r]) for r in range(world)]
     mx = max(counts) if counts else 0
-    pad = torch.zeros(mx, dtype=t.dtype, device=t.device)
-    pad[:t.numel()] = t
-    out = torch.empty(mx * world, dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, pad)
-    return torch.cat([out[r * mx:r * mx + counts[r]] for r in range(world)])
+    for lo in range(0, max(mx, 1), max_elems):
+        step = min(max_elems, mx - lo) if mx else 0
+        if step <= 0:
+            break
+        pad = torch.zeros(step, dtype=t.dtype, device=t.device)
+        mine = t[lo:lo + step]
+        pad[:mine.numel()] = mine
+        buf = torch.empty(step * world, dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(buf, pad)
+        for r in range(world):
+            c = max(0, min(step, counts[r] - lo))
+            if c:
+                out[offs[r] + lo: offs[r] + lo + c] = buf[r * step: r * step + c]
+    return out
+
+
+# Largest message (bytes) handed to one all_to_all_single call per peer.  Measured on this
+# stack (RCCL 2.26.6 / torch 2.10, MI355X): a message above 2**30 bytes is silently truncated
+# to about half (tools_a2a_probe.py), so larger sub-subarray blocks go in rounds.
+A2A_MAX_BYTES = 1 << 29
+
+
+def all_to_all_v(recv: torch.Tensor, send: torch.Tensor, rc: list[int], sc: list[int], max_bytes: int | None = None):
+    """all-to-all-v of 1-D tensors: send[sum(sc[:r]) : +sc[r]] goes to rank r, recv gets rc[r]
+    elements from rank r.  One all_to_all_single when every block fits max_bytes; otherwise
+    rounds of at most max_bytes per peer through contiguous staging buffers."""
+    max_bytes = max_bytes or A2A_MAX_BYTES
+    world = dist.get_world_size()
+    cmax = max(1, max_bytes // send.element_size())
+    big = torch.tensor([max(sc + rc) if sc else 0], dtype=torch.int64, device=send.device)
+    dist.all_reduce(big, op=dist.ReduceOp.MAX)                    # same number of rounds on every rank
+    rounds = max(1, -(-int(big.item()) // cmax))
+    if rounds == 1:
+        dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=sc)
+        return
+    so = [sum(sc[:r]) for r in range(world)]
+    ro = [sum(rc[:r]) for r in range(world)]
+    for i in range(rounds):
+        isp = [max(0, min(cmax, sc[r] - i * cmax)) for r in range(world)]
+        osp = [max(0, min(cmax, rc[r] - i * cmax)) for r in range(world)]
+        inp = torch.cat([send[so[r] + i * cmax: so[r] + i * cmax + isp[r]] for r in range(world)])
+        outp = torch.empty(sum(osp), dtype=recv.dtype, device=recv.device)
+        dist.all_to_all_single(outp, inp, output_split_sizes=osp, input_split_sizes=isp)
+        o = 0
+        for r in range(world):
+            recv[ro[r] + i * cmax: ro[r] + i * cmax + osp[r]] = outp[o:o + osp[r]]
+            o += osp[r]
 
 
 def build_sharded(lib, T: torch.Tensor, p: int = 0, idx_bits: int | None = None, stream: int = 0):
@@ -80,8 +126,8 @@ def build_sharded(lib, T: torch.Tensor, p: int = 0, idx_bits: int | None = None,
         recv_k = torch.empty(max(total, 1), dtype=torch.int64, device=dev)
         recv_s = torch.empty(max(total, 1), dtype=dt, device=dev)
         t0 = time.perf_counter()
-        dist.all_to_all_single(recv_k[:total], send_k[:sum(sc)], output_split_sizes=rc, input_split_sizes=sc)
-        dist.all_to_all_single(recv_s[:total], send_s[:sum(sc)], output_split_sizes=rc, input_split_sizes=sc)
+        all_to_all_v(recv_k[:total], send_k[:sum(sc)], rc, sc)
+        all_to_all_v(recv_s[:total], send_s[:sum(sc)], rc, sc)
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
         ms_exchange = 1e3 * (time.perf_counter() - t0)

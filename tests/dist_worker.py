@@ -17,6 +17,7 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     import caps_sa_dist
+    caps_sa_dist.A2A_MAX_BYTES = int(os.environ.get("CAPS_A2A_MAX_BYTES", caps_sa_dist.A2A_MAX_BYTES))
     import oracle as O
     from emul_util import emul
     E = emul()
