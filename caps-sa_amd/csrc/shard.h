@@ -60,13 +60,19 @@ public:
         m_local_ = (uint64_t)G_ * ppp_;
         m_total_ = (uint64_t)p_ * ppp_;
         try {
+            // Everything is allocated ONCE here (hipMalloc / hipFree of tens of GB cost seconds): the
+            // element arrays serve phase 1 (this rank's subarrays) and phase 2 (its partitions), sized
+            // for the larger of the two with 25 % slack for the imbalance of the partition ownership.
+            const uint64_t share = n / (uint64_t)world + 1;
+            cap_ = std::max<uint64_t>(local_n_, share + share / 4 + 16 * TILE_E);
             P_ = get<uint32_t>(packed_words(n, 8));
             present_ = get<uint32_t>(8);
             lut_ = get<uint8_t>(256);
-            A_ = elems(local_n_);
-            B_ = elems(local_n_);
-            seg1_ = segs(G_ ? G_ : 1, local_n_ / TILE_E + G_ + 2);
+            A_ = elems(cap_);
+            B_ = elems(cap_);
+            seg1_ = segs(G_ ? G_ : 1, cap_ / TILE_E + p_ + 2);
             seg1_.G = G_;
+            seg2_ = segs(p_, cap_ / TILE_E + p_ + 2);
             SA_ = elems(m_total_);
             SB_ = elems(m_total_);
             segS_ = segs(1, m_total_ / TILE_E + 3);
@@ -76,9 +82,10 @@ public:
             ruler_ = get<idx_t>((size_t)(G_ ? G_ : 1) * p_);
             sizes_ = get<uint64_t>(p_);
             lstart_ = get<uint64_t>((size_t)p_ + 1);
-            bk1_ = buckets(local_n_, G_ ? G_ : 1);
-            const uint64_t a = bk1_.tile_cap + 3, b = m_total_ / TILE_E + 3;
+            bk_ = buckets(cap_, p_);
+            const uint64_t a = bk_.tile_cap + 3, b = m_total_ / TILE_E + 3;
             tdesc_ = get<TileDesc>(a > b ? a : b);
+            desc_ = get<uint64_t>((size_t)3 * world * p_ + 3);
         } catch (...) {
             release();
             throw;
@@ -105,8 +112,8 @@ public:
             const uint64_t last = local_n_ - (uint64_t)(G_ - 1) * s_;
             n_tiles1_ = (G_ - 1) * tiles_of(s_) + tiles_of(last);
             prepare_segments(be_, seg1_, n_tiles1_);
-            cur_ = (bits_ == 2 ? sort<2>(seg1_, n_tiles1_, last, true, A_, B_, local_n_, text_base_, false, false, &bk1_, true)
-                               : sort<8>(seg1_, n_tiles1_, last, true, A_, B_, local_n_, text_base_, false, false, &bk1_, true)).uniform();
+            cur_ = (bits_ == 2 ? sort<2>(seg1_, n_tiles1_, last, true, A_, B_, local_n_, text_base_, false, false, &bk_, true)
+                               : sort<8>(seg1_, n_tiles1_, last, true, A_, B_, local_n_, text_base_, false, false, &bk_, true)).uniform();
             oth_ = cur_.key == A_.key ? B_ : A_;
             CAPS_LAUNCH((sample_kernel<idx_t>), (uint32_t)((m_local_ + 255) / 256), 256, be_, (const uint64_t*)seg1_.seg_start, G_,
                         ppp_, (const uint64_t*)cur_.key, (const idx_t*)cur_.sa, static_cast<uint64_t*>(d_sample_keys),
@@ -197,23 +204,10 @@ public:
                         static_cast<uint64_t*>(d_send_keys), static_cast<idx_t*>(d_send_sa));
         }
 
-        // the phase-1 arrays are dead once the send buffers are filled: give their memory back
-        // before the phase-2 arrays are allocated (peak = max of the two phases, not their sum)
-        be_.sync();
-        for (ElemBuf<idx_t>* eb : {&A_, &B_}) {
-            drop(eb->key); drop(eb->sa); drop(eb->lcp);
-            *eb = ElemBuf<idx_t>();
-        }
-        drop(Pm_); Pm_ = nullptr;
-        drop(ruler_); ruler_ = nullptr;
-        cur_ = oth_ = ElemBuf<idx_t>();
-        // phase-2 storage and descriptors (sizes are known exactly now)
-        A2_ = elems(recv_total_);
-        B2_ = elems(recv_total_);
-        seg2_ = segs(G2_ ? G2_ : 1, recv_total_ / TILE_E + G2_ + 2);
+        // phase 2 re-uses the phase-1 arrays (dead once the send buffers are filled)
+        if (recv_total_ > cap_)
+            throw std::runtime_error("partition ownership is more imbalanced than the shard's capacity allows");
         seg2_.G = G2_;
-        bk2_ = buckets(recv_total_, G2_ ? G2_ : 1);
-        tdesc2_ = get<TileDesc>(bk2_.tile_cap + 3);
         std::vector<uint64_t> st((size_t)G2_ + 1, 0);
         max_len2_ = 0;
         n_tiles2_ = 0;
@@ -239,7 +233,6 @@ public:
                 fill[k] += z;
             }
         n_desc_ = (uint32_t)(desc.size() / 3);
-        desc_ = get<uint64_t>(desc.size() + 3);
         if (!desc.empty()) be_.h2d(desc_, desc.data(), desc.size() * sizeof(uint64_t));
         BackendEvent e1 = be_.record();
         be_.sync();                      // st/desc live on this frame
@@ -256,20 +249,18 @@ public:
         if (recv_total_) {
             if (n_desc_)
                 CAPS_LAUNCH((regroup_kernel<idx_t>), n_desc_, 256, be_, (const uint64_t*)desc_, static_cast<const uint64_t*>(d_recv_keys),
-                            static_cast<const idx_t*>(d_recv_sa), A2_.key, A2_.sa);
+                            static_cast<const idx_t*>(d_recv_sa), A_.key, A_.sa);
             mark("regrouped");
             prepare_segments(be_, seg2_, n_tiles2_);
             mark("segments prepared");
-            std::swap(tdesc_, tdesc2_);
             if (bits_ == 2) {
-                SortResult<idx_t> r = sort<2>(seg2_, n_tiles2_, max_len2_, false, A2_, B2_, recv_total_, 0, true, true, &bk2_, false, true);
+                SortResult<idx_t> r = sort<2>(seg2_, n_tiles2_, max_len2_, false, A_, B_, recv_total_, 0, true, true, &bk_, false, true);
                 finalize<idx_t, 2>(be_, P_, n_, r, static_cast<idx_t*>(dSA), static_cast<idx_t*>(dLCP));
             } else {
-                SortResult<idx_t> r = sort<8>(seg2_, n_tiles2_, max_len2_, false, A2_, B2_, recv_total_, 0, true, true, &bk2_, false, true);
+                SortResult<idx_t> r = sort<8>(seg2_, n_tiles2_, max_len2_, false, A_, B_, recv_total_, 0, true, true, &bk_, false, true);
                 finalize<idx_t, 8>(be_, P_, n_, r, static_cast<idx_t*>(dSA), static_cast<idx_t*>(dLCP));
             }
             mark("sorted + finalized");
-            std::swap(tdesc_, tdesc2_);
             dSA_ = static_cast<idx_t*>(dSA);
         }
         BackendEvent e1 = be_.record();
@@ -311,10 +302,11 @@ private:
     uint32_t* P_ = nullptr;
     uint32_t* present_ = nullptr;
     uint8_t* lut_ = nullptr;
-    ElemBuf<idx_t> A_, B_, SA_, SB_, A2_, B2_, cur_, oth_;
+    ElemBuf<idx_t> A_, B_, SA_, SB_, cur_, oth_;
+    uint64_t cap_ = 0;
     idx_t* dSA_ = nullptr;
-    BucketBufs bk1_, bk2_;
-    TileDesc *tdesc_ = nullptr, *tdesc2_ = nullptr;
+    BucketBufs bk_;
+    TileDesc* tdesc_ = nullptr;
     SegBufs seg1_, segS_, seg2_;
     uint64_t *pkey_ = nullptr, *sizes_ = nullptr, *lstart_ = nullptr, *desc_ = nullptr;
     idx_t *psa_ = nullptr, *Pm_ = nullptr, *ruler_ = nullptr;
