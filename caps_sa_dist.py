@@ -54,18 +54,19 @@ def _all_gather_var(t: torch.Tensor, counts: list[int], max_elems: int = 1 << 25
     return out
 
 
-# Largest message (bytes) handed to one all_to_all_single call per peer.  Measured on this
-# stack (RCCL 2.26.6 / torch 2.10, MI355X): a message above 2**30 bytes is silently truncated
-# to about half (tools_a2a_probe.py), so larger sub-subarray blocks go in rounds.
-A2A_MAX_BYTES = 1 << 29
+# Largest message (bytes) handed to one collective / point-to-point call per peer.  Measured on
+# this stack (RCCL 2.26.6 / torch 2.10, MI355X): a message above 2**30 bytes is silently
+# truncated to about half (tools_a2a_probe.py), so larger sub-subarray blocks go in rounds.
+A2A_MAX_BYTES = (1 << 30) - (1 << 16)
 
 
 def all_to_all_v(recv: torch.Tensor, send: torch.Tensor, rc: list[int], sc: list[int], max_bytes: int | None = None):
     """all-to-all-v of 1-D tensors: send[sum(sc[:r]) : +sc[r]] goes to rank r, recv gets rc[r]
-    elements from rank r.  One all_to_all_single when every block fits max_bytes; otherwise
-    rounds of at most max_bytes per peer through contiguous staging buffers."""
+    elements from rank r.  One all_to_all_single when every block fits max_bytes (C3 on 8 GPUs:
+    375 MB per pair); otherwise rounds of grouped point-to-point sends/receives on views of the
+    buffers -- direct peer-to-peer over xGMI, all links busy, no staging copy."""
     max_bytes = max_bytes or A2A_MAX_BYTES
-    world = dist.get_world_size()
+    world, rank = dist.get_world_size(), dist.get_rank()
     cmax = max(1, max_bytes // send.element_size())
     big = torch.tensor([max(sc + rc) if sc else 0], dtype=torch.int64, device=send.device)
     dist.all_reduce(big, op=dist.ReduceOp.MAX)                    # same number of rounds on every rank
@@ -75,16 +76,20 @@ def all_to_all_v(recv: torch.Tensor, send: torch.Tensor, rc: list[int], sc: list
         return
     so = [sum(sc[:r]) for r in range(world)]
     ro = [sum(rc[:r]) for r in range(world)]
+    recv[ro[rank]: ro[rank] + rc[rank]] = send[so[rank]: so[rank] + sc[rank]]       # own block: local copy
     for i in range(rounds):
-        isp = [max(0, min(cmax, sc[r] - i * cmax)) for r in range(world)]
-        osp = [max(0, min(cmax, rc[r] - i * cmax)) for r in range(world)]
-        inp = torch.cat([send[so[r] + i * cmax: so[r] + i * cmax + isp[r]] for r in range(world)])
-        outp = torch.empty(sum(osp), dtype=recv.dtype, device=recv.device)
-        dist.all_to_all_single(outp, inp, output_split_sizes=osp, input_split_sizes=isp)
-        o = 0
-        for r in range(world):
-            recv[ro[r] + i * cmax: ro[r] + i * cmax + osp[r]] = outp[o:o + osp[r]]
-            o += osp[r]
+        ops = []
+        for d in range(1, world):                                  # staggered peers
+            to, frm = (rank + d) % world, (rank - d) % world
+            ns = max(0, min(cmax, sc[to] - i * cmax))
+            nr = max(0, min(cmax, rc[frm] - i * cmax))
+            if ns:
+                ops.append(dist.P2POp(dist.isend, send[so[to] + i * cmax: so[to] + i * cmax + ns], to))
+            if nr:
+                ops.append(dist.P2POp(dist.irecv, recv[ro[frm] + i * cmax: ro[frm] + i * cmax + nr], frm))
+        if ops:
+            for q in dist.batch_isend_irecv(ops):
+                q.wait()
 
 
 def build_sharded(lib, T: torch.Tensor, p: int = 0, idx_bits: int | None = None, stream: int = 0, shard=None):
