@@ -67,6 +67,7 @@ class ShardInfo(ctypes.Structure):
         ("m_local", ctypes.c_uint64), ("m_total", ctypes.c_uint64),
         ("recv_total", ctypes.c_uint64),
         ("slice_off", ctypes.c_uint64),
+        ("capacity", ctypes.c_uint64),
         ("ms_phase1", ctypes.c_double), ("ms_pivots", ctypes.c_double), ("ms_collate", ctypes.c_double),
         ("ms_phase2", ctypes.c_double),
     ]

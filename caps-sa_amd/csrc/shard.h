@@ -98,7 +98,7 @@ public:
         o->n = n_; o->p = p_; o->ppp = ppp_; o->rank = (uint32_t)rank_; o->world = (uint32_t)world_;
         o->g0 = g0_; o->g1 = g1_; o->bits_per_char = (uint32_t)bits_; o->idx_bytes = sizeof(idx_t);
         o->local_elems = local_n_; o->m_local = m_local_; o->m_total = m_total_;
-        o->recv_total = recv_total_; o->slice_off = slice_off_;
+        o->recv_total = recv_total_; o->slice_off = slice_off_; o->capacity = cap_;
         o->part_lo = jlo_; o->part_hi = jhi_;
         o->ms_phase1 = ms_phase1_; o->ms_pivots = ms_pivots_; o->ms_collate = ms_collate_; o->ms_phase2 = ms_phase2_;
     }

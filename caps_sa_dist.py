@@ -92,10 +92,28 @@ def all_to_all_v(recv: torch.Tensor, send: torch.Tensor, rc: list[int], sc: list
                 q.wait()
 
 
-def build_sharded(lib, T: torch.Tensor, p: int = 0, idx_bits: int | None = None, stream: int = 0, shard=None):
+class ShardBuffers:
+    """Exchange and result buffers of one rank, allocated once for a given shard (torch tensors on
+    the text's device) and re-used by every build."""
+
+    def __init__(self, info: dict, dev, dt):
+        cap, loc = max(info["capacity"], 1), max(info["local_elems"], 1)
+        self.sk = torch.empty(max(info["m_local"], 1), dtype=torch.int64, device=dev)
+        self.ss = torch.empty(max(info["m_local"], 1), dtype=dt, device=dev)
+        self.sizes = torch.empty(info["p"], dtype=torch.int64, device=dev)
+        self.send_k = torch.empty(loc, dtype=torch.int64, device=dev)
+        self.send_s = torch.empty(loc, dtype=dt, device=dev)
+        self.recv_k = torch.empty(cap, dtype=torch.int64, device=dev)
+        self.recv_s = torch.empty(cap, dtype=dt, device=dev)
+        self.SA = torch.empty(cap, dtype=dt, device=dev)
+        self.LCP = torch.empty(cap, dtype=dt, device=dev)
+
+
+def build_sharded(lib, T: torch.Tensor, p: int = 0, idx_bits: int | None = None, stream: int = 0, shard=None, bufs=None):
     """Collective: every rank passes the same text T (uint8 tensor on its device).
     `shard`: a Shard created earlier for the same (T, p, idx_bits) -- its device arrays are
-    allocated once and re-used by every build (allocating tens of GB costs seconds).
+    allocated once and re-used by every build (allocating tens of GB costs seconds); `bufs`: the
+    matching ShardBuffers (the returned SA/LCP are then views of bufs.SA / bufs.LCP).
 
     Returns (SA_slice, LCP_slice, slice_off, info dict).  SA/LCP slices are tensors on T's
     device with the signed dtype of the same width as the unsigned indices."""
@@ -105,44 +123,58 @@ def build_sharded(lib, T: torch.Tensor, p: int = 0, idx_bits: int | None = None,
     dt = _idx_dtype(idx_bits)
     dev = T.device
     sh = shard if shard is not None else lib.shard(T.data_ptr(), n, p, idx_bits, rank, world, stream)
+    prof = {} if os.environ.get("CAPS_SA_DIST_PROFILE") else None
+    tlast = [time.perf_counter()]
+
+    def lap(name):
+        if prof is not None:
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            now = time.perf_counter()
+            prof[name] = prof.get(name, 0.0) + 1e3 * (now - tlast[0])
+            tlast[0] = now
     try:
         inf = sh.info()
         P = inf["p"]
+        B = bufs if bufs is not None else ShardBuffers(inf, dev, dt)
         # ---- phase 1 + samples
-        sk = torch.empty(max(inf["m_local"], 1), dtype=torch.int64, device=dev)
-        ss = torch.empty(max(inf["m_local"], 1), dtype=dt, device=dev)
+        sk, ss = B.sk, B.ss
+        lap("alloc_samples")
         sh.phase1(sk.data_ptr(), ss.data_ptr())
+        lap("phase1")
         counts = [((r + 1) * P // world - r * P // world) * inf["ppp"] for r in range(world)]
         all_k = _all_gather_var(sk[:inf["m_local"]], counts)
         all_s = _all_gather_var(ss[:inf["m_local"]], counts)
         assert all_k.numel() == inf["m_total"]
+        lap("gather_samples")
         # ---- pivots + local partition sizes
-        sizes = torch.empty(P, dtype=torch.int64, device=dev)
+        sizes = B.sizes
         sh.pivots(all_k.data_ptr(), all_s.data_ptr(), sizes.data_ptr())
         all_sizes = torch.empty(world * P, dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(all_sizes, sizes)
         all_sizes_h = all_sizes.cpu().numpy().astype(np.uint64).reshape(world, P)
+        lap("pivots+sizes")
         # ---- collate into destination-major send buffers
-        send_k = torch.empty(max(inf["local_elems"], 1), dtype=torch.int64, device=dev)
-        send_s = torch.empty(max(inf["local_elems"], 1), dtype=dt, device=dev)
+        send_k, send_s = B.send_k, B.send_s
         sc, rc = sh.collate(all_sizes_h, send_k.data_ptr(), send_s.data_ptr())
+        lap("collate")
         sc = [int(x) for x in sc]
         rc = [int(x) for x in rc]
         total = sum(rc)
         # ---- THE exchange (RCCL all-to-all-v over xGMI on GPUs)
-        recv_k = torch.empty(max(total, 1), dtype=torch.int64, device=dev)
-        recv_s = torch.empty(max(total, 1), dtype=dt, device=dev)
+        recv_k, recv_s = B.recv_k, B.recv_s
         t0 = time.perf_counter()
         all_to_all_v(recv_k[:total], send_k[:sum(sc)], rc, sc)
         all_to_all_v(recv_s[:total], send_s[:sum(sc)], rc, sc)
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
         ms_exchange = 1e3 * (time.perf_counter() - t0)
-        del send_k, send_s
+        lap("exchange")
         # ---- phase 2
-        SA = torch.empty(max(total, 1), dtype=dt, device=dev)
-        LCP = torch.empty(max(total, 1), dtype=dt, device=dev)
+        SA, LCP = B.SA, B.LCP
+        lap("alloc_out")
         sh.phase2(recv_k.data_ptr(), recv_s.data_ptr(), SA.data_ptr(), LCP.data_ptr())
+        lap("phase2")
         # ---- boundary LCP between consecutive slices
         last = torch.tensor([sh.last_sa() - (1 << 64) if sh.last_sa() >= (1 << 63) else sh.last_sa()], dtype=torch.int64,
                             device=dev)
@@ -156,7 +188,10 @@ def build_sharded(lib, T: torch.Tensor, p: int = 0, idx_bits: int | None = None,
                 break
         sh.fix_first_lcp(prev, LCP.data_ptr())
         info = sh.info()
+        lap("boundary")
         info["ms_exchange"] = ms_exchange
+        if prof is not None:
+            info["host_profile_ms"] = prof
         info["send_counts"] = sc
         info["recv_counts"] = rc
         return SA[:total], LCP[:total], info["slice_off"], info
@@ -188,8 +223,10 @@ def bench_main(args, rank: int, local_rank: int, world: int):
 
     sh = L.shard(T.data_ptr(), n, args.p, idx_bits, rank, world, stream)     # workspace of the rank, allocated once
 
+    bufs = ShardBuffers(sh.info(), dev, _idx_dtype(idx_bits))
+
     def step():
-        return build_sharded(L, T, args.p, idx_bits, stream, shard=sh)
+        return build_sharded(L, T, args.p, idx_bits, stream, shard=sh, bufs=bufs)
 
     for _ in range(args.warmup):
         out = step()
@@ -218,6 +255,7 @@ def bench_main(args, rank: int, local_rank: int, world: int):
                        "parallelism": f"{world} GPUs: text replicated, subarrays and partitions sharded, "
                                       "one RCCL all-to-all-v"},
             "rank0_ms": {k: info[k] for k in ("ms_phase1", "ms_pivots", "ms_collate", "ms_exchange", "ms_phase2")},
+            "rank0_host_profile_ms": info.get("host_profile_ms"),
             "roofline": None, "cpu_baseline": None,
         }
         if errs is not None:

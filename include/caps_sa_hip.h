@@ -173,6 +173,7 @@ typedef struct caps_sa_shard_info {
     uint64_t m_local, m_total;     /* samples of this rank / of all ranks */
     uint64_t recv_total;           /* elements of the owned partitions (after shard_collate) */
     uint64_t slice_off;            /* position of the rank's slice in the global SA/LCP */
+    uint64_t capacity;             /* most elements this shard can receive (size of recv / SA / LCP buffers) */
     double ms_phase1, ms_pivots, ms_collate, ms_phase2;
 } caps_sa_shard_info;
 
