@@ -254,10 +254,10 @@ public:
             prepare_segments(be_, seg2_, n_tiles2_);
             mark("segments prepared");
             if (bits_ == 2) {
-                SortResult<idx_t> r = sort<2>(seg2_, n_tiles2_, max_len2_, false, A_, B_, recv_total_, 0, true, true, &bk_, false, true);
+                SortResult<idx_t> r = sort<2>(seg2_, n_tiles2_, max_len2_, false, A_, B_, recv_total_, 0, true, true, &bk_, false, true, dSA, dLCP);
                 finalize<idx_t, 2>(be_, P_, n_, r, static_cast<idx_t*>(dSA), static_cast<idx_t*>(dLCP));
             } else {
-                SortResult<idx_t> r = sort<8>(seg2_, n_tiles2_, max_len2_, false, A_, B_, recv_total_, 0, true, true, &bk_, false, true);
+                SortResult<idx_t> r = sort<8>(seg2_, n_tiles2_, max_len2_, false, A_, B_, recv_total_, 0, true, true, &bk_, false, true, dSA, dLCP);
                 finalize<idx_t, 8>(be_, P_, n_, r, static_cast<idx_t*>(dSA), static_cast<idx_t*>(dLCP));
             }
             mark("sorted + finalized");
@@ -350,9 +350,17 @@ private:
     template <int BITS>
     SortResult<idx_t> sort(const SegBufs& s, uint32_t n_tiles, uint64_t max_len, bool from_text, ElemBuf<idx_t> a, ElemBuf<idx_t> b,
                            uint64_t n_elems, uint64_t text_base, bool need_lcp, bool skip_finished, const BucketBufs* bk = nullptr,
-                           bool unify = false, bool between_pivots = false)
+                           bool unify = false, bool between_pivots = false, void* final_sa = nullptr, void* final_lcp = nullptr)
     {
         SortOpts o;
+        if (final_sa && bk) {                     // completed segments go straight to the caller's arrays
+            o.final_sa = final_sa;
+            o.final_lcp = final_lcp;
+            o.bnd.first_key = bk->first_key;
+            o.bnd.last_key = bk->last_key;
+            o.bnd.first_sa = bk->first_sa;
+            o.bnd.last_sa = bk->last_sa;
+        }
         if (between_pivots) {                     // owned partitions jlo_ .. jhi_-1 of p_
             o.range_mode = 1;
             o.pkey = pkey_;
