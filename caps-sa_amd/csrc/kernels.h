@@ -111,44 +111,82 @@ DEV_INLINE PairInfo pair_info(const TileInfo& t, uint64_t R, uint64_t single_la)
 // ----------------------------------------------------------------------------------
 
 // Which byte values occur in T: 256-bit presence set (8 x u32), OR-reduced.
+// 16 bytes per lane per load; a byte marks its flag in a 256-entry LDS table with a plain
+// store (idempotent, so colliding lanes need no atomic); the table is folded into the global
+// bit set once per workgroup.  T must be readable in 16-byte units up to n rounded up (the
+// callers' buffers are; the tail is handled bytewise).
 GLOBAL_FN LAUNCH_BOUNDS(256) alphabet_kernel(KCTX const uint8_t* __restrict__ T, uint64_t n, uint32_t* __restrict__ present)
 {
+    SHARED_ARRAY(uint32_t, flags, 256);
+    PAR(tid) { flags[tid & 255] = 0; }
+    SYNC();
     PAR(tid) {
-        uint32_t bits[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const uint64_t stride = (uint64_t)K_GRID_DIM * K_BLOCK_DIM * 16;
+        const bool aligned = (reinterpret_cast<uintptr_t>(T) & 15) == 0;
         for (uint64_t i = ((uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid) * 16; i < n; i += stride) {
-            const uint64_t e = i + 16 < n ? i + 16 : n;
-            for (uint64_t j = i; j < e; ++j) {
-                const uint32_t c = T[j];
+            if (aligned && i + 16 <= n) {
+                const uint32_t* q = reinterpret_cast<const uint32_t*>(T + i);
+                const uint32_t w[4] = {q[0], q[1], q[2], q[3]};
                 UNROLL
-                for (int w = 0; w < 8; ++w) bits[w] |= (c >> 5) == (uint32_t)w ? (1u << (c & 31)) : 0u;
+                for (int k = 0; k < 4; ++k) {
+                    flags[w[k] & 255] = 1;
+                    flags[(w[k] >> 8) & 255] = 1;
+                    flags[(w[k] >> 16) & 255] = 1;
+                    flags[w[k] >> 24] = 1;
+                }
+            } else {
+                const uint64_t e = i + 16 < n ? i + 16 : n;
+                for (uint64_t j = i; j < e; ++j) flags[T[j]] = 1;
             }
         }
-        UNROLL
-        for (int w = 0; w < 8; ++w)
-            if (bits[w]) ATOMIC_OR_U32(&present[w], bits[w]);
+    }
+    SYNC();
+    PAR(tid) {
+        if (tid < 256 && flags[tid]) ATOMIC_OR_U32(&present[tid >> 5], 1u << (tid & 31));
     }
 }
 
 // Pack raw bytes into BITS-wide codes, big-endian inside each 32-bit word (text.h).
-// lut[256] maps byte -> code.  One thread per output word; words past the text are 0.
+// lut[256] maps byte -> code (staged in LDS).  One thread per 16 input bytes (one 16-byte
+// load -> one word at BITS = 2, four words at BITS = 8); words past the text are 0.
 template <int BITS>
 GLOBAL_FN LAUNCH_BOUNDS(256) pack_kernel(KCTX const uint8_t* __restrict__ T, uint64_t n, const uint8_t* __restrict__ lut,
                                          uint32_t* __restrict__ P, uint64_t n_words)
 {
     constexpr uint32_t CPW = TextTraits<BITS>::CPW;
+    constexpr uint32_t WPT = 16 / CPW;                    // output words per 16 input bytes
+    SHARED_ARRAY(uint8_t, slut, 256);
+    PAR(tid) { slut[tid & 255] = lut[tid & 255]; }
+    SYNC();
     PAR(tid) {
         const uint64_t stride = (uint64_t)K_GRID_DIM * K_BLOCK_DIM;
-        for (uint64_t w = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid; w < n_words; w += stride) {
-            uint32_t v = 0;
-            const uint64_t base = w * CPW;
-            UNROLL
-            for (uint32_t c = 0; c < CPW; ++c) {
-                const uint64_t i = base + c;
-                const uint32_t code = i < n ? lut[T[i]] : 0u;
-                v |= code << (32 - BITS * (c + 1));
+        const uint64_t n_units = (n_words + WPT - 1) / WPT;
+        const bool aligned = (reinterpret_cast<uintptr_t>(T) & 15) == 0;
+        for (uint64_t u = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid; u < n_units; u += stride) {
+            const uint64_t base = u * 16;
+            uint8_t c[16];
+            if (aligned && base + 16 <= n) {
+                const uint32_t* q = reinterpret_cast<const uint32_t*>(T + base);
+                UNROLL
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t w = q[k];
+                    c[4 * k] = (uint8_t)w; c[4 * k + 1] = (uint8_t)(w >> 8); c[4 * k + 2] = (uint8_t)(w >> 16); c[4 * k + 3] = (uint8_t)(w >> 24);
+                }
+            } else {
+                UNROLL
+                for (int k = 0; k < 16; ++k) c[k] = base + k < n ? T[base + k] : 0;
             }
-            P[w] = v;
+            UNROLL
+            for (uint32_t wo = 0; wo < WPT; ++wo) {
+                uint32_t v = 0;
+                UNROLL
+                for (uint32_t k = 0; k < CPW; ++k) {
+                    const uint64_t i = base + wo * CPW + k;
+                    const uint32_t code = i < n ? slut[c[wo * CPW + k]] : 0u;
+                    v |= code << (32 - BITS * (k + 1));
+                }
+                if (u * WPT + wo < n_words) P[u * WPT + wo] = v;
+            }
         }
     }
 }

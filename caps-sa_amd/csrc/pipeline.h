@@ -216,7 +216,7 @@ inline int prepare_text(Backend& be, const uint8_t* dT, uint64_t n, uint32_t* P,
     const int bits = build_lut(present, lut);
     be.h2d(lut_dev, lut, 256);
     const uint64_t n_words = packed_words(n, bits);
-    const uint64_t want = (n_words + 255) / 256;
+    const uint64_t want = (n_words / (bits == 2 ? 1 : 4) + 255) / 256 + 1;
     const uint32_t grid = (uint32_t)(want < 65536 ? want : 65536);
     if (bits == 2) CAPS_LAUNCH(pack_kernel<2>, grid, 256, be, dT, n, (const uint8_t*)lut_dev, P, n_words);
     else CAPS_LAUNCH(pack_kernel<8>, grid, 256, be, dT, n, (const uint8_t*)lut_dev, P, n_words);
