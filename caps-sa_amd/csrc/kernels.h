@@ -523,7 +523,8 @@ template <typename idx_t, int BITS, bool FROM_TEXT>
 GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
                                                   uint64_t text_base, uint32_t lcp_mode, const uint64_t* in_key,
                                                   const idx_t* in_sa, uint64_t* out_key, idx_t* out_sa, idx_t* out_lcp,
-                                                  FinalOut<idx_t> fin)
+                                                  FinalOut<idx_t> fin, const uint64_t* __restrict__ seg_lo,
+                                                  const uint64_t* __restrict__ seg_hi)
 {
     const uint32_t b = K_BLOCK_IDX;
     if (b >= sd.tile_off[sd.G]) return;
@@ -567,12 +568,9 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
                 }
                 TL(rk, tid, k) = key;
                 TL(rs, tid, k) = sa;
-                skey[e] = key;                   // input order: what the merge levels start from
-                ssa[e] = sa;
             }
         }
     }
-    SYNC();
 
     // ---- fast path: interpolation bucket sort in LDS ---------------------------------
     // bin = monotone linear map of the key onto TILE_BINS bins between the tile's smallest
@@ -581,30 +579,38 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
     // order.  ~100 VALU instructions per suffix instead of ~1000 for the merge levels.
     // Taken when no bin holds more than TILE_BIN_LIMIT elements (always on keys that are
     // roughly uniform in their range: random DNA, buckets of the bucketing stage).
-    PAR(tid) {
-        uint64_t mn = ~0ull, mx = 0;
-        UNROLL
-        for (uint32_t k = 0; k < TILE_EPT; ++k) {
-            const uint32_t e = tid + k * TILE_NT;
-            if (e < cnt) {
-                const uint64_t key = TL(rk, tid, k);
-                mn = key < mn ? key : mn;
-                mx = key > mx ? key : mx;
+    // Key range of the tile: known in advance when the tile belongs to a key-range bucket
+    // (seg_lo / seg_hi from bucket_ranges_kernel), otherwise min / max over the tile.
+    const bool known_range = seg_lo != nullptr;
+    if (!known_range) {
+        SYNC();                                     // kmm initialised
+        PAR(tid) {
+            uint64_t mn = ~0ull, mx = 0;
+            UNROLL
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                const uint32_t e = tid + k * TILE_NT;
+                if (e < cnt) {
+                    const uint64_t key = TL(rk, tid, k);
+                    mn = key < mn ? key : mn;
+                    mx = key > mx ? key : mx;
+                }
             }
+            BLOCK_MINMAX_U64(&kmm[0], &kmm[1], mn, mx);
         }
-        BLOCK_MINMAX_U64(&kmm[0], &kmm[1], mn, mx);
     }
     SYNC();
+    const uint64_t tile_kmin = known_range ? seg_lo[g] : kmm[0];
+    const uint64_t tile_kmax = known_range ? seg_hi[g] : kmm[1];
     BucketParams tb;                                   // block-uniform
     {
-        const uint64_t kmin = kmm[0], kmax = kmm[1];
+        const uint64_t kmin = tile_kmin, kmax = tile_kmax;
         const uint64_t range = kmax > kmin ? kmax - kmin : 0;
         tb.kmin = kmin;
         tb.B = TILE_BINS;
         tb.shift = range ? (uint32_t)caps_clz64(range) : 0u;
         tb.bq = (uint64_t)((double)TILE_BINS * 18446744073709551616.0 / ((double)(range << tb.shift) + 1.0));
     }
-    bool fast = cnt > 1 && kmm[1] > kmm[0];
+    bool fast = cnt > 1 && tile_kmax > tile_kmin;
     if (fast) {
         PAR(tid) {
             UNROLL
@@ -669,6 +675,16 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
     }
 
     // ---- general path: bottom-up rank-merge levels (skewed / repetitive keys) -----------
+    if (!fast) {
+        PAR(tid) {                                  // (back to) input order
+            UNROLL
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                const uint32_t e = tid + k * TILE_NT;
+                if (e < cnt) { skey[e] = TL(rk, tid, k); ssa[e] = TL(rs, tid, k); }
+            }
+        }
+        SYNC();
+    }
     for (uint32_t R = 1; !fast && R < cnt; R <<= 1) {
         PAR(tid) {
             UNROLL
@@ -1105,6 +1121,44 @@ GLOBAL_FN LAUNCH_BOUNDS(256) bucket_plan_kernel(KCTX const uint64_t* __restrict_
     }
 }
 
+// Key range of every bucket (inverse of bucket_of, to within rounding: keys just outside are
+// clamped into the edge bins of the tile sort, which stays correct).  One thread per bucket.
+GLOBAL_FN LAUNCH_BOUNDS(256) bucket_ranges_kernel(KCTX const uint64_t* __restrict__ bstart, uint32_t G,
+                                                  const BucketParams* __restrict__ bps, const uint64_t* __restrict__ pkey,
+                                                  uint32_t range_mode, uint32_t part_off, uint32_t part_total,
+                                                  uint64_t* __restrict__ lo, uint64_t* __restrict__ hi)
+{
+    PAR(tid) {
+        const uint64_t i = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (i < bstart[G]) {
+            uint32_t a = 0, b = G;                     // parent segment: largest g with bstart[g] <= i
+            while (b - a > 1) {
+                const uint32_t mid = (a + b) / 2;
+                if (bstart[mid] <= i) a = mid; else b = mid;
+            }
+            const uint32_t g = a;
+            const BucketParams bp = bps[g];
+            uint64_t kmin = 0, kmax = ~0ull;
+            if (range_mode == 1) {
+                const uint32_t j = part_off + g;
+                if (j > 0) kmin = pkey[j - 1];
+                if (j + 1 < part_total) kmax = pkey[j];
+            }
+            const uint32_t bk = (uint32_t)(i - bstart[g]);
+            const double range1 = (double)(kmax - kmin) + 1.0;
+            uint64_t l = kmin, h = kmax;
+            if (bp.B > 1) {
+                const double dl = (double)bk / (double)bp.B * range1, dh = (double)(bk + 1) / (double)bp.B * range1;
+                if (bk > 0) l = kmin + (uint64_t)dl;
+                if (bk + 1 < bp.B) h = kmin + (uint64_t)dh;
+                if (h < l) h = l;
+            }
+            lo[i] = l;
+            hi[i] = h;
+        }
+    }
+}
+
 // Keys of a tile of consecutive text positions are cut from a copy of the tile's slice of the
 // packed text in LDS (one coalesced read of ~1 KiB) instead of three dependent global loads
 // per suffix.  TEXT_WIN words cover TILE_E positions + one key + alignment slack for BITS = 8.
@@ -1388,23 +1442,54 @@ GLOBAL_FN LAUNCH_BOUNDS(256) locate_kernel(KCTX const uint32_t* __restrict__ P, 
 
 // ----------------------------------------------------------------------------------
 // a9: partition sizes and the "ruler" (reference: partition_sub_subarrays, cpp:300-368).
-// Thread j walks column j of Pm: ruler[g*p + j] = offset of sub-subarray (g, j) inside
-// partition j (exclusive scan over g, cpp:340-349), sizes[j] = partition size (cpp:305-316).
+// Column j of Pm: ruler[g*p + j] = offset of sub-subarray (g, j) inside partition j
+// (exclusive scan over g, cpp:340-349), sizes[j] = partition size (cpp:305-316).
 // ----------------------------------------------------------------------------------
+// Two launches over a (column block) x (row chunk) grid: partial column sums per row chunk,
+// then every chunk walks its rows again with the sum of the chunks above it as base.
+constexpr uint32_t PART_CHUNKS = 64;
+
 template <typename idx_t>
-GLOBAL_FN LAUNCH_BOUNDS(64) partition_sizes_kernel(KCTX const idx_t* __restrict__ Pm, uint32_t G, uint32_t p,
-                                                   idx_t* __restrict__ ruler, uint64_t* __restrict__ sizes)
+GLOBAL_FN LAUNCH_BOUNDS(256) partition_partial_kernel(KCTX const idx_t* __restrict__ Pm, uint32_t G, uint32_t p,
+                                                      uint64_t* __restrict__ partial)
 {
+    const uint32_t ncb = (p + K_BLOCK_DIM - 1) / K_BLOCK_DIM;
+    const uint32_t cb = K_BLOCK_IDX % ncb, rc = K_BLOCK_IDX / ncb;
+    const uint32_t rows = (G + PART_CHUNKS - 1) / PART_CHUNKS;
+    const uint32_t g0 = rc * rows, g1 = g0 + rows < G ? g0 + rows : G;
     PAR(tid) {
-        const uint32_t j = K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        const uint32_t j = cb * K_BLOCK_DIM + tid;
         if (j < p) {
             uint64_t run = 0;
-            for (uint32_t g = 0; g < G; ++g) {                 // G sorted subarrays (all p, or a shard's slice)
+            for (uint32_t g = g0; g < g1; ++g) {
+                const idx_t* row = Pm + (uint64_t)g * (p + 1);
+                run += (uint64_t)(row[j + 1] - row[j]);
+            }
+            partial[(uint64_t)rc * p + j] = run;
+        }
+    }
+}
+
+template <typename idx_t>
+GLOBAL_FN LAUNCH_BOUNDS(256) partition_sizes_kernel(KCTX const idx_t* __restrict__ Pm, uint32_t G, uint32_t p,
+                                                    const uint64_t* __restrict__ partial, idx_t* __restrict__ ruler,
+                                                    uint64_t* __restrict__ sizes)
+{
+    const uint32_t ncb = (p + K_BLOCK_DIM - 1) / K_BLOCK_DIM;
+    const uint32_t cb = K_BLOCK_IDX % ncb, rc = K_BLOCK_IDX / ncb;
+    const uint32_t rows = (G + PART_CHUNKS - 1) / PART_CHUNKS;
+    const uint32_t g0 = rc * rows, g1 = g0 + rows < G ? g0 + rows : G;
+    PAR(tid) {
+        const uint32_t j = cb * K_BLOCK_DIM + tid;
+        if (j < p) {
+            uint64_t run = 0;
+            for (uint32_t c = 0; c < rc; ++c) run += partial[(uint64_t)c * p + j];
+            for (uint32_t g = g0; g < g1; ++g) {               // G sorted subarrays (all p, or a shard's slice)
                 const idx_t* row = Pm + (uint64_t)g * (p + 1);
                 ruler[(uint64_t)g * p + j] = (idx_t)run;
                 run += (uint64_t)(row[j + 1] - row[j]);
             }
-            sizes[j] = run;
+            if (rc == PART_CHUNKS - 1) sizes[j] = run;
         }
     }
 }

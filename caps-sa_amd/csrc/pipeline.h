@@ -71,6 +71,7 @@ struct BucketBufs {
     uint32_t* cursor = nullptr;       // [nb_cap]
     uint64_t* scan_tmp = nullptr;     // [2 * (nb_cap / SCAN_CHUNK + 2)]
     uint64_t *first_key = nullptr, *last_key = nullptr;   // [nb_cap] boundary records of the sorted segments
+    uint64_t *range_lo = nullptr, *range_hi = nullptr;    // [nb_cap] key range of every bucket
     void *first_sa = nullptr, *last_sa = nullptr;         // [nb_cap] idx_t
     SegBufs sub;                      // the buckets as segments (G = nb_cap, trailing ones empty)
     uint32_t nb_cap = 0;
@@ -91,6 +92,7 @@ template <typename idx_t> struct Plan {
     idx_t* Pm = nullptr;
     idx_t* ruler = nullptr;
     uint64_t* sizes = nullptr;
+    uint64_t* partial = nullptr;     // [PART_CHUNKS * p] partial column sums of Pm
     SegBufs seg1, seg2, segS;
     TileDesc* desc = nullptr;        // [tile_cap] per-pass tile descriptors
     BucketBufs bk;                   // bucketing scratch (shared by phase 1 and phase 2)
@@ -153,6 +155,7 @@ Plan<idx_t> make_plan(uint64_t n, uint64_t p_arg, char* base)
         pl.Pm = ar.take<idx_t>((size_t)p * (p + 1));
         pl.ruler = ar.take<idx_t>((size_t)p * p);
         pl.sizes = ar.take<uint64_t>(p);
+        pl.partial = ar.take<uint64_t>((size_t)PART_CHUNKS * p);
         segs(pl.seg2, p, pl.tile_cap);
         segs(pl.segS, 1, pl.m / TILE_E + 3);
     }
@@ -163,6 +166,8 @@ Plan<idx_t> make_plan(uint64_t n, uint64_t p_arg, char* base)
     pl.bk.count = ar.take<uint64_t>(pl.bk.nb_cap);
     pl.bk.cursor = ar.take<uint32_t>(pl.bk.nb_cap);
     pl.bk.scan_tmp = ar.take<uint64_t>(2 * ((size_t)pl.bk.nb_cap / SCAN_CHUNK + 2));
+    pl.bk.range_lo = ar.take<uint64_t>(pl.bk.nb_cap);
+    pl.bk.range_hi = ar.take<uint64_t>(pl.bk.nb_cap);
     pl.bk.first_key = ar.take<uint64_t>(pl.bk.nb_cap);
     pl.bk.last_key = ar.take<uint64_t>(pl.bk.nb_cap);
     pl.bk.first_sa = ar.take<idx_t>(pl.bk.nb_cap);
@@ -319,6 +324,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
     const bool dbg = std::getenv("CAPS_SA_DEBUG") != nullptr;
     auto mark = [&](const char* what) { if (dbg) { be.sync(); std::fprintf(stderr, "[sort] %s\n", what); } };
     bool from_text = o.from_text;
+    const uint64_t *range_lo = nullptr, *range_hi = nullptr;      // key ranges of the sorted segments, if bucketed
     SegBufs segs = s;
     bool skip = o.skip_finished;
     if (o.bk && max_len > TILE_E) {
@@ -328,6 +334,11 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
                     o.part_total ? o.part_total : s.G, 1u,
                     bk.params, bk.segB);
         CAPS_LAUNCH(scan_sizes_kernel, 1, 1024, be, (const uint64_t*)bk.segB, s.G, bk.bstart);
+        CAPS_LAUNCH(bucket_ranges_kernel, (bk.nb_cap + 255) / 256, 256, be, (const uint64_t*)bk.bstart, s.G,
+                    (const BucketParams*)bk.params, o.pkey, o.range_mode, o.part_off, o.part_total ? o.part_total : s.G,
+                    bk.range_lo, bk.range_hi);
+        range_lo = bk.range_lo;
+        range_hi = bk.range_hi;
         mark("bucket plan");
         be.memset(bk.count, 0, (size_t)bk.nb_cap * sizeof(uint64_t));
         be.memset(bk.cursor, 0, (size_t)bk.nb_cap * sizeof(uint32_t));
@@ -395,10 +406,10 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
     BackendEvent t0 = be.record();
     if (from_text)
         CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, sd, P, n, o.text_base, lcp_mode,
-                    (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin);
+                    (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, range_lo, range_hi);
     else
         CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode,
-                    (const uint64_t*)cur.key, (const idx_t*)cur.sa, cur.key, cur.sa, cur.lcp, fin);
+                    (const uint64_t*)cur.key, (const idx_t*)cur.sa, cur.key, cur.sa, cur.lcp, fin, range_lo, range_hi);
     BackendEvent t1 = be.record();
     mark("tile sort");
     if (o.tile_clock) { o.tile_clock->spans.push_back({t0, t1}); o.tile_clock->elems.push_back(n_elems); }
@@ -565,7 +576,9 @@ private:
             e4 = be_.record();
 
             // ---- partition sizes, offsets, collate (a9)
-            CAPS_LAUNCH((partition_sizes_kernel<idx_t>), (p + 63) / 64, 64, be_, (const idx_t*)pl_.Pm, p, p, pl_.ruler, pl_.sizes);
+            CAPS_LAUNCH((partition_partial_kernel<idx_t>), ((p + 255) / 256) * PART_CHUNKS, 256, be_, (const idx_t*)pl_.Pm, p, p, pl_.partial);
+            CAPS_LAUNCH((partition_sizes_kernel<idx_t>), ((p + 255) / 256) * PART_CHUNKS, 256, be_, (const idx_t*)pl_.Pm, p, p,
+                        (const uint64_t*)pl_.partial, pl_.ruler, pl_.sizes);
             CAPS_LAUNCH(scan_sizes_kernel, 1, 1024, be_, (const uint64_t*)pl_.sizes, p, pl_.seg2.seg_start);
             prepare_segments(pl_.seg2, n / TILE_E + p + 1);
             uint64_t out2[2];

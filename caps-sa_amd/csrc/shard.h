@@ -81,6 +81,7 @@ public:
             Pm_ = get<idx_t>((size_t)(G_ ? G_ : 1) * (p_ + 1));
             ruler_ = get<idx_t>((size_t)(G_ ? G_ : 1) * p_);
             sizes_ = get<uint64_t>(p_);
+            partial_ = get<uint64_t>((size_t)PART_CHUNKS * p_);
             lstart_ = get<uint64_t>((size_t)p_ + 1);
             bk_ = buckets(cap_, p_);
             const uint64_t a = bk_.tile_cap + 3, b = m_total_ / TILE_E + 3;
@@ -145,7 +146,9 @@ public:
                 CAPS_LAUNCH((locate_kernel<idx_t, 8>), G_ * bpr, 256, be_, (const uint32_t*)P_, n_, (const uint64_t*)seg1_.seg_start, G_,
                             (const uint64_t*)cur_.key, (const idx_t*)cur_.sa, (const uint64_t*)pkey_, (const idx_t*)psa_, np, Pm_);
         }
-        CAPS_LAUNCH((partition_sizes_kernel<idx_t>), (p_ + 63) / 64, 64, be_, (const idx_t*)Pm_, G_, p_, ruler_, sizes_);
+        CAPS_LAUNCH((partition_partial_kernel<idx_t>), ((p_ + 255) / 256) * PART_CHUNKS, 256, be_, (const idx_t*)Pm_, G_, p_, partial_);
+        CAPS_LAUNCH((partition_sizes_kernel<idx_t>), ((p_ + 255) / 256) * PART_CHUNKS, 256, be_, (const idx_t*)Pm_, G_, p_,
+                    (const uint64_t*)partial_, ruler_, sizes_);
         be_.d2d(d_local_sizes, sizes_, (size_t)p_ * sizeof(uint64_t));
         BackendEvent e1 = be_.record();
         be_.sync();
@@ -308,7 +311,7 @@ private:
     BucketBufs bk_;
     TileDesc* tdesc_ = nullptr;
     SegBufs seg1_, segS_, seg2_;
-    uint64_t *pkey_ = nullptr, *sizes_ = nullptr, *lstart_ = nullptr, *desc_ = nullptr;
+    uint64_t *pkey_ = nullptr, *sizes_ = nullptr, *lstart_ = nullptr, *desc_ = nullptr, *partial_ = nullptr;
     idx_t *psa_ = nullptr, *Pm_ = nullptr, *ruler_ = nullptr;
     double ms_phase1_ = 0, ms_pivots_ = 0, ms_collate_ = 0, ms_phase2_ = 0;
 
@@ -386,6 +389,8 @@ private:
         k.count = get<uint64_t>(k.nb_cap);
         k.cursor = get<uint32_t>(k.nb_cap);
         k.scan_tmp = get<uint64_t>(2 * ((size_t)k.nb_cap / SCAN_CHUNK + 2));
+        k.range_lo = get<uint64_t>(k.nb_cap);
+        k.range_hi = get<uint64_t>(k.nb_cap);
         k.first_key = get<uint64_t>(k.nb_cap);
         k.last_key = get<uint64_t>(k.nb_cap);
         k.first_sa = get<idx_t>(k.nb_cap);
