@@ -23,6 +23,8 @@
 #include <vector>
 #include <algorithm>
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
 #define HD inline
 #define DEV_INLINE inline
 #define HD_NOINLINE

@@ -436,10 +436,33 @@ HD uint32_t pow2_above(uint32_t x) { return 1u << (32 - (x ? __builtin_clz(x) : 
 
 struct BucketParams {        // per parent segment
     uint64_t kmin;           // smallest key of the segment's range
-    uint64_t bq;             // bucket = mulhi((key - kmin) << shift, bq), clamped to B - 1
+    uint64_t bq;             // bucket = mulhi((key - kmin) << shift, bq) >> post, clamped to B - 1
     uint32_t shift;
     uint32_t B;
+    uint32_t post;
+    uint32_t pad;
 };
+
+// Monotone linear map of [kmin, kmin + range] onto B buckets: with d_s = (key - kmin) << shift
+// (range normalised to [2^63, 2^64)), bucket = d_s * B / (range_s + 1).  The factor
+// B * 2^64 / (range_s + 1) lies in [B, 2B]; it is kept as a 63-bit fixed-point number
+// (scaled by 2^post) so that bucket boundaries are exact to ~2^-40 of the range.
+HD BucketParams make_bucket_params(uint64_t kmin, uint64_t kmax, uint32_t B)
+{
+    BucketParams q;
+    q.kmin = kmin;
+    q.B = B;
+    q.pad = 0;
+    const uint64_t range = kmax > kmin ? kmax - kmin : 0;
+    q.shift = range ? (uint32_t)caps_clz64(range) : 0u;
+    const double rs = (double)(range << q.shift) + 1.0;                 // in [2^63, 2^64]
+    const double f = (double)B * 18446744073709551616.0 / rs;           // in [B, 2B]
+    uint32_t bits = 1;
+    while ((2ull * B) >> bits) ++bits;                                  // 2B < 2^bits
+    q.post = 63 - bits;
+    q.bq = (uint64_t)(f * (double)(1ull << q.post));
+    return q;
+}
 
 DEV_INLINE uint32_t bucket_of(const BucketParams& bp, uint64_t key)
 {
@@ -447,10 +470,9 @@ DEV_INLINE uint32_t bucket_of(const BucketParams& bp, uint64_t key)
     if (key <= bp.kmin) return 0;
     const uint64_t d = key - bp.kmin;
     if (bp.shift && (d >> (64 - bp.shift))) return bp.B - 1;          // above the nominal range
-    const uint64_t b = caps_umul64hi(d << bp.shift, bp.bq);
+    const uint64_t b = caps_umul64hi(d << bp.shift, bp.bq) >> bp.post;
     return b < bp.B ? (uint32_t)b : bp.B - 1;
 }
-
 
 // Exclusive scan of the TILE_BINS bin counts of a tile, in place; hist[TILE_BINS] = total.
 // gfx950: every thread owns TILE_BINS / TILE_NT consecutive bins; wave64 shuffle scan of the
@@ -501,6 +523,9 @@ template <typename idx_t> struct FinalOut {
 
 // Bins of the in-LDS bucket sort of one tile, and the bin occupancy above which the tile
 // falls back to the merge levels.
+#ifdef CAPS_EMUL
+extern "C" void caps_emul_count_tile(bool fast, bool known_range);   // test statistics (tests/emul/emul_lib.cpp)
+#endif
 constexpr uint32_t TILE_BINS = TILE_BINS_;
 constexpr uint32_t TILE_BIN_LIMIT = 24;
 
@@ -601,15 +626,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
     SYNC();
     const uint64_t tile_kmin = known_range ? seg_lo[g] : kmm[0];
     const uint64_t tile_kmax = known_range ? seg_hi[g] : kmm[1];
-    BucketParams tb;                                   // block-uniform
-    {
-        const uint64_t kmin = tile_kmin, kmax = tile_kmax;
-        const uint64_t range = kmax > kmin ? kmax - kmin : 0;
-        tb.kmin = kmin;
-        tb.B = TILE_BINS;
-        tb.shift = range ? (uint32_t)caps_clz64(range) : 0u;
-        tb.bq = (uint64_t)((double)TILE_BINS * 18446744073709551616.0 / ((double)(range << tb.shift) + 1.0));
-    }
+    const BucketParams tb = make_bucket_params(tile_kmin, tile_kmax, TILE_BINS);      // block-uniform
     bool fast = cnt > 1 && tile_kmax > tile_kmin;
     if (fast) {
         PAR(tid) {
@@ -675,6 +692,15 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
     }
 
     // ---- general path: bottom-up rank-merge levels (skewed / repetitive keys) -----------
+#ifdef CAPS_EMUL
+    caps_emul_count_tile(fast, known_range);
+    if (!fast && known_range && std::getenv("CAPS_DBG_TILE")) {
+        uint64_t mn = ~0ull, mx = 0; uint32_t below = 0, above = 0;
+        PAR(tid) { for (uint32_t k = 0; k < TILE_EPT; ++k) { const uint32_t e = tid + k * TILE_NT; if (e < cnt) { const uint64_t key = TL(rk, tid, k); mn = key < mn ? key : mn; mx = key > mx ? key : mx; below += key < tile_kmin; above += key > tile_kmax; } } }
+        std::fprintf(stderr, "tile seg %u cnt %u known [%016llx, %016llx] actual [%016llx, %016llx] below %u above %u\n", g, cnt,
+                     (unsigned long long)tile_kmin, (unsigned long long)tile_kmax, (unsigned long long)mn, (unsigned long long)mx, below, above);
+    }
+#endif
     if (!fast) {
         PAR(tid) {                                  // (back to) input order
             UNROLL
@@ -1107,14 +1133,7 @@ GLOBAL_FN LAUNCH_BOUNDS(256) bucket_plan_kernel(KCTX const uint64_t* __restrict_
             }
             uint32_t B = 1;
             if (enable && len > TILE_E && kmax > kmin) B = (uint32_t)((len + BUCKET_TARGET - 1) / BUCKET_TARGET);
-            BucketParams q;
-            q.kmin = kmin;
-            q.B = B;
-            const uint64_t range = kmax - kmin;
-            q.shift = range ? (uint32_t)caps_clz64(range) : 0u;
-            const double rs = (double)(range << q.shift) + 1.0;                 // in [2^63, 2^64]
-            const double f = (double)B * 18446744073709551616.0 / rs;           // in [B, 2B]
-            q.bq = (uint64_t)f;
+            const BucketParams q = make_bucket_params(kmin, kmax, B);
             bp[g] = q;
             segB[g] = B;
         }

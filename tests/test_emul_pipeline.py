@@ -125,3 +125,23 @@ def test_segmented_sort_mixed_lengths(oracle):
     seg = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
     idx = rs.permutation(200000)[:int(seg[-1])].astype(np.uint32)
     _check_segments(emul(), oracle, T, idx, seg)
+
+
+def test_uniform_keys_take_the_bucket_sort_fast_path(oracle):
+    """Regression guard for the bucket maps: on random DNA every tile of the two big sorts must be
+    sorted by the in-LDS bucket sort (known key range, no bin overflow), with no merge pass."""
+    import ctypes
+    E = emul()
+    f = E.dll.caps_sa_emul_tile_stats
+    f.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    a = (ctypes.c_uint64 * 4)()
+    f(a, 1)
+    T = np.random.RandomState(31).choice(DNA, size=1_500_000)
+    SA, LCP, st = E.build(T, p=20)
+    f(a, 1)
+    slow_unknown, fast_unknown, slow_known, fast_known = list(a)
+    assert slow_known == 0 and slow_unknown == 0, list(a)
+    assert fast_known > 700
+    assert st["merge_passes_phase1"] == 0 and st["merge_passes_phase2"] == 0
+    SAo, LCPo = oracle.build_sa_lcp(T, p=20)
+    assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo)
