@@ -52,7 +52,10 @@ constexpr uint32_t LOCK_K = CAPS_LOCK_K < TILE_EPT ? CAPS_LOCK_K : TILE_EPT;
 #define LAUNCH_BOUNDS2(n, w) LAUNCH_BOUNDS(n)
 #endif
 static_assert(TILE_E % TILE_NT == 0 && TILE_EPT % LOCK_K == 0, "tile geometry");
-constexpr uint32_t TILE_BINS_ = TILE_E / 2;   // bins of the in-LDS bucket sort of one tile
+#ifndef CAPS_TILE_BINS_DIV
+#define CAPS_TILE_BINS_DIV 2
+#endif
+constexpr uint32_t TILE_BINS_ = TILE_E / CAPS_TILE_BINS_DIV;   // bins of the in-LDS bucket sort of one tile
 
 // Segment/tile descriptor shared by the tile-granular kernels.
 struct SegDesc {
@@ -1292,7 +1295,7 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
                                                : in_key[start + e];
                 const idx_t sa = FROM_TEXT ? (idx_t)(text_base + start + e) : in_sa[start + e];
                 uint32_t bk = 0, r;
-                if (bp.B == 1) r = (uint32_t)(start - t.s0) + e;             // identity: the segment is its own bucket
+                if (bp.B == 1) r = e;                                        // identity: the segment is its own bucket
                 else {
                     bk = bucket_of(bp, key);
                     r = lds ? FETCH_ADD_U32(&hist[bk], 1u) : FETCH_ADD_U32(&cursor[b0 + bk], 1u);
@@ -1310,7 +1313,8 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
             for (uint32_t k = 0; k < TILE_EPT; ++k) {
                 const uint32_t e = tid + k * TILE_NT;
                 if (e < cnt) {
-                    const uint64_t dst = sub_start[b0 + TL(rb, tid, k)] + TL(rr, tid, k);
+                    // one bucket: slot = same offset inside the segment (64-bit: such a segment can be long)
+                    const uint64_t dst = sub_start[b0 + TL(rb, tid, k)] + (bp.B == 1 ? (start - t.s0) : 0) + TL(rr, tid, k);
                     out_key[dst] = TL(rk, tid, k);
                     out_sa[dst] = TL(rs, tid, k);
                 }
