@@ -149,8 +149,16 @@ def main():
         avg_ms = ms / launches
         alg_bytes = 4 * w * (elems / launches)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        # HBM bytes per launch measured with rocprofv3 PMC passes (cannot be collected inside this
+        # process): taken from the committed profile of the same workload, if there is one
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                traffic = json.load(f).get(args.workload if not args.bases else "", {}).get(dom, {}).get("traffic_bytes_per_launch")
+        except OSError:
+            pass
         roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "avg_launch_ms": avg_ms, "launches_per_step": launches / args.steps,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "moved_bytes_per_launch_incl_keys": moved_per_elem * (elems / launches),
