@@ -697,12 +697,6 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
     // ---- general path: bottom-up rank-merge levels (skewed / repetitive keys) -----------
 #ifdef CAPS_EMUL
     caps_emul_count_tile(fast, known_range);
-    if (!fast && known_range && std::getenv("CAPS_DBG_TILE")) {
-        uint64_t mn = ~0ull, mx = 0; uint32_t below = 0, above = 0;
-        PAR(tid) { for (uint32_t k = 0; k < TILE_EPT; ++k) { const uint32_t e = tid + k * TILE_NT; if (e < cnt) { const uint64_t key = TL(rk, tid, k); mn = key < mn ? key : mn; mx = key > mx ? key : mx; below += key < tile_kmin; above += key > tile_kmax; } } }
-        std::fprintf(stderr, "tile seg %u cnt %u known [%016llx, %016llx] actual [%016llx, %016llx] below %u above %u\n", g, cnt,
-                     (unsigned long long)tile_kmin, (unsigned long long)tile_kmax, (unsigned long long)mn, (unsigned long long)mx, below, above);
-    }
 #endif
     if (!fast) {
         PAR(tid) {                                  // (back to) input order

@@ -56,7 +56,7 @@ def _all_gather_var(t: torch.Tensor, counts: list[int], max_elems: int = 1 << 25
 
 # Largest message (bytes) handed to one collective / point-to-point call per peer.  Measured on
 # this stack (RCCL 2.26.6 / torch 2.10, MI355X): a message above 2**30 bytes is silently
-# truncated to about half (tools_a2a_probe.py), so larger sub-subarray blocks go in rounds.
+# truncated to about half (tools/a2a_probe.py), so larger sub-subarray blocks go in rounds.
 A2A_MAX_BYTES = (1 << 30) - (1 << 16)
 
 
