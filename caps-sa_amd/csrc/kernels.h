@@ -477,24 +477,25 @@ DEV_INLINE uint32_t bucket_of(const BucketParams& bp, uint64_t key)
     return b < bp.B ? (uint32_t)b : bp.B - 1;
 }
 
-// Exclusive scan of the TILE_BINS bin counts of a tile, in place; hist[TILE_BINS] = total.
-// gfx950: every thread owns TILE_BINS / TILE_NT consecutive bins; wave64 shuffle scan of the
+// Exclusive scan of NBINS counters in LDS, in place; h[NBINS] = total.
+// gfx950: every thread owns NBINS / TILE_NT consecutive counters; wave64 shuffle scan of the
 // per-thread sums, wave totals combined through LDS (two barriers).
-DEV_INLINE void block_exclusive_scan_bins(KCTX uint32_t* hist)
+template <uint32_t NBINS>
+DEV_INLINE void block_exclusive_scan(KCTX uint32_t* h)
 {
 #ifdef CAPS_EMUL
     (void)kctx_;
     uint32_t run = 0;
-    for (uint32_t i = 0; i < TILE_BINS_; ++i) { const uint32_t c = hist[i]; hist[i] = run; run += c; }
-    hist[TILE_BINS_] = run;
+    for (uint32_t i = 0; i < NBINS; ++i) { const uint32_t c = h[i]; h[i] = run; run += c; }
+    h[NBINS] = run;
 #else
-    constexpr uint32_t BPT = TILE_BINS_ / TILE_NT;
-    static_assert(BPT >= 1 && BPT * TILE_NT == TILE_BINS_, "bins per thread");
+    constexpr uint32_t BPT = NBINS / TILE_NT;
+    static_assert(BPT >= 1 && BPT * TILE_NT == NBINS, "counters per thread");
     __shared__ uint32_t wave_tot[TILE_NT / 64];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     uint32_t v[BPT], sum = 0;
     UNROLL
-    for (uint32_t i = 0; i < BPT; ++i) { v[i] = hist[tid * BPT + i]; sum += v[i]; }
+    for (uint32_t i = 0; i < BPT; ++i) { v[i] = h[tid * BPT + i]; sum += v[i]; }
     uint32_t x = sum;
     UNROLL
     for (int d = 1; d < 64; d <<= 1) {
@@ -506,11 +507,12 @@ DEV_INLINE void block_exclusive_scan_bins(KCTX uint32_t* hist)
     uint32_t run = x - sum;
     for (uint32_t w = 0; w < wv; ++w) run += wave_tot[w];
     UNROLL
-    for (uint32_t i = 0; i < BPT; ++i) { hist[tid * BPT + i] = run; run += v[i]; }
-    if (tid == TILE_NT - 1) hist[TILE_BINS_] = run;
+    for (uint32_t i = 0; i < BPT; ++i) { h[tid * BPT + i] = run; run += v[i]; }
+    if (tid == TILE_NT - 1) h[NBINS] = run;
     __syncthreads();
 #endif
 }
+DEV_INLINE void block_exclusive_scan_bins(KCTX uint32_t* hist) { block_exclusive_scan<TILE_BINS_>(KCTX_PASS hist); }
 
 // Final destination of a sort whose result is THE suffix / LCP array (phase 2): SA and LCP slots
 // of the caller plus, per sorted segment, its first and last (key, sa) -- the boundary records
@@ -528,9 +530,13 @@ template <typename idx_t> struct FinalOut {
 // falls back to the merge levels.
 #ifdef CAPS_EMUL
 extern "C" void caps_emul_count_tile(bool fast, bool known_range);   // test statistics (tests/emul/emul_lib.cpp)
+extern "C" void caps_emul_count_tile2(bool two_level_ok);
 #endif
 constexpr uint32_t TILE_BINS = TILE_BINS_;
-constexpr uint32_t TILE_BIN_LIMIT = 24;
+#ifndef CAPS_TILE_BIN_LIMIT
+#define CAPS_TILE_BIN_LIMIT 24
+#endif
+constexpr uint32_t TILE_BIN_LIMIT = CAPS_TILE_BIN_LIMIT;
 
 // ----------------------------------------------------------------------------------
 // a4/a5: tile sort -- one workgroup sorts up to TILE_E suffixes in LDS and emits the
@@ -547,89 +553,137 @@ constexpr uint32_t TILE_BIN_LIMIT = 24;
 // keys (text only on equal keys).
 // LDS: TILE_E x (8 + sizeof(idx_t)).
 // ----------------------------------------------------------------------------------
+// Shared pieces of the two tile sort kernels (macros: they use the kernels' TL registers).
+#define TILE_SORT_PROLOGUE                                                                                      \
+    const uint32_t b = K_BLOCK_IDX;                                                                             \
+    if (b >= sd.tile_off[sd.G]) return;                                                                         \
+    const uint32_t g = sd.tile_seg[b];                                                                          \
+    const TileInfo t = tile_info(sd, b);                                                                        \
+    const uint64_t start = t.s0 + (uint64_t)t.tl * TILE_E;                                                      \
+    const uint32_t cnt = (uint32_t)(t.s1 - start < TILE_E ? t.s1 - start : TILE_E);                             \
+    /* LCPs are only needed from the sort that completes a segment: lcp_mode 0 = never,                      */ \
+    /* 1 = when the whole segment is this tile (otherwise its final merge pass emits them).                  */ \
+    const bool with_lcp = lcp_mode != 0 && (t.s1 - t.s0) <= TILE_E;                                             \
+    /* fin.sa != null: a segment completed here goes straight to the caller's SA / LCP arrays                */ \
+    /* (its head LCP is filled in by head_lcp_kernel from the boundary records).                             */ \
+    const bool direct = with_lcp && fin.sa != nullptr;
+
+#define TILE_SORT_LOAD                                                                                          \
+    PAR(tid) {                                                                                                  \
+        if (tid == 0) { kmm[0] = ~0ull; kmm[1] = 0; flag[0] = 0; }                                              \
+        for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0;                                   \
+        UNROLL                                                                                                  \
+        for (uint32_t k = 0; k < TILE_EPT; ++k) {                                                               \
+            const uint32_t e = tid + k * TILE_NT;                                                               \
+            if (e < cnt) {                                                                                      \
+                uint64_t key;                                                                                   \
+                idx_t sa;                                                                                       \
+                if (FROM_TEXT) {                                                                                \
+                    key = window64<BITS>(P, text_base + start + e);                                             \
+                    sa = (idx_t)(text_base + start + e);                                                        \
+                } else {                                                                                        \
+                    key = in_key[start + e];                                                                    \
+                    sa = in_sa[start + e];                                                                      \
+                }                                                                                               \
+                TL(rk, tid, k) = key;                                                                           \
+                TL(rs, tid, k) = sa;                                                                            \
+            }                                                                                                   \
+        }                                                                                                       \
+    }
+
+// Key range of the tile: known in advance when the tile belongs to a key-range bucket
+// (seg_lo / seg_hi from bucket_ranges_kernel), otherwise min / max over the tile.
+#define TILE_SORT_RANGE                                                                                         \
+    const bool known_range = seg_lo != nullptr;                                                                 \
+    if (!known_range) {                                                                                         \
+        SYNC(); /* kmm initialised */                                                                           \
+        PAR(tid) {                                                                                              \
+            uint64_t mn = ~0ull, mx = 0;                                                                        \
+            UNROLL                                                                                              \
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {                                                           \
+                const uint32_t e = tid + k * TILE_NT;                                                           \
+                if (e < cnt) {                                                                                  \
+                    const uint64_t key = TL(rk, tid, k);                                                        \
+                    mn = key < mn ? key : mn;                                                                   \
+                    mx = key > mx ? key : mx;                                                                   \
+                }                                                                                               \
+            }                                                                                                   \
+            BLOCK_MINMAX_U64(&kmm[0], &kmm[1], mn, mx);                                                         \
+        }                                                                                                       \
+    }                                                                                                           \
+    SYNC();                                                                                                     \
+    const uint64_t tile_kmin = known_range ? seg_lo[g] : kmm[0];                                                \
+    const uint64_t tile_kmax = known_range ? seg_hi[g] : kmm[1];                                                \
+    const BucketParams tb = make_bucket_params(tile_kmin, tile_kmax, TILE_BINS); /* block-uniform */
+
+// registers -> final slots TL(rd) in LDS
+#define TILE_SORT_PLACE_FINAL                                                                                   \
+    PAR(tid) {                                                                                                  \
+        UNROLL                                                                                                  \
+        for (uint32_t k = 0; k < TILE_EPT; ++k) {                                                               \
+            const uint32_t e = tid + k * TILE_NT;                                                               \
+            if (e < cnt) {                                                                                      \
+                const uint32_t d = TL(rd, tid, k);                                                              \
+                skey[d] = TL(rk, tid, k);                                                                       \
+                ssa[d] = TL(rs, tid, k);                                                                        \
+            }                                                                                                   \
+        }                                                                                                       \
+    }                                                                                                           \
+    SYNC();
+
+// sorted tile in LDS -> HBM (+ LCPs from adjacent keys, + boundary records)
+#define TILE_SORT_EMIT                                                                                          \
+    PAR(tid) {                                                                                                  \
+        UNROLL                                                                                                  \
+        for (uint32_t k = 0; k < TILE_EPT; ++k) {                                                               \
+            const uint32_t e = tid + k * TILE_NT;                                                               \
+            if (e < cnt) {                                                                                      \
+                const uint64_t key = skey[e];                                                                   \
+                const idx_t sa = ssa[e];                                                                        \
+                uint64_t l = 0;                                                                                 \
+                if (with_lcp && e) l = pair_lcp<BITS>(P, n, skey[e - 1], (uint64_t)ssa[e - 1], key, (uint64_t)sa); \
+                if (direct) {                                                                                   \
+                    fin.sa[start + e] = sa;                                                                     \
+                    fin.lcp[start + e] = (idx_t)l;                                                              \
+                    if (e == 0) { fin.first_key[g] = key; fin.first_sa[g] = sa; }                               \
+                    if (e == cnt - 1) { fin.last_key[g] = key; fin.last_sa[g] = sa; }                           \
+                } else {                                                                                        \
+                    out_key[start + e] = key;                                                                   \
+                    out_sa[start + e] = sa;                                                                     \
+                    if (with_lcp) out_lcp[start + e] = (idx_t)l;                                                \
+                }                                                                                               \
+            }                                                                                                   \
+        }                                                                                                       \
+    }
+
+// ---- tile_sort_kernel: interpolation bucket sort in LDS ------------------------------
+// bin = monotone linear map of the key onto TILE_BINS bins over the tile's key range; a
+// counting sort by bin (LDS histogram + scan) places every element next to the few others of
+// its bin, and a short exact scan of its own bin fixes the order.  ~100 VALU instructions per
+// suffix instead of ~1000 for a comparison sort.  Completes the tile when no bin holds more than
+// TILE_BIN_LIMIT elements (always on keys that are roughly uniform in their range: random DNA,
+// buckets of the bucketing stage); otherwise it writes nothing and sets redo[tile], and
+// tile_sort_general_kernel sorts the tile.
 template <typename idx_t, int BITS, bool FROM_TEXT>
 GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
                                                   uint64_t text_base, uint32_t lcp_mode, const uint64_t* in_key,
                                                   const idx_t* in_sa, uint64_t* out_key, idx_t* out_sa, idx_t* out_lcp,
                                                   FinalOut<idx_t> fin, const uint64_t* __restrict__ seg_lo,
-                                                  const uint64_t* __restrict__ seg_hi)
+                                                  const uint64_t* __restrict__ seg_hi, uint32_t* __restrict__ redo)
 {
-    const uint32_t b = K_BLOCK_IDX;
-    if (b >= sd.tile_off[sd.G]) return;
-    const uint32_t g = sd.tile_seg[b];
-    const TileInfo t = tile_info(sd, b);
-    const uint64_t start = t.s0 + (uint64_t)t.tl * TILE_E;
-    const uint32_t cnt = (uint32_t)(t.s1 - start < TILE_E ? t.s1 - start : TILE_E);
-
-    // LCPs are only needed from the sort that completes a segment: lcp_mode 0 = never,
-    // 1 = when the whole segment is this tile (otherwise its final merge pass emits them).
-    const bool with_lcp = lcp_mode != 0 && (t.s1 - t.s0) <= TILE_E;
-    // fin.sa != null: a segment completed here goes straight to the caller's SA / LCP arrays
-    // (its head LCP is filled in by head_lcp_kernel from the boundary records).
-    const bool direct = with_lcp && fin.sa != nullptr;
-
+    TILE_SORT_PROLOGUE
     SHARED_ARRAY(uint64_t, skey, TILE_E);
     SHARED_ARRAY(idx_t, ssa, TILE_E);
     SHARED_ARRAY(uint32_t, hist, TILE_BINS + 1);
     SHARED_ARRAY(uint64_t, kmm, 2);          // min / max key of the tile
-    SHARED_ARRAY(uint32_t, flag, 1);         // a bin overflowed: use the merge levels instead
+    SHARED_ARRAY(uint32_t, flag, 1);         // a bin overflowed
     TL_DECL(uint64_t, rk, TILE_EPT);
     TL_DECL(idx_t, rs, TILE_EPT);
     TL_DECL(uint32_t, rd, TILE_EPT);
     TL_DECL(uint32_t, rb, TILE_EPT);
 
-    PAR(tid) {
-        if (tid == 0) { kmm[0] = ~0ull; kmm[1] = 0; flag[0] = 0; }
-        for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0;
-        UNROLL
-        for (uint32_t k = 0; k < TILE_EPT; ++k) {
-            const uint32_t e = tid + k * TILE_NT;
-            if (e < cnt) {
-                uint64_t key;
-                idx_t sa;
-                if (FROM_TEXT) {
-                    key = window64<BITS>(P, text_base + start + e);
-                    sa = (idx_t)(text_base + start + e);
-                } else {
-                    key = in_key[start + e];
-                    sa = in_sa[start + e];
-                }
-                TL(rk, tid, k) = key;
-                TL(rs, tid, k) = sa;
-            }
-        }
-    }
-
-    // ---- fast path: interpolation bucket sort in LDS ---------------------------------
-    // bin = monotone linear map of the key onto TILE_BINS bins between the tile's smallest
-    // and largest key; a counting sort by bin (LDS histogram + scan) places every element
-    // next to the few others of its bin, and a short exact scan of its own bin fixes the
-    // order.  ~100 VALU instructions per suffix instead of ~1000 for the merge levels.
-    // Taken when no bin holds more than TILE_BIN_LIMIT elements (always on keys that are
-    // roughly uniform in their range: random DNA, buckets of the bucketing stage).
-    // Key range of the tile: known in advance when the tile belongs to a key-range bucket
-    // (seg_lo / seg_hi from bucket_ranges_kernel), otherwise min / max over the tile.
-    const bool known_range = seg_lo != nullptr;
-    if (!known_range) {
-        SYNC();                                     // kmm initialised
-        PAR(tid) {
-            uint64_t mn = ~0ull, mx = 0;
-            UNROLL
-            for (uint32_t k = 0; k < TILE_EPT; ++k) {
-                const uint32_t e = tid + k * TILE_NT;
-                if (e < cnt) {
-                    const uint64_t key = TL(rk, tid, k);
-                    mn = key < mn ? key : mn;
-                    mx = key > mx ? key : mx;
-                }
-            }
-            BLOCK_MINMAX_U64(&kmm[0], &kmm[1], mn, mx);
-        }
-    }
-    SYNC();
-    const uint64_t tile_kmin = known_range ? seg_lo[g] : kmm[0];
-    const uint64_t tile_kmax = known_range ? seg_hi[g] : kmm[1];
-    const BucketParams tb = make_bucket_params(tile_kmin, tile_kmax, TILE_BINS);      // block-uniform
+    TILE_SORT_LOAD
+    TILE_SORT_RANGE
     bool fast = cnt > 1 && tile_kmax > tile_kmin;
     if (fast) {
         PAR(tid) {
@@ -648,7 +702,11 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
         SYNC();
         fast = flag[0] == 0;
     }
-    if (fast) {
+    if (cnt == 1) {                              // nothing to sort
+        PAR(tid) { if (tid == 0) { skey[0] = TL(rk, tid, 0); ssa[0] = TL(rs, tid, 0); } }
+        SYNC();
+        fast = true;
+    } else if (fast) {
         block_exclusive_scan_bins(KCTX_PASS hist);         // hist[b] = first slot of bin b, hist[TILE_BINS] = cnt
         PAR(tid) {
             UNROLL
@@ -680,26 +738,145 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
             }
         }
         SYNC();
+        TILE_SORT_PLACE_FINAL
+    }
+#ifdef CAPS_EMUL
+    caps_emul_count_tile(fast, known_range);
+#endif
+    PAR(tid) { if (tid == 0) redo[b] = fast ? 0u : 1u; }
+    if (!fast) return;
+    TILE_SORT_EMIT
+}
+
+// ---- tile_sort_general_kernel: the tiles tile_sort_kernel could not finish ------------------
+// (keys far from uniform inside the tile, or equal keys: repeats).  Two attempts:
+//  1. two-level bins: bins that overflowed are re-binned on their own, finer key range (one
+//     sub-bin per element of the bin) -- follows the local density of skewed but distinct keys;
+//  2. bottom-up rank-merge levels: every element finds its slot by a branch-free fixed-depth binary
+//     search over the sibling run's keys, finished with the exact comparator on key ties -- the
+//     distribution-independent path (reference: merge_sort, src/Suffix_Array.cpp:112-129).
+constexpr uint32_t TILE_SUB_LIMIT = 32;      // sub-bin occupancy above which attempt 1 gives up
+
+template <typename idx_t, int BITS, bool FROM_TEXT>
+GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) tile_sort_general_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
+                                                          uint64_t text_base, uint32_t lcp_mode, const uint64_t* in_key,
+                                                          const idx_t* in_sa, uint64_t* out_key, idx_t* out_sa, idx_t* out_lcp,
+                                                          FinalOut<idx_t> fin, const uint64_t* __restrict__ seg_lo,
+                                                          const uint64_t* __restrict__ seg_hi, const uint32_t* __restrict__ redo)
+{
+    if (K_BLOCK_IDX < sd.tile_off[sd.G] && redo[K_BLOCK_IDX] == 0) return;
+    TILE_SORT_PROLOGUE
+    SHARED_ARRAY(uint64_t, skey, TILE_E);
+    SHARED_ARRAY(idx_t, ssa, TILE_E);
+    SHARED_ARRAY(uint32_t, hist, TILE_BINS + 1);
+    SHARED_ARRAY(uint32_t, hist2, TILE_E + 1);      // sub-bin counters, laid out over the slots of their bin
+    SHARED_ARRAY(uint64_t, kmm, 2);
+    SHARED_ARRAY(uint32_t, flag, 1);
+    TL_DECL(uint64_t, rk, TILE_EPT);
+    TL_DECL(idx_t, rs, TILE_EPT);
+    TL_DECL(uint32_t, rd, TILE_EPT);
+    TL_DECL(uint32_t, rb, TILE_EPT);
+    TL_DECL(uint32_t, r2, TILE_EPT);                // sub-bin slot index (bs + sub) of elements of big bins, else ~0
+
+    TILE_SORT_LOAD
+    TILE_SORT_RANGE
+    bool done = false;
+    if (cnt > 1 && tile_kmax > tile_kmin) {
+        // ---- attempt 1: two-level bins
         PAR(tid) {
+            for (uint32_t i = tid; i <= TILE_E; i += K_BLOCK_DIM) hist2[i] = 0;
             UNROLL
             for (uint32_t k = 0; k < TILE_EPT; ++k) {
                 const uint32_t e = tid + k * TILE_NT;
                 if (e < cnt) {
-                    const uint32_t d = TL(rd, tid, k);
-                    skey[d] = TL(rk, tid, k);
-                    ssa[d] = TL(rs, tid, k);
+                    const uint32_t bin = bucket_of(tb, TL(rk, tid, k));
+                    TL(rb, tid, k) = bin;
+                    TL(rd, tid, k) = FETCH_ADD_U32(&hist[bin], 1u);
                 }
             }
         }
         SYNC();
+        block_exclusive_scan_bins(KCTX_PASS hist);
+        const double range1 = (double)(tile_kmax - tile_kmin) + 1.0;
+        PAR(tid) {
+            UNROLL
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                const uint32_t e = tid + k * TILE_NT;
+                TL(r2, tid, k) = ~0u;
+                if (e < cnt) {
+                    const uint32_t bin = TL(rb, tid, k);
+                    const uint32_t bs = hist[bin], sz = hist[bin + 1] - bs;
+                    if (sz > TILE_BIN_LIMIT) {
+                        // key interval of the bin (inverse of the bin map, to within rounding)
+                        uint64_t lo = tile_kmin, hi = tile_kmax;
+                        if (bin > 0) lo = tile_kmin + (uint64_t)((double)bin / (double)TILE_BINS * range1);
+                        if (bin + 1 < TILE_BINS) hi = tile_kmin + (uint64_t)((double)(bin + 1) / (double)TILE_BINS * range1);
+                        if (hi < lo) hi = lo;
+                        const BucketParams sp = make_bucket_params(lo, hi, sz);
+                        const uint32_t sub = bs + bucket_of(sp, TL(rk, tid, k));
+                        const uint32_t q = FETCH_ADD_U32(&hist2[sub], 1u);
+                        if (q >= TILE_SUB_LIMIT) flag[0] = 1;
+                        TL(r2, tid, k) = sub;
+                        TL(rd, tid, k) = q;
+                    } else {
+                        TL(rd, tid, k) = bs + TL(rd, tid, k);                 // level-1 slot
+                    }
+                }
+            }
+        }
+        SYNC();
+        if (flag[0] == 0) {
+            block_exclusive_scan<TILE_E>(KCTX_PASS hist2);       // hist2[bs + sub] - hist2[bs] = offset of the sub-bin in its bin
+            PAR(tid) {
+                UNROLL
+                for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                    const uint32_t e = tid + k * TILE_NT;
+                    if (e < cnt) {
+                        const uint32_t sub = TL(r2, tid, k);
+                        uint32_t slot = TL(rd, tid, k);
+                        if (sub != ~0u) {
+                            const uint32_t bs = hist[TL(rb, tid, k)];
+                            slot = bs + (hist2[sub] - hist2[bs]) + slot;
+                        }
+                        skey[slot] = TL(rk, tid, k);
+                        ssa[slot] = TL(rs, tid, k);
+                        TL(rd, tid, k) = slot;
+                    }
+                }
+            }
+            SYNC();
+            PAR(tid) {
+                UNROLL
+                for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                    const uint32_t e = tid + k * TILE_NT;
+                    if (e < cnt) {
+                        const uint32_t bin = TL(rb, tid, k), slot = TL(rd, tid, k), sub = TL(r2, tid, k);
+                        uint32_t bs = hist[bin], be = hist[bin + 1];        // candidates: my bin ...
+                        if (sub != ~0u) {                                      // ... or my sub-bin of a big bin
+                            const uint32_t base = bs - hist2[bs];
+                            bs = base + hist2[sub];
+                            be = base + hist2[sub + 1];
+                        }
+                        const uint64_t key = TL(rk, tid, k);
+                        const uint64_t sa = (uint64_t)TL(rs, tid, k);
+                        uint32_t less = 0;
+                        for (uint32_t j = bs; j < be; ++j)
+                            if (j != slot && suffix_less<BITS>(P, n, skey[j], (uint64_t)ssa[j], key, sa)) ++less;
+                        TL(rd, tid, k) = bs + less;
+                    }
+                }
+            }
+            SYNC();
+            TILE_SORT_PLACE_FINAL
+            done = true;
+        }
     }
-
-    // ---- general path: bottom-up rank-merge levels (skewed / repetitive keys) -----------
 #ifdef CAPS_EMUL
-    caps_emul_count_tile(fast, known_range);
+    caps_emul_count_tile2(done);
 #endif
-    if (!fast) {
-        PAR(tid) {                                  // (back to) input order
+    // ---- attempt 2: bottom-up rank-merge levels
+    if (!done) {
+        PAR(tid) {                                  // input order
             UNROLL
             for (uint32_t k = 0; k < TILE_EPT; ++k) {
                 const uint32_t e = tid + k * TILE_NT;
@@ -708,16 +885,16 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
         }
         SYNC();
     }
-    for (uint32_t R = 1; !fast && R < cnt; R <<= 1) {
+    for (uint32_t R = 1; !done && R < cnt; R <<= 1) {
         PAR(tid) {
             UNROLL
-            for (uint32_t g = 0; g < TILE_EPT; g += LOCK_K) {            // LOCK_K searches in lockstep
+            for (uint32_t gg = 0; gg < TILE_EPT; gg += LOCK_K) {          // LOCK_K searches in lockstep
                 uint64_t key[LOCK_K];
                 idx_t sa[LOCK_K];
                 uint32_t lo[LOCK_K], hi[LOCK_K], dbase[LOCK_K];
                 UNROLL
                 for (uint32_t k = 0; k < LOCK_K; ++k) {
-                    const uint32_t e = tid + (g + k) * TILE_NT;
+                    const uint32_t e = tid + (gg + k) * TILE_NT;
                     key[k] = 0;
                     sa[k] = 0;
                     lo[k] = hi[k] = dbase[k] = 0;
@@ -735,49 +912,16 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
                 multi_lower_bound<idx_t, BITS, LOCK_K>(P, n, skey, ssa, key, sa, lo, hi, 2 * R);
                 UNROLL
                 for (uint32_t k = 0; k < LOCK_K; ++k) {
-                    TL(rk, tid, g + k) = key[k];
-                    TL(rs, tid, g + k) = sa[k];
-                    TL(rd, tid, g + k) = dbase[k] + lo[k];
+                    TL(rk, tid, gg + k) = key[k];
+                    TL(rs, tid, gg + k) = sa[k];
+                    TL(rd, tid, gg + k) = dbase[k] + lo[k];
                 }
             }
         }
         SYNC();
-        PAR(tid) {
-            UNROLL
-            for (uint32_t k = 0; k < TILE_EPT; ++k) {
-                const uint32_t e = tid + k * TILE_NT;
-                if (e < cnt) {
-                    const uint32_t d = TL(rd, tid, k);
-                    skey[d] = TL(rk, tid, k);
-                    ssa[d] = TL(rs, tid, k);
-                }
-            }
-        }
-        SYNC();
+        TILE_SORT_PLACE_FINAL
     }
-
-    PAR(tid) {
-        UNROLL
-        for (uint32_t k = 0; k < TILE_EPT; ++k) {
-            const uint32_t e = tid + k * TILE_NT;
-            if (e < cnt) {
-                const uint64_t key = skey[e];
-                const idx_t sa = ssa[e];
-                uint64_t l = 0;
-                if (with_lcp && e) l = pair_lcp<BITS>(P, n, skey[e - 1], (uint64_t)ssa[e - 1], key, (uint64_t)sa);
-                if (direct) {
-                    fin.sa[start + e] = sa;
-                    fin.lcp[start + e] = (idx_t)l;
-                    if (e == 0) { fin.first_key[g] = key; fin.first_sa[g] = sa; }
-                    if (e == cnt - 1) { fin.last_key[g] = key; fin.last_sa[g] = sa; }
-                } else {
-                    out_key[start + e] = key;
-                    out_sa[start + e] = sa;
-                    if (with_lcp) out_lcp[start + e] = (idx_t)l;
-                }
-            }
-        }
-    }
+    TILE_SORT_EMIT
 }
 
 // ----------------------------------------------------------------------------------

@@ -1,0 +1,61 @@
+"""Genome-like synthetic DNA on the GPU: an order-k Markov chain with skewed transition
+probabilities (composition bias: k-mer frequencies spread over ~2 orders of magnitude) plus
+planted repeats (copies of earlier segments with point mutations).  No real genome is available
+offline; this stands in for the *shape* of one when tuning the bucket maps."""
+import torch
+
+
+def markov_dna(n, order=5, seed=7, device="cuda", skew=0.5, repeats=0.02, repeat_len=5000, mut=0.01):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    states = 4 ** order
+    # Dirichlet(skew) rows via gamma sampling
+    gam = torch.distributions.Gamma(torch.full((states, 4), skew), torch.ones(states, 4)).sample().to(device)
+    cdf = torch.cumsum(gam / gam.sum(1, keepdim=True), 1)
+    # chains run in parallel from random states and are concatenated (stationary enough)
+    lanes = 1 << 16
+    steps = (n + lanes - 1) // lanes
+    out = torch.empty((steps, lanes), dtype=torch.uint8, device=device)
+    st = torch.randint(0, states, (lanes,), device=device, generator=g)
+    for t in range(steps):
+        u = torch.rand(lanes, device=device, generator=g)
+        c = (u.unsqueeze(1) > cdf[st]).sum(1).clamp_(max=3)
+        out[t] = c.to(torch.uint8)
+        st = (st * 4 + c) % states
+    seq = out.t().contiguous().view(-1)[:n].clone()     # lane-major: each lane is one contiguous chain
+    # planted repeats
+    n_rep = int(n * repeats / repeat_len)
+    if n_rep:
+        src = torch.randint(0, n - repeat_len, (n_rep,), device=device, generator=g)
+        dst = torch.randint(0, n - repeat_len, (n_rep,), device=device, generator=g)
+        for s, d in zip(src.tolist(), dst.tolist()):
+            seg = seq[s:s + repeat_len].clone()
+            m = torch.rand(repeat_len, device=device, generator=g) < mut
+            seg[m] = torch.randint(0, 4, (int(m.sum()),), device=device, generator=g, dtype=torch.uint8)
+            seq[d:d + repeat_len] = seg
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    return lut[seq.long()]
+
+
+if __name__ == "__main__":
+    import os, sys, time, json
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    import caps_sa_amd
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 64_000_001
+    L = caps_sa_amd.lib()
+    T = markov_dna(n)
+    SA = torch.empty(n, dtype=torch.int32, device="cuda")
+    LCP = torch.empty(n, dtype=torch.int32, device="cuda")
+    for it in range(2):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        st = L.build_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr(), p=8000)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+    errs = L.verify_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr())
+    keep = ("ms_total", "ms_sort_subarrays", "ms_merge_partitions", "merge_passes_phase1", "merge_passes_phase2",
+            "max_partition", "tile_sort_ms", "merge_pass_ms", "bucket_scatter_ms")
+    print(json.dumps({"n": n, "wall_ms": 1e3 * dt, "G_suffixes_per_s": n / dt / 1e9, "verify_errors": errs,
+                      "max_lcp": int(LCP.max().item()), "mean_lcp": float(LCP.double().mean().item()),
+                      **{k: st[k] for k in keep}}))
