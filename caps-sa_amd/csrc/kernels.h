@@ -743,149 +743,62 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
 #ifdef CAPS_EMUL
     caps_emul_count_tile(fast, known_range);
 #endif
-    PAR(tid) { if (tid == 0) redo[b] = fast ? 0u : 1u; }
-    if (!fast) return;
+    // unfinished: queue the tile for tile_sort_general_kernel (redo[0] = queue length)
+    if (!fast) {
+        PAR(tid) { if (tid == 0) redo[1 + FETCH_ADD_U32(&redo[0], 1u)] = b; }
+        return;
+    }
     TILE_SORT_EMIT
 }
 
 // ---- tile_sort_general_kernel: the tiles tile_sort_kernel could not finish ------------------
-// (keys far from uniform inside the tile, or equal keys: repeats).  Two attempts:
-//  1. two-level bins: bins that overflowed are re-binned on their own, finer key range (one
-//     sub-bin per element of the bin) -- follows the local density of skewed but distinct keys;
-//  2. bottom-up rank-merge levels: every element finds its slot by a branch-free fixed-depth binary
-//     search over the sibling run's keys, finished with the exact comparator on key ties -- the
-//     distribution-independent path (reference: merge_sort, src/Suffix_Array.cpp:112-129).
-constexpr uint32_t TILE_SUB_LIMIT = 32;      // sub-bin occupancy above which attempt 1 gives up
-
+// (keys far from uniform inside the tile, or equal keys: repeats), taken from its queue
+// (redo[0] = length, redo[1..] = tile ids) by a fixed grid of workgroups.  Bottom-up rank-merge
+// levels: every element finds its slot by a branch-free fixed-depth binary search over the
+// sibling run's keys, finished with the exact comparator on key ties -- the
+// distribution-independent path (reference: merge_sort, src/Suffix_Array.cpp:112-129).
+// (A second, finer level of interpolation bins for the overflowing bins was tried first: on
+// Markov-skewed DNA it rescued < 20 % of the tiles and cost more than it saved.)
 template <typename idx_t, int BITS, bool FROM_TEXT>
 GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) tile_sort_general_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
                                                           uint64_t text_base, uint32_t lcp_mode, const uint64_t* in_key,
                                                           const idx_t* in_sa, uint64_t* out_key, idx_t* out_sa, idx_t* out_lcp,
-                                                          FinalOut<idx_t> fin, const uint64_t* __restrict__ seg_lo,
-                                                          const uint64_t* __restrict__ seg_hi, const uint32_t* __restrict__ redo)
+                                                          FinalOut<idx_t> fin, const uint32_t* __restrict__ redo)
 {
-    if (K_BLOCK_IDX < sd.tile_off[sd.G] && redo[K_BLOCK_IDX] == 0) return;
-    TILE_SORT_PROLOGUE
     SHARED_ARRAY(uint64_t, skey, TILE_E);
     SHARED_ARRAY(idx_t, ssa, TILE_E);
-    SHARED_ARRAY(uint32_t, hist, TILE_BINS + 1);
-    SHARED_ARRAY(uint32_t, hist2, TILE_E + 1);      // sub-bin counters, laid out over the slots of their bin
-    SHARED_ARRAY(uint64_t, kmm, 2);
-    SHARED_ARRAY(uint32_t, flag, 1);
     TL_DECL(uint64_t, rk, TILE_EPT);
     TL_DECL(idx_t, rs, TILE_EPT);
     TL_DECL(uint32_t, rd, TILE_EPT);
-    TL_DECL(uint32_t, rb, TILE_EPT);
-    TL_DECL(uint32_t, r2, TILE_EPT);                // sub-bin slot index (bs + sub) of elements of big bins, else ~0
-
-    TILE_SORT_LOAD
-    TILE_SORT_RANGE
-    bool done = false;
-    if (cnt > 1 && tile_kmax > tile_kmin) {
-        // ---- attempt 1: two-level bins
-        PAR(tid) {
-            for (uint32_t i = tid; i <= TILE_E; i += K_BLOCK_DIM) hist2[i] = 0;
-            UNROLL
-            for (uint32_t k = 0; k < TILE_EPT; ++k) {
-                const uint32_t e = tid + k * TILE_NT;
-                if (e < cnt) {
-                    const uint32_t bin = bucket_of(tb, TL(rk, tid, k));
-                    TL(rb, tid, k) = bin;
-                    TL(rd, tid, k) = FETCH_ADD_U32(&hist[bin], 1u);
+    const uint32_t n_redo = redo[0];
+    for (uint32_t qi = K_BLOCK_IDX; qi < n_redo; qi += K_GRID_DIM) {
+    const uint32_t b = redo[1 + qi];
+    const uint32_t g = sd.tile_seg[b];
+    const TileInfo t = tile_info(sd, b);
+    const uint64_t start = t.s0 + (uint64_t)t.tl * TILE_E;
+    const uint32_t cnt = (uint32_t)(t.s1 - start < TILE_E ? t.s1 - start : TILE_E);
+    const bool with_lcp = lcp_mode != 0 && (t.s1 - t.s0) <= TILE_E;
+    const bool direct = with_lcp && fin.sa != nullptr;
+    PAR(tid) {
+        UNROLL
+        for (uint32_t k = 0; k < TILE_EPT; ++k) {
+            const uint32_t e = tid + k * TILE_NT;
+            if (e < cnt) {
+                if (FROM_TEXT) {
+                    skey[e] = window64<BITS>(P, text_base + start + e);
+                    ssa[e] = (idx_t)(text_base + start + e);
+                } else {
+                    skey[e] = in_key[start + e];
+                    ssa[e] = in_sa[start + e];
                 }
             }
-        }
-        SYNC();
-        block_exclusive_scan_bins(KCTX_PASS hist);
-        const double range1 = (double)(tile_kmax - tile_kmin) + 1.0;
-        PAR(tid) {
-            UNROLL
-            for (uint32_t k = 0; k < TILE_EPT; ++k) {
-                const uint32_t e = tid + k * TILE_NT;
-                TL(r2, tid, k) = ~0u;
-                if (e < cnt) {
-                    const uint32_t bin = TL(rb, tid, k);
-                    const uint32_t bs = hist[bin], sz = hist[bin + 1] - bs;
-                    if (sz > TILE_BIN_LIMIT) {
-                        // key interval of the bin (inverse of the bin map, to within rounding)
-                        uint64_t lo = tile_kmin, hi = tile_kmax;
-                        if (bin > 0) lo = tile_kmin + (uint64_t)((double)bin / (double)TILE_BINS * range1);
-                        if (bin + 1 < TILE_BINS) hi = tile_kmin + (uint64_t)((double)(bin + 1) / (double)TILE_BINS * range1);
-                        if (hi < lo) hi = lo;
-                        const BucketParams sp = make_bucket_params(lo, hi, sz);
-                        const uint32_t sub = bs + bucket_of(sp, TL(rk, tid, k));
-                        const uint32_t q = FETCH_ADD_U32(&hist2[sub], 1u);
-                        if (q >= TILE_SUB_LIMIT) flag[0] = 1;
-                        TL(r2, tid, k) = sub;
-                        TL(rd, tid, k) = q;
-                    } else {
-                        TL(rd, tid, k) = bs + TL(rd, tid, k);                 // level-1 slot
-                    }
-                }
-            }
-        }
-        SYNC();
-        if (flag[0] == 0) {
-            block_exclusive_scan<TILE_E>(KCTX_PASS hist2);       // hist2[bs + sub] - hist2[bs] = offset of the sub-bin in its bin
-            PAR(tid) {
-                UNROLL
-                for (uint32_t k = 0; k < TILE_EPT; ++k) {
-                    const uint32_t e = tid + k * TILE_NT;
-                    if (e < cnt) {
-                        const uint32_t sub = TL(r2, tid, k);
-                        uint32_t slot = TL(rd, tid, k);
-                        if (sub != ~0u) {
-                            const uint32_t bs = hist[TL(rb, tid, k)];
-                            slot = bs + (hist2[sub] - hist2[bs]) + slot;
-                        }
-                        skey[slot] = TL(rk, tid, k);
-                        ssa[slot] = TL(rs, tid, k);
-                        TL(rd, tid, k) = slot;
-                    }
-                }
-            }
-            SYNC();
-            PAR(tid) {
-                UNROLL
-                for (uint32_t k = 0; k < TILE_EPT; ++k) {
-                    const uint32_t e = tid + k * TILE_NT;
-                    if (e < cnt) {
-                        const uint32_t bin = TL(rb, tid, k), slot = TL(rd, tid, k), sub = TL(r2, tid, k);
-                        uint32_t bs = hist[bin], be = hist[bin + 1];        // candidates: my bin ...
-                        if (sub != ~0u) {                                      // ... or my sub-bin of a big bin
-                            const uint32_t base = bs - hist2[bs];
-                            bs = base + hist2[sub];
-                            be = base + hist2[sub + 1];
-                        }
-                        const uint64_t key = TL(rk, tid, k);
-                        const uint64_t sa = (uint64_t)TL(rs, tid, k);
-                        uint32_t less = 0;
-                        for (uint32_t j = bs; j < be; ++j)
-                            if (j != slot && suffix_less<BITS>(P, n, skey[j], (uint64_t)ssa[j], key, sa)) ++less;
-                        TL(rd, tid, k) = bs + less;
-                    }
-                }
-            }
-            SYNC();
-            TILE_SORT_PLACE_FINAL
-            done = true;
         }
     }
+    SYNC();
 #ifdef CAPS_EMUL
-    caps_emul_count_tile2(done);
+    caps_emul_count_tile2(false);
 #endif
-    // ---- attempt 2: bottom-up rank-merge levels
-    if (!done) {
-        PAR(tid) {                                  // input order
-            UNROLL
-            for (uint32_t k = 0; k < TILE_EPT; ++k) {
-                const uint32_t e = tid + k * TILE_NT;
-                if (e < cnt) { skey[e] = TL(rk, tid, k); ssa[e] = TL(rs, tid, k); }
-            }
-        }
-        SYNC();
-    }
-    for (uint32_t R = 1; !done && R < cnt; R <<= 1) {
+    for (uint32_t R = 1; R < cnt; R <<= 1) {
         PAR(tid) {
             UNROLL
             for (uint32_t gg = 0; gg < TILE_EPT; gg += LOCK_K) {          // LOCK_K searches in lockstep
@@ -922,6 +835,8 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) tile_sort_general_kernel(KCTX SegDesc sd, const
         TILE_SORT_PLACE_FINAL
     }
     TILE_SORT_EMIT
+    SYNC();                                        // before the next queued tile re-uses the LDS
+    }
 }
 
 // ----------------------------------------------------------------------------------

@@ -403,23 +403,23 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         fin.last_sa = static_cast<idx_t*>(o.bnd.last_sa);
     }
     r.fin = fin;
-    // per-tile flags "the bucket sort could not finish this tile": the (idle) tile descriptors' memory
+    // queue of the tiles the bucket sort could not finish ([0] = length): the (idle) tile descriptors' memory
     uint32_t* redo = reinterpret_cast<uint32_t*>(desc);
+    be.memset(redo, 0, sizeof(uint32_t));
+    const uint32_t ggrid = n_tiles < 4 * be.persistent_blocks() ? n_tiles : 4 * be.persistent_blocks();
     BackendEvent t0 = be.record();
     if (from_text)
         CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, sd, P, n, o.text_base, lcp_mode,
                     (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, range_lo, range_hi, redo);
     if (from_text)
-        CAPS_LAUNCH((tile_sort_general_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, sd, P, n, o.text_base, lcp_mode,
-                    (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, range_lo, range_hi,
-                    (const uint32_t*)redo);
+        CAPS_LAUNCH((tile_sort_general_kernel<idx_t, BITS, true>), ggrid, TILE_NT, be, sd, P, n, o.text_base, lcp_mode,
+                    (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo);
     else
         CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode,
                     (const uint64_t*)cur.key, (const idx_t*)cur.sa, cur.key, cur.sa, cur.lcp, fin, range_lo, range_hi, redo);
     if (!from_text)
-        CAPS_LAUNCH((tile_sort_general_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode,
-                    (const uint64_t*)cur.key, (const idx_t*)cur.sa, cur.key, cur.sa, cur.lcp, fin, range_lo, range_hi,
-                    (const uint32_t*)redo);
+        CAPS_LAUNCH((tile_sort_general_kernel<idx_t, BITS, false>), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode,
+                    (const uint64_t*)cur.key, (const idx_t*)cur.sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo);
     BackendEvent t1 = be.record();
     mark("tile sort");
     if (o.tile_clock) { o.tile_clock->spans.push_back({t0, t1}); o.tile_clock->elems.push_back(n_elems); }
