@@ -753,23 +753,40 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
 
 // ---- tile_sort_general_kernel: the tiles tile_sort_kernel could not finish ------------------
 // (keys far from uniform inside the tile, or equal keys: repeats), taken from its queue
-// (redo[0] = length, redo[1..] = tile ids) by a fixed grid of workgroups.  Bottom-up rank-merge
-// levels: every element finds its slot by a branch-free fixed-depth binary search over the
-// sibling run's keys, finished with the exact comparator on key ties -- the
-// distribution-independent path (reference: merge_sort, src/Suffix_Array.cpp:112-129).
+// (redo[0] = length, redo[1..] = tile ids) by a fixed grid of workgroups.  Comparison based,
+// hence independent of the key distribution:
+//  1. samplesort in LDS: every 4th element is a sample; the (<= 1023) samples are sorted by
+//     rank-merge levels; every element finds its bin among the sorted samples by a branch-free
+//     fixed-depth binary search (exact comparator on key ties), a counting sort groups the bins,
+//     and each element ranks itself exactly inside its bin (~4 candidates).  ~25 comparison
+//     steps per suffix instead of ~78.  Gives up when a bin holds more than TILE_SAMPLE_LIMIT
+//     suffixes;
+//  2. bottom-up rank-merge levels over the whole tile (reference: merge_sort,
+//     src/Suffix_Array.cpp:112-129): every element finds its slot by the same binary search in
+//     the sibling run.
 // (A second, finer level of interpolation bins for the overflowing bins was tried first: on
 // Markov-skewed DNA it rescued < 20 % of the tiles and cost more than it saved.)
+constexpr uint32_t TILE_SAMPLE_LIMIT = 64;
+
 template <typename idx_t, int BITS, bool FROM_TEXT>
-GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) tile_sort_general_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
+GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_general_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
                                                           uint64_t text_base, uint32_t lcp_mode, const uint64_t* in_key,
                                                           const idx_t* in_sa, uint64_t* out_key, idx_t* out_sa, idx_t* out_lcp,
                                                           FinalOut<idx_t> fin, const uint32_t* __restrict__ redo)
 {
     SHARED_ARRAY(uint64_t, skey, TILE_E);
     SHARED_ARRAY(idx_t, ssa, TILE_E);
+    SHARED_ARRAY(uint64_t, smk, 2 * TILE_NT);       // samples (2x: the fixed-depth search may probe past the end)
+    SHARED_ARRAY(idx_t, sms, 2 * TILE_NT);
+    SHARED_ARRAY(uint32_t, hist, TILE_NT + 1);      // bin counters: #bins = #samples + 1 <= TILE_NT
+    SHARED_ARRAY(uint32_t, flag, 1);
     TL_DECL(uint64_t, rk, TILE_EPT);
     TL_DECL(idx_t, rs, TILE_EPT);
     TL_DECL(uint32_t, rd, TILE_EPT);
+    TL_DECL(uint32_t, rb, TILE_EPT);
+    TL_DECL(uint64_t, sk1, 1);                      // the thread's sample while the samples are sorted
+    TL_DECL(idx_t, ss1, 1);
+    TL_DECL(uint32_t, sd1, 1);
     const uint32_t n_redo = redo[0];
     for (uint32_t qi = K_BLOCK_IDX; qi < n_redo; qi += K_GRID_DIM) {
     const uint32_t b = redo[1 + qi];
@@ -779,26 +796,147 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) tile_sort_general_kernel(KCTX SegDesc sd, const
     const uint32_t cnt = (uint32_t)(t.s1 - start < TILE_E ? t.s1 - start : TILE_E);
     const bool with_lcp = lcp_mode != 0 && (t.s1 - t.s0) <= TILE_E;
     const bool direct = with_lcp && fin.sa != nullptr;
+    const uint32_t S = cnt / 4 < TILE_NT - 1 ? cnt / 4 : TILE_NT - 1;      // samples
     PAR(tid) {
+        if (tid == 0) flag[0] = 0;
+        for (uint32_t i = tid; i <= TILE_NT; i += K_BLOCK_DIM) hist[i] = 0;
         UNROLL
         for (uint32_t k = 0; k < TILE_EPT; ++k) {
             const uint32_t e = tid + k * TILE_NT;
             if (e < cnt) {
+                uint64_t key;
+                idx_t sa;
                 if (FROM_TEXT) {
-                    skey[e] = window64<BITS>(P, text_base + start + e);
-                    ssa[e] = (idx_t)(text_base + start + e);
+                    key = window64<BITS>(P, text_base + start + e);
+                    sa = (idx_t)(text_base + start + e);
                 } else {
-                    skey[e] = in_key[start + e];
-                    ssa[e] = in_sa[start + e];
+                    key = in_key[start + e];
+                    sa = in_sa[start + e];
                 }
+                TL(rk, tid, k) = key;
+                TL(rs, tid, k) = sa;
+                skey[e] = key;
+                ssa[e] = sa;
             }
         }
     }
     SYNC();
+    bool done = false;
+    if (S >= 16) {
+        // ---- 1. samplesort.  Samples: one per thread, sorted by rank-merge levels.
+        const uint32_t stride = cnt / S;
+        PAR(tid) {
+            if (tid < S) { smk[tid] = skey[tid * stride]; sms[tid] = ssa[tid * stride]; }
+        }
+        SYNC();
+        for (uint32_t R = 1; R < S; R <<= 1) {
+            PAR(tid) {
+                uint64_t key1[1] = {0};
+                idx_t sa1[1] = {0};
+                uint32_t lo1[1] = {0}, hi1[1] = {0};
+                uint32_t dbase = 0;
+                if (tid < S) {
+                    key1[0] = smk[tid];
+                    sa1[0] = sms[tid];
+                    const uint32_t run = tid / R;
+                    uint32_t sib = (run ^ 1u) * R;
+                    if (sib > S) sib = S;
+                    lo1[0] = sib;
+                    hi1[0] = sib + R < S ? sib + R : S;
+                    dbase = (run & ~1u) * R + (tid - run * R) - sib;
+                }
+                multi_lower_bound<idx_t, BITS, 1>(P, n, smk, sms, key1, sa1, lo1, hi1, 2 * R);
+                TL(sk1, tid, 0) = key1[0];
+                TL(ss1, tid, 0) = sa1[0];
+                TL(sd1, tid, 0) = dbase + lo1[0];
+            }
+            SYNC();
+            PAR(tid) {
+                if (tid < S) { smk[TL(sd1, tid, 0)] = TL(sk1, tid, 0); sms[TL(sd1, tid, 0)] = TL(ss1, tid, 0); }
+            }
+            SYNC();
+        }
+        // bin(x) = #samples < x  (bin j = (sample j-1, sample j]); counting sort by bin
+        const uint32_t top = pow2_above(S);
+        PAR(tid) {
+            UNROLL
+            for (uint32_t gg = 0; gg < TILE_EPT; gg += LOCK_K) {
+                uint64_t key[LOCK_K];
+                idx_t sa[LOCK_K];
+                uint32_t lo[LOCK_K], hi[LOCK_K];
+                UNROLL
+                for (uint32_t k = 0; k < LOCK_K; ++k) {
+                    const uint32_t e = tid + (gg + k) * TILE_NT;
+                    key[k] = TL(rk, tid, gg + k);
+                    sa[k] = TL(rs, tid, gg + k);
+                    lo[k] = 0;
+                    hi[k] = e < cnt ? S : 0u;
+                }
+                multi_lower_bound<idx_t, BITS, LOCK_K>(P, n, smk, sms, key, sa, lo, hi, top);
+                UNROLL
+                for (uint32_t k = 0; k < LOCK_K; ++k) {
+                    const uint32_t e = tid + (gg + k) * TILE_NT;
+                    if (e < cnt) {
+                        const uint32_t r = FETCH_ADD_U32(&hist[lo[k]], 1u);
+                        if (r >= TILE_SAMPLE_LIMIT) flag[0] = 1;
+                        TL(rb, tid, gg + k) = lo[k];
+                        TL(rd, tid, gg + k) = r;
+                    }
+                }
+            }
+        }
+        SYNC();
+        if (flag[0] == 0) {
+            block_exclusive_scan<TILE_NT>(KCTX_PASS hist);        // hist[j] = first slot of bin j, hist[TILE_NT] = cnt
+            PAR(tid) {
+                UNROLL
+                for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                    const uint32_t e = tid + k * TILE_NT;
+                    if (e < cnt) {
+                        const uint32_t slot = hist[TL(rb, tid, k)] + TL(rd, tid, k);
+                        skey[slot] = TL(rk, tid, k);
+                        ssa[slot] = TL(rs, tid, k);
+                        TL(rd, tid, k) = slot;
+                    }
+                }
+            }
+            SYNC();
+            PAR(tid) {
+                UNROLL
+                for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                    const uint32_t e = tid + k * TILE_NT;
+                    if (e < cnt) {
+                        const uint32_t bin = TL(rb, tid, k), slot = TL(rd, tid, k);
+                        const uint32_t bs = hist[bin], be = hist[bin + 1];
+                        const uint64_t key = TL(rk, tid, k);
+                        const uint64_t sa = (uint64_t)TL(rs, tid, k);
+                        uint32_t less = 0;                        // members of my bin that sort before me
+                        for (uint32_t j = bs; j < be; ++j)
+                            if (j != slot && suffix_less<BITS>(P, n, skey[j], (uint64_t)ssa[j], key, sa)) ++less;
+                        TL(rd, tid, k) = bs + less;
+                    }
+                }
+            }
+            SYNC();
+            TILE_SORT_PLACE_FINAL
+            done = true;
+        }
+    }
 #ifdef CAPS_EMUL
-    caps_emul_count_tile2(false);
+    caps_emul_count_tile2(done);
 #endif
-    for (uint32_t R = 1; R < cnt; R <<= 1) {
+    // ---- 2. bottom-up rank-merge levels
+    if (!done && S >= 16) {
+        PAR(tid) {                                  // the counting sort may have been abandoned half way: restore
+            UNROLL
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                const uint32_t e = tid + k * TILE_NT;
+                if (e < cnt) { skey[e] = TL(rk, tid, k); ssa[e] = TL(rs, tid, k); }
+            }
+        }
+        SYNC();
+    }
+    for (uint32_t R = 1; !done && R < cnt; R <<= 1) {
         PAR(tid) {
             UNROLL
             for (uint32_t gg = 0; gg < TILE_EPT; gg += LOCK_K) {          // LOCK_K searches in lockstep
