@@ -293,3 +293,22 @@ def test_skewed_and_texty_inputs_device(L, oracle):
     assert st["merge_passes_phase1"] + st["merge_passes_phase2"] > 0
     letters = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz ", dtype=np.uint8)
     _same(L, oracle, rs.choice(letters, size=2_000_000, p=np.r_[np.full(26, 0.03), 0.22]), 40)
+
+
+def test_genome_like_markov_with_repeats_device(L):
+    """Order-5 Markov chain with skewed transitions + planted mutated repeats (tools/genome_like.py):
+    most tiles leave the bucket-sort fast path (samplesort / rank-merge levels), buckets overflow into
+    LCP-merge passes.  Checked with the exact device verifier."""
+    import os
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    from genome_like import markov_dna
+    n = 30_000_001
+    T = markov_dna(n, seed=11)
+    SA = torch.empty(n, dtype=torch.int32, device="cuda")
+    LCP = torch.empty(n, dtype=torch.int32, device="cuda")
+    st = L.build_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr(), p=1000)
+    assert L.verify_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr()) == 0
+    assert int(LCP.max().item()) > 200          # the planted repeats are there
