@@ -60,17 +60,23 @@ def _all_gather_var(t: torch.Tensor, counts: list[int], max_elems: int = 1 << 25
 A2A_MAX_BYTES = (1 << 30) - (1 << 16)
 
 
-def all_to_all_v(recv: torch.Tensor, send: torch.Tensor, rc: list[int], sc: list[int], max_bytes: int | None = None):
-    """all-to-all-v of 1-D tensors: send[sum(sc[:r]) : +sc[r]] goes to rank r, recv gets rc[r]
-    elements from rank r.  One all_to_all_single when every block fits max_bytes (C3 on 8 GPUs:
-    375 MB per pair); otherwise rounds of grouped point-to-point sends/receives on views of the
-    buffers -- direct peer-to-peer over xGMI, all links busy, no staging copy."""
+def exchange_plan(rc: list[int], sc: list[int], elem_bytes: int, device, max_bytes: int | None = None):
+    """(rounds, elements per round and peer) for an all-to-all-v of blocks of rc/sc elements whose
+    widest element has elem_bytes bytes; agreed on by all ranks (one tiny all_reduce)."""
     max_bytes = max_bytes or A2A_MAX_BYTES
+    cmax = max(1, max_bytes // elem_bytes)
+    big = torch.tensor([max(sc + rc) if sc else 0], dtype=torch.int64, device=device)
+    dist.all_reduce(big, op=dist.ReduceOp.MAX)
+    return max(1, -(-int(big.item()) // cmax)), cmax
+
+
+def all_to_all_v(recv: torch.Tensor, send: torch.Tensor, rc: list[int], sc: list[int], plan=None):
+    """all-to-all-v of 1-D tensors: send[sum(sc[:r]) : +sc[r]] goes to rank r, recv gets rc[r]
+    elements from rank r.  One all_to_all_single when every block fits the message cap (C3 on 8
+    GPUs: 375 MB per pair); otherwise rounds of grouped point-to-point sends/receives on views of
+    the buffers -- direct peer-to-peer over xGMI, all links busy, no staging copy."""
     world, rank = dist.get_world_size(), dist.get_rank()
-    cmax = max(1, max_bytes // send.element_size())
-    big = torch.tensor([max(sc + rc) if sc else 0], dtype=torch.int64, device=send.device)
-    dist.all_reduce(big, op=dist.ReduceOp.MAX)                    # same number of rounds on every rank
-    rounds = max(1, -(-int(big.item()) // cmax))
+    rounds, cmax = plan if plan is not None else exchange_plan(rc, sc, send.element_size(), send.device)
     if rounds == 1:
         dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=sc)
         return
@@ -164,8 +170,9 @@ def build_sharded(lib, T: torch.Tensor, p: int = 0, idx_bits: int | None = None,
         # ---- THE exchange (RCCL all-to-all-v over xGMI on GPUs)
         recv_k, recv_s = B.recv_k, B.recv_s
         t0 = time.perf_counter()
-        all_to_all_v(recv_k[:total], send_k[:sum(sc)], rc, sc)
-        all_to_all_v(recv_s[:total], send_s[:sum(sc)], rc, sc)
+        plan = exchange_plan(rc, sc, 8, dev)                      # one agreement for both tensors (keys are the wider)
+        all_to_all_v(recv_k[:total], send_k[:sum(sc)], rc, sc, plan)
+        all_to_all_v(recv_s[:total], send_s[:sum(sc)], rc, sc, plan)
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
         ms_exchange = 1e3 * (time.perf_counter() - t0)
@@ -176,8 +183,8 @@ def build_sharded(lib, T: torch.Tensor, p: int = 0, idx_bits: int | None = None,
         sh.phase2(recv_k.data_ptr(), recv_s.data_ptr(), SA.data_ptr(), LCP.data_ptr())
         lap("phase2")
         # ---- boundary LCP between consecutive slices
-        last = torch.tensor([sh.last_sa() - (1 << 64) if sh.last_sa() >= (1 << 63) else sh.last_sa()], dtype=torch.int64,
-                            device=dev)
+        mine = sh.last_sa()
+        last = torch.tensor([mine - (1 << 64) if mine >= (1 << 63) else mine], dtype=torch.int64, device=dev)
         lasts = torch.empty(world, dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(lasts, last)
         prev = 0xFFFFFFFFFFFFFFFF
