@@ -54,6 +54,8 @@ static inline uint64_t caps_fetch_add_u64(uint64_t* p, uint64_t v) { const uint6
 #define FETCH_ADD_U32(ptr, v) caps_fetch_add_u32((ptr), (v))      /* returns the old value */
 #define BLOCK_MINMAX_U64(pmin, pmax, mn, mx) do { if ((mn) < *(pmin)) *(pmin) = (mn); if ((mx) > *(pmax)) *(pmax) = (mx); } while (0)
 #define FETCH_ADD_U64(ptr, v) caps_fetch_add_u64((ptr), (v))
+static inline uint32_t caps_fetch_add(uint32_t* p, uint32_t v) { return caps_fetch_add_u32(p, v); }
+static inline uint64_t caps_fetch_add(uint64_t* p, uint64_t v) { return caps_fetch_add_u64(p, v); }
 static inline uint64_t caps_umul64hi(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
 static inline int caps_clz64(uint64_t x) { return __builtin_clzll(x); }
 static inline uint32_t caps_bswap32(uint32_t x) { return __builtin_bswap32(x); }
@@ -99,6 +101,8 @@ static __device__ __forceinline__ void caps_block_minmax_u64(uint64_t* pmin, uin
 }
 #define BLOCK_MINMAX_U64(pmin, pmax, mn, mx) caps_block_minmax_u64((pmin), (pmax), (mn), (mx))
 #define FETCH_ADD_U64(ptr, v) ((uint64_t)atomicAdd((unsigned long long*)(ptr), (unsigned long long)(v)))
+static __device__ __forceinline__ uint32_t caps_fetch_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+static __device__ __forceinline__ uint64_t caps_fetch_add(uint64_t* p, uint64_t v) { return (uint64_t)atomicAdd((unsigned long long*)p, (unsigned long long)v); }
 static __device__ __forceinline__ uint64_t caps_umul64hi(uint64_t a, uint64_t b) { return __umul64hi(a, b); }
 static __host__ __device__ __forceinline__ int caps_clz64(uint64_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -1444,7 +1444,7 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
                                                        uint64_t text_base, const uint64_t* __restrict__ in_key,
                                                        const idx_t* __restrict__ in_sa,
                                                        const BucketParams* __restrict__ bps, const uint64_t* __restrict__ bstart,
-                                                       const uint64_t* __restrict__ sub_start, uint32_t* __restrict__ cursor,
+                                                       const uint64_t* __restrict__ sub_start, idx_t* __restrict__ cursor,
                                                        uint64_t* __restrict__ out_key, idx_t* __restrict__ out_sa)
 {
     const uint32_t b = K_BLOCK_IDX;
@@ -1464,7 +1464,8 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
     TL_DECL(uint64_t, rk, TILE_EPT);
     TL_DECL(idx_t, rs, TILE_EPT);
     TL_DECL(uint32_t, rb, TILE_EPT);      // bucket
-    TL_DECL(uint32_t, rr, TILE_EPT);      // rank inside (tile, bucket) or inside the bucket
+    TL_DECL(idx_t, rr, TILE_EPT);         // rank inside (tile, bucket) or inside the bucket (idx_t: a bucket of a
+                                          // degenerate text can hold more than 2^32 suffixes at 64-bit indices)
     const bool lds = bp.B > 1 && bp.B <= BUCKET_LDS;
     // FROM_TEXT: the tile's slice of the packed text is staged in the (not yet used) key staging array
     uint32_t* twin = reinterpret_cast<uint32_t*>(skey);
@@ -1485,11 +1486,12 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
                 const uint64_t key = FROM_TEXT ? window64<BITS>(twin, text_base + start + e - w0 * TextTraits<BITS>::CPW)
                                                : in_key[start + e];
                 const idx_t sa = FROM_TEXT ? (idx_t)(text_base + start + e) : in_sa[start + e];
-                uint32_t bk = 0, r;
+                uint32_t bk = 0;
+                idx_t r;
                 if (bp.B == 1) r = e;                                        // identity: the segment is its own bucket
                 else {
                     bk = bucket_of(bp, key);
-                    r = lds ? FETCH_ADD_U32(&hist[bk], 1u) : FETCH_ADD_U32(&cursor[b0 + bk], 1u);
+                    r = lds ? FETCH_ADD_U32(&hist[bk], 1u) : caps_fetch_add(&cursor[b0 + bk], (idx_t)1);
                 }
                 TL(rk, tid, k) = key;
                 TL(rs, tid, k) = sa;
@@ -1517,7 +1519,7 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
     PAR(tid) {                                             // one global cursor bump per (tile, non-empty bucket)
         for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM) {
             const uint32_t c = hist[i];
-            obase[i] = c ? (idx_t)(sub_start[b0 + i] + FETCH_ADD_U32(&cursor[b0 + i], c)) : (idx_t)0;
+            obase[i] = c ? (idx_t)(sub_start[b0 + i] + caps_fetch_add(&cursor[b0 + i], (idx_t)c)) : (idx_t)0;
         }
     }
     SYNC();
@@ -1529,7 +1531,7 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
             const uint32_t e = tid + k * TILE_NT;
             if (e < cnt) {
                 const uint32_t bk = TL(rb, tid, k);
-                const uint32_t q = hist[bk] + TL(rr, tid, k);
+                const uint32_t q = hist[bk] + (uint32_t)TL(rr, tid, k);
                 skey[q] = TL(rk, tid, k);
                 ssa[q] = TL(rs, tid, k);
                 sbk[q] = (uint16_t)bk;

@@ -68,7 +68,7 @@ struct BucketBufs {
     uint64_t* segB = nullptr;         // [G]    buckets per parent segment
     uint64_t* bstart = nullptr;       // [G+1]  exclusive scan of segB
     uint64_t* count = nullptr;        // [nb_cap] elements per bucket
-    uint32_t* cursor = nullptr;       // [nb_cap]
+    void* cursor = nullptr;           // [nb_cap] idx_t
     uint64_t* scan_tmp = nullptr;     // [2 * (nb_cap / SCAN_CHUNK + 2)]
     uint64_t *first_key = nullptr, *last_key = nullptr;   // [nb_cap] boundary records of the sorted segments
     uint64_t *range_lo = nullptr, *range_hi = nullptr;    // [nb_cap] key range of every bucket
@@ -164,7 +164,7 @@ Plan<idx_t> make_plan(uint64_t n, uint64_t p_arg, char* base)
     pl.bk.segB = ar.take<uint64_t>(p);
     pl.bk.bstart = ar.take<uint64_t>((size_t)p + 1);
     pl.bk.count = ar.take<uint64_t>(pl.bk.nb_cap);
-    pl.bk.cursor = ar.take<uint32_t>(pl.bk.nb_cap);
+    pl.bk.cursor = ar.take<idx_t>(pl.bk.nb_cap);
     pl.bk.scan_tmp = ar.take<uint64_t>(2 * ((size_t)pl.bk.nb_cap / SCAN_CHUNK + 2));
     pl.bk.range_lo = ar.take<uint64_t>(pl.bk.nb_cap);
     pl.bk.range_hi = ar.take<uint64_t>(pl.bk.nb_cap);
@@ -341,7 +341,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         range_hi = bk.range_hi;
         mark("bucket plan");
         be.memset(bk.count, 0, (size_t)bk.nb_cap * sizeof(uint64_t));
-        be.memset(bk.cursor, 0, (size_t)bk.nb_cap * sizeof(uint32_t));
+        be.memset(bk.cursor, 0, (size_t)bk.nb_cap * sizeof(idx_t));
         ElemBuf<idx_t> dst = from_text ? cur : oth;
         const uint32_t pgrid = n_tiles < be.persistent_blocks() ? n_tiles : be.persistent_blocks();
         if (from_text) {
@@ -353,7 +353,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
             BackendEvent s0 = be.record();
             CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, psd, P, packed_words(n, BITS), o.text_base, (const uint64_t*)nullptr,
                         (const idx_t*)nullptr, (const BucketParams*)bk.params, (const uint64_t*)bk.bstart,
-                        (const uint64_t*)bk.sub.seg_start, bk.cursor, dst.key, dst.sa);
+                        (const uint64_t*)bk.sub.seg_start, static_cast<idx_t*>(bk.cursor), dst.key, dst.sa);
             BackendEvent s1 = be.record();
             if (o.count_clock) { o.count_clock->spans.push_back({c0, c1}); o.count_clock->elems.push_back(n_elems); }
             if (o.scatter_clock) { o.scatter_clock->spans.push_back({s0, s1}); o.scatter_clock->elems.push_back(n_elems); }
@@ -366,7 +366,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
             BackendEvent s0 = be.record();
             CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, psd, P, (uint64_t)0, (uint64_t)0, (const uint64_t*)cur.key,
                         (const idx_t*)cur.sa, (const BucketParams*)bk.params, (const uint64_t*)bk.bstart,
-                        (const uint64_t*)bk.sub.seg_start, bk.cursor, dst.key, dst.sa);
+                        (const uint64_t*)bk.sub.seg_start, static_cast<idx_t*>(bk.cursor), dst.key, dst.sa);
             BackendEvent s1 = be.record();
             if (o.count_clock) { o.count_clock->spans.push_back({c0, c1}); o.count_clock->elems.push_back(n_elems); }
             if (o.scatter_clock) { o.scatter_clock->spans.push_back({s0, s1}); o.scatter_clock->elems.push_back(n_elems); }

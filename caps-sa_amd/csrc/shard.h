@@ -387,7 +387,7 @@ private:
         k.segB = get<uint64_t>(G);
         k.bstart = get<uint64_t>((size_t)G + 1);
         k.count = get<uint64_t>(k.nb_cap);
-        k.cursor = get<uint32_t>(k.nb_cap);
+        k.cursor = get<idx_t>(k.nb_cap);
         k.scan_tmp = get<uint64_t>(2 * ((size_t)k.nb_cap / SCAN_CHUNK + 2));
         k.range_lo = get<uint64_t>(k.nb_cap);
         k.range_hi = get<uint64_t>(k.nb_cap);
