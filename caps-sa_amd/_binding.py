@@ -49,6 +49,8 @@ class Stats(ctypes.Structure):
         ("bucket_scatter_elems", ctypes.c_uint64),
         ("bucket_count_ms", ctypes.c_double),
         ("collate_ms", ctypes.c_double),
+        ("slot_splits", ctypes.c_uint32),
+        ("slot_splits_redone", ctypes.c_uint32),
     ]
 
     def as_dict(self) -> dict:

@@ -182,7 +182,7 @@ template <typename idx_t> SegBufs one_segment(Backend& be, DevAllocs& da, uint64
     s.G = 1;
     s.seg_start = da.get<uint64_t>(2);
     s.tile_off = da.get<uint32_t>(2);
-    s.tile_seg = da.get<uint32_t>(tiles_of(cnt) + 2);
+    s.tile_rec = da.get<TileInfo>(tiles_of(cnt) + 2);
     s.out2 = da.get<uint64_t>(2);
     CAPS_LAUNCH(uniform_segments_kernel, 1, 256, be, s.seg_start, 1u, cnt, cnt);
     prepare_segments(be, s, tiles_of(cnt));
@@ -277,7 +277,7 @@ int sort_segments(const char* T, uint64_t n, const idx_t* idx, uint64_t cnt, con
         s.G = (uint32_t)G;
         s.seg_start = da.get<uint64_t>(G + 1);
         s.tile_off = da.get<uint32_t>(G + 1);
-        s.tile_seg = da.get<uint32_t>(n_tiles + 2);
+        s.tile_rec = da.get<TileInfo>(n_tiles + 2);
         s.out2 = da.get<uint64_t>(2);
         be.h2d(a.sa, idx, cnt * sizeof(idx_t));
         be.h2d(s.seg_start, seg_start, (G + 1) * sizeof(uint64_t));

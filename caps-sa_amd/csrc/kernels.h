@@ -58,27 +58,24 @@ static_assert(TILE_E % TILE_NT == 0 && TILE_EPT % LOCK_K == 0, "tile geometry");
 constexpr uint32_t TILE_BINS_ = TILE_E / CAPS_TILE_BINS_DIV;   // bins of the in-LDS bucket sort of one tile
 
 // Segment/tile descriptor shared by the tile-granular kernels.
+// One record per tile, written once by tile_map_kernel: a tile kernel starts with ONE load of
+// its record instead of the dependent chain tile -> segment -> segment bounds (a workgroup is
+// a few microseconds of work, so every dependent global load at its start shows).
+struct alignas(16) TileInfo {
+    uint64_t s0, s1;     // segment range
+    uint32_t tl;         // tile index inside the segment
+    uint32_t g;          // segment
+    uint32_t pad_[2];
+};
+
 struct SegDesc {
     const uint64_t* seg_start;   // [G+1] element offsets of the segments
     const uint32_t* tile_off;    // [G+1] exclusive scan of ceil(len/TILE_E); tile_off[G] = #tiles
-    const uint32_t* tile_seg;    // [#tiles] segment of each tile
+    const TileInfo* tile_rec;    // [#tiles] record of each tile
     uint32_t G;
 };
 
-struct TileInfo {
-    uint64_t s0, s1;     // segment range
-    uint32_t tl;         // tile index inside the segment
-};
-
-DEV_INLINE TileInfo tile_info(const SegDesc& sd, uint32_t b)
-{
-    const uint32_t g = sd.tile_seg[b];
-    TileInfo t;
-    t.s0 = sd.seg_start[g];
-    t.s1 = sd.seg_start[g + 1];
-    t.tl = b - sd.tile_off[g];
-    return t;
-}
+DEV_INLINE TileInfo tile_info(const SegDesc& sd, uint32_t b) { return sd.tile_rec[b]; }
 
 // Geometry of the run pair a tile belongs to during a merge pass with run length R
 // (R is a multiple of TILE_E).  single_la != ~0: the segment is ONE pair whose first run
@@ -381,8 +378,9 @@ GLOBAL_FN LAUNCH_BOUNDS(64) tile_total_kernel(KCTX const uint32_t* __restrict__ 
     PAR(tid) { if (tid == 0 && K_BLOCK_IDX == 0) out2[0] = tile_off[G]; }
 }
 
-// tile_seg[b] = the segment g with tile_off[g] <= b < tile_off[g+1].
-GLOBAL_FN LAUNCH_BOUNDS(256) tile_map_kernel(KCTX const uint32_t* __restrict__ tile_off, uint32_t G, uint32_t* __restrict__ tile_seg)
+// tile_rec[b] for the segment g with tile_off[g] <= b < tile_off[g+1].
+GLOBAL_FN LAUNCH_BOUNDS(256) tile_map_kernel(KCTX const uint64_t* __restrict__ seg_start, const uint32_t* __restrict__ tile_off, uint32_t G,
+                                             TileInfo* __restrict__ tile_rec)
 {
     PAR(tid) {
         const uint64_t b = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
@@ -392,7 +390,13 @@ GLOBAL_FN LAUNCH_BOUNDS(256) tile_map_kernel(KCTX const uint32_t* __restrict__ t
                 const uint32_t mid = (lo + hi) / 2;
                 if (tile_off[mid] <= b) lo = mid; else hi = mid;
             }
-            tile_seg[b] = lo;
+            TileInfo t;
+            t.s0 = seg_start[lo];
+            t.s1 = seg_start[lo + 1];
+            t.tl = (uint32_t)b - tile_off[lo];
+            t.g = lo;
+            t.pad_[0] = t.pad_[1] = 0;
+            tile_rec[b] = t;
         }
     }
 }
@@ -557,7 +561,7 @@ constexpr uint32_t TILE_BIN_LIMIT = CAPS_TILE_BIN_LIMIT;
 #define TILE_SORT_PROLOGUE                                                                                      \
     const uint32_t b = K_BLOCK_IDX;                                                                             \
     if (b >= sd.tile_off[sd.G]) return;                                                                         \
-    const uint32_t g = sd.tile_seg[b];                                                                          \
+    const uint32_t g = sd.tile_rec[b].g;                                                                          \
     const TileInfo t = tile_info(sd, b);                                                                        \
     const uint64_t start = t.s0 + (uint64_t)t.tl * TILE_E;                                                      \
     const uint32_t cnt = (uint32_t)(t.s1 - start < TILE_E ? t.s1 - start : TILE_E);                             \
@@ -566,7 +570,9 @@ constexpr uint32_t TILE_BIN_LIMIT = CAPS_TILE_BIN_LIMIT;
     const bool with_lcp = lcp_mode != 0 && (t.s1 - t.s0) <= TILE_E;                                             \
     /* fin.sa != null: a segment completed here goes straight to the caller's SA / LCP arrays                */ \
     /* (its head LCP is filled in by head_lcp_kernel from the boundary records).                             */ \
-    const bool direct = with_lcp && fin.sa != nullptr;
+    const bool direct = with_lcp && fin.sa != nullptr;                                                          \
+    /* slot_cap != 0: the input of segment (bucket) g sits in its fixed-capacity slot, see bucket_scatter_kernel */ \
+    const uint64_t in0 = slot_cap ? (uint64_t)g * slot_cap : start;
 
 #define TILE_SORT_LOAD                                                                                          \
     PAR(tid) {                                                                                                  \
@@ -582,8 +588,8 @@ constexpr uint32_t TILE_BIN_LIMIT = CAPS_TILE_BIN_LIMIT;
                     key = window64<BITS>(P, text_base + start + e);                                             \
                     sa = (idx_t)(text_base + start + e);                                                        \
                 } else {                                                                                        \
-                    key = in_key[start + e];                                                                    \
-                    sa = in_sa[start + e];                                                                      \
+                    key = in_key[in0 + e];                                                                      \
+                    sa = in_sa[in0 + e];                                                                        \
                 }                                                                                               \
                 TL(rk, tid, k) = key;                                                                           \
                 TL(rs, tid, k) = sa;                                                                            \
@@ -666,7 +672,7 @@ constexpr uint32_t TILE_BIN_LIMIT = CAPS_TILE_BIN_LIMIT;
 // tile_sort_general_kernel sorts the tile.
 template <typename idx_t, int BITS, bool FROM_TEXT>
 GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
-                                                  uint64_t text_base, uint32_t lcp_mode, const uint64_t* in_key,
+                                                  uint64_t text_base, uint32_t lcp_mode, uint32_t slot_cap, const uint64_t* in_key,
                                                   const idx_t* in_sa, uint64_t* out_key, idx_t* out_sa, idx_t* out_lcp,
                                                   FinalOut<idx_t> fin, const uint64_t* __restrict__ seg_lo,
                                                   const uint64_t* __restrict__ seg_hi, uint32_t* __restrict__ redo)
@@ -770,7 +776,7 @@ constexpr uint32_t TILE_SAMPLE_LIMIT = 64;
 
 template <typename idx_t, int BITS, bool FROM_TEXT>
 GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_general_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
-                                                          uint64_t text_base, uint32_t lcp_mode, const uint64_t* in_key,
+                                                          uint64_t text_base, uint32_t lcp_mode, uint32_t slot_cap, const uint64_t* in_key,
                                                           const idx_t* in_sa, uint64_t* out_key, idx_t* out_sa, idx_t* out_lcp,
                                                           FinalOut<idx_t> fin, const uint32_t* __restrict__ redo)
 {
@@ -790,12 +796,13 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_general_kernel(
     const uint32_t n_redo = redo[0];
     for (uint32_t qi = K_BLOCK_IDX; qi < n_redo; qi += K_GRID_DIM) {
     const uint32_t b = redo[1 + qi];
-    const uint32_t g = sd.tile_seg[b];
+    const uint32_t g = sd.tile_rec[b].g;
     const TileInfo t = tile_info(sd, b);
     const uint64_t start = t.s0 + (uint64_t)t.tl * TILE_E;
     const uint32_t cnt = (uint32_t)(t.s1 - start < TILE_E ? t.s1 - start : TILE_E);
     const bool with_lcp = lcp_mode != 0 && (t.s1 - t.s0) <= TILE_E;
     const bool direct = with_lcp && fin.sa != nullptr;
+    const uint64_t in0 = slot_cap ? (uint64_t)g * slot_cap : start;
     const uint32_t S = cnt / 4 < TILE_NT - 1 ? cnt / 4 : TILE_NT - 1;      // samples
     PAR(tid) {
         if (tid == 0) flag[0] = 0;
@@ -810,8 +817,8 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_general_kernel(
                     key = window64<BITS>(P, text_base + start + e);
                     sa = (idx_t)(text_base + start + e);
                 } else {
-                    key = in_key[start + e];
-                    sa = in_sa[start + e];
+                    key = in_key[in0 + e];
+                    sa = in_sa[in0 + e];
                 }
                 TL(rk, tid, k) = key;
                 TL(rs, tid, k) = sa;
@@ -1232,7 +1239,7 @@ GLOBAL_FN LAUNCH_BOUNDS(256) finalize_kernel(KCTX SegDesc sd, const uint32_t* __
 {
     const uint32_t b = K_BLOCK_IDX;
     if (b >= sd.tile_off[sd.G]) return;
-    const uint32_t g = sd.tile_seg[b];
+    const uint32_t g = sd.tile_rec[b].g;
     const TileInfo t = tile_info(sd, b);
     const uint64_t seglen = t.s1 - t.s0;
     // with boundary records (fin): segments completed by the tile sort are already in place
@@ -1284,6 +1291,110 @@ GLOBAL_FN LAUNCH_BOUNDS(256) head_lcp_kernel(KCTX const uint32_t* __restrict__ P
     }
 }
 
+// Maps a launch-order block id to a logical block id such that the blocks that share
+// an XCD (b % 8, MI355X_MICROARCH "Workgroup dispatch") work on a contiguous range of
+// logical blocks: consecutive logical blocks -- here the searches over one subarray --
+// then hit the same 4 MiB L2.  Speed only; any placement is correct.
+DEV_INLINE uint64_t xcd_swizzle(uint64_t b, uint64_t nb)
+{
+    const uint64_t q = nb / 8, r = nb % 8, x = b % 8, y = b / 8;
+    return x * q + (x < r ? x : r) + y;
+}
+
+// ---- phase 2 straight from the sorted subarrays (a9 + a10 in one pass) ----------------
+// The reference first gathers every partition (p^2 memcpy's, cpp:343-358) and then sorts it.
+// On one GPU the bucket split of phase 2 can read the partition THROUGH the partition matrix
+// instead: element x of partition j is element  PmT[j][g] + (x - rulerT[j][g])  of sorted
+// subarray g, g = the run with rulerT[j][g] <= x < rulerT[j][g+1].  That removes one full
+// read + write of (key, sa) -- the collate pass -- from the build.  PmT / rulerT are the
+// transposes of Pm / ruler (a partition's runs are then consecutive in memory).
+template <typename idx_t> struct RunSrc {
+    const idx_t* PmT = nullptr;            // [(p+1) x G1]  PmT[j * G1 + g] = Pm[g][j]
+    const idx_t* rulerT = nullptr;         // [p x G1]      rulerT[j * G1 + g] = ruler[g][j]
+    const uint64_t* sub_start = nullptr;   // [G1 + 1] element offsets of the sorted subarrays
+    const uint32_t* first_run = nullptr;   // [#tiles of the partitions] run holding the tile's first element
+    uint32_t G1 = 0;
+};
+
+// out[c * rows + r] = in[r * cols + c]; 32 x 32 tiles through LDS, 256 threads.
+template <typename idx_t>
+GLOBAL_FN LAUNCH_BOUNDS(256) transpose_kernel(KCTX const idx_t* __restrict__ in, uint32_t rows, uint32_t cols,
+                                              idx_t* __restrict__ out)
+{
+    SHARED_ARRAY(idx_t, tile, 32 * 33);
+    const uint32_t tc = (cols + 31) / 32;
+    const uint32_t r0 = (K_BLOCK_IDX / tc) * 32, c0 = (K_BLOCK_IDX % tc) * 32;
+    PAR(tid) {
+        const uint32_t x = tid & 31, y = tid >> 5;             // 8 rows of 32 per step
+        for (uint32_t yy = y; yy < 32; yy += 8)
+            if (r0 + yy < rows && c0 + x < cols) tile[yy * 33 + x] = in[(uint64_t)(r0 + yy) * cols + c0 + x];
+    }
+    SYNC();
+    PAR(tid) {
+        const uint32_t x = tid & 31, y = tid >> 5;
+        for (uint32_t yy = y; yy < 32; yy += 8)
+            if (c0 + yy < cols && r0 + x < rows) out[(uint64_t)(c0 + yy) * rows + r0 + x] = tile[x * 33 + yy];
+    }
+}
+
+// largest g in [lo, hi] with row[g] <= x   (row[lo] <= x)
+template <typename idx_t>
+DEV_INLINE uint32_t run_of(const idx_t* row, uint32_t lo, uint32_t hi, uint64_t x)
+{
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if ((uint64_t)row[mid] <= x) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// One thread per tile of the partitions: the run that holds the tile's first element.
+template <typename idx_t>
+GLOBAL_FN LAUNCH_BOUNDS(256) runs_plan_kernel(KCTX SegDesc sd, const idx_t* __restrict__ rulerT, uint32_t G1,
+                                              uint32_t* __restrict__ first_run)
+{
+    PAR(tid) {
+        const uint64_t b = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (b < sd.tile_off[sd.G]) {
+            const uint32_t j = sd.tile_rec[b].g;
+            const TileInfo t = tile_info(sd, (uint32_t)b);
+            first_run[b] = run_of<idx_t>(rulerT + (uint64_t)j * G1, 0u, G1 - 1, (uint64_t)t.tl * TILE_E);
+        }
+    }
+}
+
+// The runs a tile of partition j spans, staged in LDS: lrow[k] = rulerT[j][ga + k],
+// lsrc[k] = (offset of run ga + k in the phase-1 arrays) - lrow[k], so that element x of the
+// partition is phase-1 element lsrc[k] + x.  ns = #runs (<= TILE_E to be staged).
+#define RUNS_TILE_SETUP                                                                                         \
+    const uint32_t run_a = FROM_RUNS ? rsrc.first_run[b] : 0u;                                                  \
+    const uint32_t run_b = !FROM_RUNS ? 0u : (start + cnt >= t.s1) ? rsrc.G1 - 1 : rsrc.first_run[b + 1];       \
+    const uint32_t run_ns = run_b - run_a + 1;                                                                  \
+    const bool runs_staged = run_ns <= TILE_E;                                                                  \
+    const idx_t* run_rowR = rsrc.rulerT + (uint64_t)g * rsrc.G1;                                                \
+    const idx_t* run_rowA = rsrc.PmT + (uint64_t)g * rsrc.G1;                                                   \
+    const uint64_t run_x0 = start - t.s0;                                                                       \
+    (void)run_a; (void)run_b; (void)run_ns; (void)runs_staged; (void)run_rowR; (void)run_rowA; (void)run_x0;
+
+#define RUNS_STAGE(tid)                                                                                         \
+    if (runs_staged)                                                                                            \
+        for (uint32_t k = tid; k < run_ns; k += K_BLOCK_DIM) {                                                  \
+            const idx_t r = run_rowR[run_a + k];                                                                \
+            lrow[k] = r;                                                                                        \
+            lsrc[k] = rsrc.sub_start[run_a + k] + (uint64_t)run_rowA[run_a + k] - (uint64_t)r;                  \
+        }
+
+template <typename idx_t>
+DEV_INLINE uint64_t run_source(const RunSrc<idx_t>& rsrc, bool staged, const idx_t* lrow, const uint64_t* lsrc, uint32_t ns,
+                               const idx_t* rowR, const idx_t* rowA, uint32_t ga, uint32_t gb, uint64_t x)
+{
+    if (staged) return lsrc[run_of<idx_t>(lrow, 0u, ns - 1, x)] + x;
+    const uint32_t r = run_of<idx_t>(rowR, ga, gb, x);
+    return rsrc.sub_start[r] + (uint64_t)rowA[r] + (x - (uint64_t)rowR[r]);
+}
+
+constexpr int SRC_ARRAYS = 0, SRC_TEXT = 1, SRC_RUNS = 2;      // where a bucket split reads its elements
+
 // ----------------------------------------------------------------------------------
 // Bucketing inside a sort (a4/a10): before the tile sort, every segment longer than a tile
 // is split by KEY RANGE into B = ceil(len / BUCKET_TARGET) buckets; bucket(key) is a
@@ -1303,6 +1414,15 @@ GLOBAL_FN LAUNCH_BOUNDS(256) head_lcp_kernel(KCTX const uint32_t* __restrict__ P
 // ----------------------------------------------------------------------------------
 #ifndef CAPS_BUCKET_EIGHTHS
 #define CAPS_BUCKET_EIGHTHS 7
+#endif
+#ifndef CAPS_SCATTER_SWZ
+#define CAPS_SCATTER_SWZ 1
+#endif
+#ifndef CAPS_COLLATE_SWZ
+#define CAPS_COLLATE_SWZ 0
+#endif
+#ifndef CAPS_TILE_SWZ
+#define CAPS_TILE_SWZ 0
 #endif
 constexpr uint32_t BUCKET_TARGET = (TILE_E * CAPS_BUCKET_EIGHTHS) / 8;   // mean bucket size (headroom for the spread of bucket sizes)
 constexpr uint32_t BUCKET_LDS = TILE_BINS_;            // buckets per segment the LDS histogram can hold
@@ -1382,17 +1502,21 @@ template <int BITS> HD uint64_t text_win_base(uint64_t pos0) { return pos0 / Tex
 
 // Persistent workgroups (a tile is little work: launching one workgroup per tile is bound by
 // the wave launch rate).
-template <typename idx_t, int BITS, bool FROM_TEXT>
+template <typename idx_t, int BITS, int SRC>
 GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_count_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n_words,
-                                                     uint64_t text_base, const uint64_t* __restrict__ in_key,
+                                                     uint64_t text_base, const uint64_t* __restrict__ in_key, RunSrc<idx_t> rsrc,
                                                      const BucketParams* __restrict__ bps, const uint64_t* __restrict__ bstart,
                                                      uint64_t* __restrict__ count)
 {
+    constexpr bool FROM_TEXT = SRC == SRC_TEXT, FROM_RUNS = SRC == SRC_RUNS;
     SHARED_ARRAY(uint32_t, hist, BUCKET_LDS);
     SHARED_ARRAY(uint32_t, twin, FROM_TEXT ? TEXT_WIN : 1);
+    SHARED_ARRAY(uint64_t, lsrc, FROM_RUNS ? TILE_E : 1);
+    SHARED_ARRAY(idx_t, lrow, FROM_RUNS ? TILE_E : 1);
     const uint32_t n_tiles = sd.tile_off[sd.G];
-    for (uint32_t b = K_BLOCK_IDX; b < n_tiles; b += K_GRID_DIM) {
-        const uint32_t g = sd.tile_seg[b];
+    for (uint32_t v = K_BLOCK_IDX; v < n_tiles; v += K_GRID_DIM) {
+        const uint32_t b = v;
+        const uint32_t g = sd.tile_rec[b].g;
         const TileInfo t = tile_info(sd, b);
         const uint64_t start = t.s0 + (uint64_t)t.tl * TILE_E;
         const uint32_t cnt = (uint32_t)(t.s1 - start < TILE_E ? t.s1 - start : TILE_E);
@@ -1404,10 +1528,12 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_count_kernel(KCTX SegDesc sd, const uint
         }
         const bool lds = bp.B <= BUCKET_LDS;
         const uint64_t w0 = text_win_base<BITS>(text_base + start);
+        RUNS_TILE_SETUP
         PAR(tid) {
             if (lds) for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM) hist[i] = 0;
             if (FROM_TEXT)
                 for (uint32_t i = tid; i < TEXT_WIN; i += K_BLOCK_DIM) twin[i] = w0 + i < n_words ? P[w0 + i] : 0u;
+            if (FROM_RUNS) { RUNS_STAGE(tid) }
         }
         SYNC();
         PAR(tid) {
@@ -1416,6 +1542,8 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_count_kernel(KCTX SegDesc sd, const uint
                 const uint32_t e = tid + k * TILE_NT;
                 if (e < cnt) {
                     const uint64_t key = FROM_TEXT ? window64<BITS>(twin, text_base + start + e - w0 * TextTraits<BITS>::CPW)
+                                       : FROM_RUNS ? in_key[run_source<idx_t>(rsrc, runs_staged, lrow, lsrc, run_ns, run_rowR, run_rowA,
+                                                                              run_a, run_b, run_x0 + e)]
                                                    : in_key[start + e];
                     const uint32_t bk = bucket_of(bp, key);
                     if (lds) FETCH_ADD_U32(&hist[bk], 1u);
@@ -1439,17 +1567,30 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_count_kernel(KCTX SegDesc sd, const uint
 // cursor bump per (tile, non-empty bucket); the tile is then re-ordered by bucket in LDS so
 // that consecutive lanes write consecutive slots (a bucket receives a run of consecutive
 // elements from every tile instead of 64 scattered 8-byte stores per wave instruction).
-template <typename idx_t, int BITS, bool FROM_TEXT>
+template <typename idx_t, int BITS, int SRC>
 GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n_words,
                                                        uint64_t text_base, const uint64_t* __restrict__ in_key,
-                                                       const idx_t* __restrict__ in_sa,
+                                                       const idx_t* __restrict__ in_sa, RunSrc<idx_t> rsrc,
                                                        const BucketParams* __restrict__ bps, const uint64_t* __restrict__ bstart,
-                                                       const uint64_t* __restrict__ sub_start, idx_t* __restrict__ cursor,
+                                                       const uint64_t* __restrict__ sub_start, uint32_t slot_cap,
+                                                       idx_t* __restrict__ cursor,
                                                        uint64_t* __restrict__ out_key, idx_t* __restrict__ out_sa)
 {
-    const uint32_t b = K_BLOCK_IDX;
-    if (b >= sd.tile_off[sd.G]) return;
-    const uint32_t g = sd.tile_seg[b];
+    // slot_cap != 0 ("speculative" split, no count pass): bucket i of the launch owns the fixed slot
+    // [i * slot_cap, (i + 1) * slot_cap) of the output; cursor[] ends as the exact bucket sizes, and
+    // elements that do not fit their slot are dropped -- the caller sees a size > slot_cap and
+    // redoes the split with the count pass.  slot_cap == 0: bucket i starts at sub_start[i].
+    const bool spec = slot_cap != 0;
+    const idx_t NO_SLOT = (idx_t)~(idx_t)0;
+#if CAPS_SCATTER_SWZ
+    const uint32_t v = (uint32_t)xcd_swizzle(K_BLOCK_IDX, K_GRID_DIM);   // tiles of one segment on one XCD: the partial
+                                                                         // lines of neighbouring runs meet in its L2
+#else
+    const uint32_t v = K_BLOCK_IDX;
+#endif
+    if (v >= sd.tile_off[sd.G]) return;
+    const uint32_t b = v;
+    const uint32_t g = sd.tile_rec[b].g;
     const TileInfo t = tile_info(sd, b);
     const uint64_t start = t.s0 + (uint64_t)t.tl * TILE_E;
     const uint32_t cnt = (uint32_t)(t.s1 - start < TILE_E ? t.s1 - start : TILE_E);
@@ -1466,15 +1607,21 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
     TL_DECL(uint32_t, rb, TILE_EPT);      // bucket
     TL_DECL(idx_t, rr, TILE_EPT);         // rank inside (tile, bucket) or inside the bucket (idx_t: a bucket of a
                                           // degenerate text can hold more than 2^32 suffixes at 64-bit indices)
+    constexpr bool FROM_TEXT = SRC == SRC_TEXT, FROM_RUNS = SRC == SRC_RUNS;
     const bool lds = bp.B > 1 && bp.B <= BUCKET_LDS;
-    // FROM_TEXT: the tile's slice of the packed text is staged in the (not yet used) key staging array
+    // FROM_TEXT: the tile's slice of the packed text is staged in the (not yet used) key staging array;
+    // FROM_RUNS: the runs the tile spans are staged in the (not yet used) key and index staging arrays
     uint32_t* twin = reinterpret_cast<uint32_t*>(skey);
+    uint64_t* lsrc = skey;
+    idx_t* lrow = ssa;
     const uint64_t w0 = text_win_base<BITS>(text_base + start);
-    if (lds || FROM_TEXT) {
+    RUNS_TILE_SETUP
+    if (lds || FROM_TEXT || FROM_RUNS) {
         PAR(tid) {
             if (lds) for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0;
             if (FROM_TEXT)
                 for (uint32_t i = tid; i < TEXT_WIN; i += K_BLOCK_DIM) twin[i] = w0 + i < n_words ? P[w0 + i] : 0u;
+            if (FROM_RUNS) { RUNS_STAGE(tid) }
         }
         SYNC();
     }
@@ -1483,9 +1630,12 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
         for (uint32_t k = 0; k < TILE_EPT; ++k) {
             const uint32_t e = tid + k * TILE_NT;
             if (e < cnt) {
+                const uint64_t src = FROM_RUNS ? run_source<idx_t>(rsrc, runs_staged, lrow, lsrc, run_ns, run_rowR, run_rowA, run_a,
+                                                                   run_b, run_x0 + e)
+                                               : start + e;
                 const uint64_t key = FROM_TEXT ? window64<BITS>(twin, text_base + start + e - w0 * TextTraits<BITS>::CPW)
-                                               : in_key[start + e];
-                const idx_t sa = FROM_TEXT ? (idx_t)(text_base + start + e) : in_sa[start + e];
+                                               : in_key[src];
+                const idx_t sa = FROM_TEXT ? (idx_t)(text_base + start + e) : in_sa[src];
                 uint32_t bk = 0;
                 idx_t r;
                 if (bp.B == 1) r = e;                                        // identity: the segment is its own bucket
@@ -1507,11 +1657,16 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
                 const uint32_t e = tid + k * TILE_NT;
                 if (e < cnt) {
                     // one bucket: slot = same offset inside the segment (64-bit: such a segment can be long)
-                    const uint64_t dst = sub_start[b0 + TL(rb, tid, k)] + (bp.B == 1 ? (start - t.s0) : 0) + TL(rr, tid, k);
-                    out_key[dst] = TL(rk, tid, k);
-                    out_sa[dst] = TL(rs, tid, k);
+                    const uint64_t off = (bp.B == 1 ? (start - t.s0) : 0) + TL(rr, tid, k);
+                    const uint64_t bi = b0 + TL(rb, tid, k);
+                    if (!spec || off < slot_cap) {
+                        const uint64_t dst = (spec ? bi * slot_cap : sub_start[bi]) + off;
+                        out_key[dst] = TL(rk, tid, k);
+                        out_sa[dst] = TL(rs, tid, k);
+                    }
                 }
             }
+            if (spec && bp.B == 1 && tid == 0) caps_fetch_add(&cursor[b0], (idx_t)cnt);    // the size of a one-bucket segment
         }
         return;
     }
@@ -1519,13 +1674,18 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
     PAR(tid) {                                             // one global cursor bump per (tile, non-empty bucket)
         for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM) {
             const uint32_t c = hist[i];
-            obase[i] = c ? (idx_t)(sub_start[b0 + i] + caps_fetch_add(&cursor[b0 + i], (idx_t)c)) : (idx_t)0;
+            idx_t ob = 0;
+            if (c) {
+                const idx_t old = caps_fetch_add(&cursor[b0 + i], (idx_t)c);
+                if (!spec) ob = (idx_t)(sub_start[b0 + i] + old);
+                else ob = (uint64_t)old + c <= slot_cap ? (idx_t)((b0 + i) * slot_cap + old) : NO_SLOT;
+            }
+            obase[i] = ob;
         }
     }
     SYNC();
     block_exclusive_scan_bins(KCTX_PASS hist);             // hist[i] = position of bucket i inside the re-ordered tile
     PAR(tid) {
-        for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM) obase[i] = (idx_t)(obase[i] - hist[i]);
         UNROLL
         for (uint32_t k = 0; k < TILE_EPT; ++k) {
             const uint32_t e = tid + k * TILE_NT;
@@ -1544,11 +1704,25 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
         for (uint32_t k = 0; k < TILE_EPT; ++k) {
             const uint32_t q = tid + k * TILE_NT;
             if (q < cnt) {
-                const uint64_t dst = (uint64_t)(idx_t)(obase[sbk[q]] + (idx_t)q);
-                out_key[dst] = skey[q];
-                out_sa[dst] = ssa[q];
+                const uint32_t bk = sbk[q];
+                const idx_t ob = obase[bk];
+                if (ob != NO_SLOT) {
+                    const uint64_t dst = (uint64_t)ob + (q - hist[bk]);
+                    out_key[dst] = skey[q];
+                    out_sa[dst] = ssa[q];
+                }
             }
         }
+    }
+}
+
+// Bucket sizes of a speculative split: cursor (idx_t) -> count (u64), the input of the scan.
+template <typename idx_t>
+GLOBAL_FN LAUNCH_BOUNDS(256) widen_kernel(KCTX const idx_t* __restrict__ in, uint64_t cnt, uint64_t* __restrict__ out)
+{
+    PAR(tid) {
+        const uint64_t i = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (i < cnt) out[i] = (uint64_t)in[i];
     }
 }
 
@@ -1610,16 +1784,6 @@ GLOBAL_FN LAUNCH_BOUNDS(256) pick_pivots_kernel(KCTX const uint64_t* __restrict_
             psa[j] = ssa[at];
         }
     }
-}
-
-// Maps a launch-order block id to a logical block id such that the blocks that share
-// an XCD (b % 8, MI355X_MICROARCH "Workgroup dispatch") work on a contiguous range of
-// logical blocks: consecutive logical blocks -- here the searches over one subarray --
-// then hit the same 4 MiB L2.  Speed only; any placement is correct.
-DEV_INLINE uint64_t xcd_swizzle(uint64_t b, uint64_t nb)
-{
-    const uint64_t q = nb / 8, r = nb % 8, x = b % 8, y = b / 8;
-    return x * q + (x < r ? x : r) + y;
 }
 
 // ----------------------------------------------------------------------------------
@@ -1738,7 +1902,7 @@ GLOBAL_FN LAUNCH_BOUNDS(256) collate_plan_kernel(KCTX SegDesc sd, uint32_t p, co
     PAR(tid) {
         const uint64_t b = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
         if (b < sd.tile_off[sd.G]) {
-            const uint32_t g = sd.tile_seg[b];
+            const uint32_t g = sd.tile_rec[b].g;
             const TileInfo t = tile_info(sd, (uint32_t)b);
             first_part[b] = partition_of<idx_t>(Pm + (uint64_t)g * (p + 1), p, (uint64_t)t.tl * TILE_E);
         }
@@ -1752,9 +1916,13 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) collate_kernel(KCTX SegDesc sd, uint32_t p, con
                                                 const uint64_t* __restrict__ in_key, const idx_t* __restrict__ in_sa,
                                                 uint64_t* __restrict__ out_key, idx_t* __restrict__ out_sa)
 {
+#if CAPS_COLLATE_SWZ
+    const uint32_t b = (uint32_t)xcd_swizzle(K_BLOCK_IDX, K_GRID_DIM);
+#else
     const uint32_t b = K_BLOCK_IDX;
+#endif
     if (b >= sd.tile_off[sd.G]) return;
-    const uint32_t g = sd.tile_seg[b];
+    const uint32_t g = sd.tile_rec[b].g;
     const TileInfo t = tile_info(sd, b);
     const uint64_t x0 = (uint64_t)t.tl * TILE_E;                  // index of the tile's first element in the subarray
     const uint64_t start = t.s0 + x0;

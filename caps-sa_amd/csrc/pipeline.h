@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstdio>
+#include <limits>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -36,6 +37,8 @@ template <typename idx_t> struct ElemBuf {
     uint64_t* key = nullptr;
     idx_t* sa = nullptr;
     idx_t* lcp = nullptr;
+    size_t region_bytes = 0;      // != 0: key | sa | lcp are one contiguous allocation of this many bytes starting at key
+                                  // (it can then be viewed as a slot buffer of a speculative bucket split)
 };
 
 // Bump allocator over one device allocation (or a dry run that only measures).
@@ -54,10 +57,10 @@ struct Arena {
 struct SegBufs {
     uint64_t* seg_start = nullptr;   // [G+1]
     uint32_t* tile_off = nullptr;    // [G+1]
-    uint32_t* tile_seg = nullptr;    // [tile capacity]
+    TileInfo* tile_rec = nullptr;    // [tile capacity]
     uint64_t* out2 = nullptr;        // [2] = {#tiles, max segment length}
     uint32_t G = 0;
-    SegDesc desc() const { return SegDesc{seg_start, tile_off, tile_seg, G}; }
+    SegDesc desc() const { return SegDesc{seg_start, tile_off, tile_rec, G}; }
 };
 
 constexpr uint32_t kMaxPasses = 96;
@@ -91,6 +94,8 @@ template <typename idx_t> struct Plan {
     idx_t* psa = nullptr;
     idx_t* Pm = nullptr;
     idx_t* ruler = nullptr;
+    idx_t* PmT = nullptr;            // transposes (phase 2 reads partitions through them)
+    idx_t* rulerT = nullptr;
     uint64_t* sizes = nullptr;
     uint64_t* partial = nullptr;     // [PART_CHUNKS * p] partial column sums of Pm
     SegBufs seg1, seg2, segS;
@@ -133,14 +138,16 @@ Plan<idx_t> make_plan(uint64_t n, uint64_t p_arg, char* base)
     pl.P = ar.take<uint32_t>(packed_words(nn, 8));
     for (ElemBuf<idx_t>* b : {&pl.A, &pl.B}) {
         b->key = ar.take<uint64_t>(nn);
+        const size_t at = ar.off - nn * sizeof(uint64_t);
         b->sa = ar.take<idx_t>(nn);
         b->lcp = ar.take<idx_t>(nn);
+        b->region_bytes = ar.off - at;
     }
     auto segs = [&](SegBufs& s, uint32_t G, uint64_t cap) {
         s.G = G;
         s.seg_start = ar.take<uint64_t>((size_t)G + 1);
         s.tile_off = ar.take<uint32_t>((size_t)G + 1);
-        s.tile_seg = ar.take<uint32_t>(cap);
+        s.tile_rec = ar.take<TileInfo>(cap);
         s.out2 = ar.take<uint64_t>(2);
     };
     segs(pl.seg1, p, pl.tile_cap);
@@ -154,6 +161,8 @@ Plan<idx_t> make_plan(uint64_t n, uint64_t p_arg, char* base)
         pl.psa = ar.take<idx_t>(p);
         pl.Pm = ar.take<idx_t>((size_t)p * (p + 1));
         pl.ruler = ar.take<idx_t>((size_t)p * p);
+        pl.PmT = ar.take<idx_t>((size_t)p * (p + 1));
+        pl.rulerT = ar.take<idx_t>((size_t)p * p);
         pl.sizes = ar.take<uint64_t>(p);
         pl.partial = ar.take<uint64_t>((size_t)PART_CHUNKS * p);
         segs(pl.seg2, p, pl.tile_cap);
@@ -260,7 +269,7 @@ inline void prepare_segments(Backend& be, const SegBufs& s, uint64_t tile_bound,
         CAPS_LAUNCH(tile_total_kernel, 1, 64, be, (const uint32_t*)s.tile_off, s.G, s.out2);
     }
     const uint32_t grid = (uint32_t)((tile_bound + 255) / 256);
-    CAPS_LAUNCH(tile_map_kernel, grid ? grid : 1, 256, be, (const uint32_t*)s.tile_off, s.G, s.tile_seg);
+    CAPS_LAUNCH(tile_map_kernel, grid ? grid : 1, 256, be, (const uint64_t*)s.seg_start, (const uint32_t*)s.tile_off, s.G, s.tile_rec);
 }
 
 inline uint32_t tiles_of(uint64_t len) { return (uint32_t)((len + TILE_E - 1) / TILE_E); }
@@ -294,6 +303,10 @@ struct SortOpts {
     uint32_t range_mode = 0;      // bucket_plan_kernel: 0 full key range, 1 between pivots
     const uint64_t* pkey = nullptr;
     uint32_t part_off = 0, part_total = 0;    // range_mode 1: segment g = partition part_off + g of part_total
+    bool speculate = false;       // try the bucket split without its count pass first (slots carved from `oth`)
+    uint32_t* slot_stats = nullptr;   // [2] host counters: splits done with slots / redone with the count pass
+    const void* runs = nullptr;   // RunSrc<idx_t>*: the segments are partitions still spread over the sorted subarrays in
+                                  //   `cur` (requires the bucket split: bk != null and max_len > TILE_E)
     bool unify = false;           // gather the result into buf[0] (consumers that index whole segments)
     void* final_sa = nullptr;     // non-null (with need_lcp): completed segments are written straight to the
     void* final_lcp = nullptr;    //   caller's SA / LCP arrays; boundary records in `bnd` (6 arrays of G entries)
@@ -327,6 +340,9 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
     const uint64_t *range_lo = nullptr, *range_hi = nullptr;      // key ranges of the sorted segments, if bucketed
     SegBufs segs = s;
     bool skip = o.skip_finished;
+    uint32_t slot_cap = 0;                           // != 0: the tile sort's input sits in fixed-capacity slots
+    uint64_t* slot_key = nullptr;
+    idx_t* slot_sa = nullptr;
     if (o.bk && max_len > TILE_E) {
         const BucketBufs& bk = *o.bk;
         const SegDesc psd = s.desc();
@@ -340,48 +356,88 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         range_lo = bk.range_lo;
         range_hi = bk.range_hi;
         mark("bucket plan");
-        be.memset(bk.count, 0, (size_t)bk.nb_cap * sizeof(uint64_t));
-        be.memset(bk.cursor, 0, (size_t)bk.nb_cap * sizeof(idx_t));
-        ElemBuf<idx_t> dst = from_text ? cur : oth;
         const uint32_t pgrid = n_tiles < be.persistent_blocks() ? n_tiles : be.persistent_blocks();
-        if (from_text) {
-            BackendEvent c0 = be.record();
-            CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, true>), pgrid, TILE_NT, be, psd, P, packed_words(n, BITS), o.text_base, (const uint64_t*)nullptr,
-                        (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, bk.count);
-            BackendEvent c1 = be.record();
-            device_exclusive_scan<uint64_t>(be, bk.count, bk.nb_cap, bk.sub.seg_start, bk.scan_tmp);
+        const bool runs = o.runs != nullptr;             // phase 2 reading the sorted subarrays through the partition matrix
+        const RunSrc<idx_t> rsrc = runs ? *static_cast<const RunSrc<idx_t>*>(o.runs) : RunSrc<idx_t>();
+        const uint64_t n_words = from_text ? packed_words(n, BITS) : 0;
+        const uint64_t tbase = from_text ? o.text_base : 0;
+        auto scatter = [&](const uint64_t* sub_start, uint32_t cap, uint64_t* okey, idx_t* osa) {
             BackendEvent s0 = be.record();
-            CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, psd, P, packed_words(n, BITS), o.text_base, (const uint64_t*)nullptr,
-                        (const idx_t*)nullptr, (const BucketParams*)bk.params, (const uint64_t*)bk.bstart,
-                        (const uint64_t*)bk.sub.seg_start, static_cast<idx_t*>(bk.cursor), dst.key, dst.sa);
+            if (from_text)
+                CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, SRC_TEXT>), n_tiles, TILE_NT, be, psd, P, n_words, tbase, (const uint64_t*)nullptr,
+                            (const idx_t*)nullptr, rsrc, (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, sub_start, cap,
+                            static_cast<idx_t*>(bk.cursor), okey, osa);
+            else if (runs)
+                CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, SRC_RUNS>), n_tiles, TILE_NT, be, psd, P, n_words, tbase, (const uint64_t*)cur.key,
+                            (const idx_t*)cur.sa, rsrc, (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, sub_start, cap,
+                            static_cast<idx_t*>(bk.cursor), okey, osa);
+            else
+                CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, SRC_ARRAYS>), n_tiles, TILE_NT, be, psd, P, n_words, tbase, (const uint64_t*)cur.key,
+                            (const idx_t*)cur.sa, rsrc, (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, sub_start, cap,
+                            static_cast<idx_t*>(bk.cursor), okey, osa);
             BackendEvent s1 = be.record();
-            if (o.count_clock) { o.count_clock->spans.push_back({c0, c1}); o.count_clock->elems.push_back(n_elems); }
             if (o.scatter_clock) { o.scatter_clock->spans.push_back({s0, s1}); o.scatter_clock->elems.push_back(n_elems); }
+        };
+        // the buckets become the segments (trailing unused ones are empty): sizes -> offsets -> tiles
+        uint64_t out2[2] = {0, 0};
+        auto adopt_buckets = [&]() {
+            device_exclusive_scan<uint64_t>(be, bk.count, bk.nb_cap, bk.sub.seg_start, bk.scan_tmp);
+        };
+        auto bucket_tiles = [&]() {
+            segs = bk.sub;
+            segs.G = bk.nb_cap;
+            prepare_segments(be, segs, bk.tile_cap, bk.scan_tmp, bk.count);    // count[] is free again: reuse as scratch
+            be.d2h(out2, segs.out2, sizeof out2);
+            be.sync();
+        };
+        // ---- speculative split: no count pass.  Bucket i gets the fixed slot [i * TILE_E, (i + 1) * TILE_E) of a
+        // slot buffer viewed over `oth`; the scatter's cursors end as the exact bucket sizes.  If every bucket fits
+        // its slot (keys roughly uniform inside their ranges: random DNA) the tile sort reads the slots and writes
+        // the buckets compactly into `cur`; otherwise the split is redone below with the count pass.
+        const uint64_t slot_elems = (uint64_t)bk.nb_cap * TILE_E;
+        bool slots = false;
+        if (o.speculate && oth.region_bytes >= slot_elems * (sizeof(uint64_t) + sizeof(idx_t)) &&
+            slot_elems + TILE_E < (uint64_t)std::numeric_limits<idx_t>::max()) {
+            slot_key = oth.key;
+            slot_sa = reinterpret_cast<idx_t*>(reinterpret_cast<char*>(oth.key) + slot_elems * sizeof(uint64_t));
+            be.memset(bk.cursor, 0, (size_t)bk.nb_cap * sizeof(idx_t));
+            scatter(nullptr, TILE_E, slot_key, slot_sa);
+            CAPS_LAUNCH((widen_kernel<idx_t>), (bk.nb_cap + 255) / 256, 256, be, (const idx_t*)static_cast<idx_t*>(bk.cursor),
+                        (uint64_t)bk.nb_cap, bk.count);
+            adopt_buckets();
+            bucket_tiles();
+            slots = out2[1] <= TILE_E;
+            if (o.slot_stats) ++o.slot_stats[slots ? 0 : 1];
+            if (dbg) std::fprintf(stderr, "[sort] slot split: largest bucket %llu -> %s\n", (unsigned long long)out2[1], slots ? "kept" : "redone");
+        }
+        if (!slots) {
+            be.memset(bk.count, 0, (size_t)bk.nb_cap * sizeof(uint64_t));
+            be.memset(bk.cursor, 0, (size_t)bk.nb_cap * sizeof(idx_t));
+            BackendEvent c0 = be.record();
+            if (from_text)
+                CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, SRC_TEXT>), pgrid, TILE_NT, be, psd, P, n_words, tbase, (const uint64_t*)nullptr, rsrc,
+                            (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, bk.count);
+            else if (runs)
+                CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, SRC_RUNS>), pgrid, TILE_NT, be, psd, P, n_words, tbase, (const uint64_t*)cur.key, rsrc,
+                            (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, bk.count);
+            else
+                CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, SRC_ARRAYS>), pgrid, TILE_NT, be, psd, P, n_words, tbase, (const uint64_t*)cur.key, rsrc,
+                            (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, bk.count);
+            BackendEvent c1 = be.record();
+            if (o.count_clock) { o.count_clock->spans.push_back({c0, c1}); o.count_clock->elems.push_back(n_elems); }
+            adopt_buckets();
+            ElemBuf<idx_t> dst = from_text ? cur : oth;
+            scatter((const uint64_t*)bk.sub.seg_start, 0u, dst.key, dst.sa);
+            if (!from_text) {
+                std::swap(cur, oth);                     // the scattered copy is the working buffer now
+                r.buf[0] = cur;
+                r.buf[1] = oth;
+            }
+            bucket_tiles();
         } else {
-            BackendEvent c0 = be.record();
-            CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, false>), pgrid, TILE_NT, be, psd, P, (uint64_t)0, (uint64_t)0, (const uint64_t*)cur.key,
-                        (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, bk.count);
-            BackendEvent c1 = be.record();
-            device_exclusive_scan<uint64_t>(be, bk.count, bk.nb_cap, bk.sub.seg_start, bk.scan_tmp);
-            BackendEvent s0 = be.record();
-            CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, psd, P, (uint64_t)0, (uint64_t)0, (const uint64_t*)cur.key,
-                        (const idx_t*)cur.sa, (const BucketParams*)bk.params, (const uint64_t*)bk.bstart,
-                        (const uint64_t*)bk.sub.seg_start, static_cast<idx_t*>(bk.cursor), dst.key, dst.sa);
-            BackendEvent s1 = be.record();
-            if (o.count_clock) { o.count_clock->spans.push_back({c0, c1}); o.count_clock->elems.push_back(n_elems); }
-            if (o.scatter_clock) { o.scatter_clock->spans.push_back({s0, s1}); o.scatter_clock->elems.push_back(n_elems); }
-            std::swap(cur, oth);                         // the scattered copy is the working buffer now
-            r.buf[0] = cur;
-            r.buf[1] = oth;
+            slot_cap = TILE_E;                           // the tile sort reads the slots, writes `cur`
         }
         mark("bucket scatter");
-        // the buckets are the segments from here on (trailing unused ones are empty)
-        segs = bk.sub;
-        segs.G = bk.nb_cap;
-        prepare_segments(be, segs, bk.tile_cap, bk.scan_tmp, bk.count);    // count[] is free again: reuse as scratch
-        uint64_t out2[2];
-        be.d2h(out2, segs.out2, sizeof out2);
-        be.sync();
         n_tiles = (uint32_t)out2[0];
         max_len = out2[1];
         if (dbg) std::fprintf(stderr, "[sort] buckets: tiles %u max_len %llu\n", n_tiles, (unsigned long long)max_len);
@@ -408,18 +464,19 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
     be.memset(redo, 0, sizeof(uint32_t));
     const uint32_t ggrid = n_tiles < 4 * be.persistent_blocks() ? n_tiles : 4 * be.persistent_blocks();
     BackendEvent t0 = be.record();
-    if (from_text)
-        CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, sd, P, n, o.text_base, lcp_mode,
+    const uint64_t* in_key = slot_cap ? slot_key : cur.key;
+    const idx_t* in_sa = slot_cap ? slot_sa : cur.sa;
+    if (from_text) {
+        CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, sd, P, n, o.text_base, lcp_mode, 0u,
                     (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, range_lo, range_hi, redo);
-    if (from_text)
-        CAPS_LAUNCH((tile_sort_general_kernel<idx_t, BITS, true>), ggrid, TILE_NT, be, sd, P, n, o.text_base, lcp_mode,
+        CAPS_LAUNCH((tile_sort_general_kernel<idx_t, BITS, true>), ggrid, TILE_NT, be, sd, P, n, o.text_base, lcp_mode, 0u,
                     (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo);
-    else
-        CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode,
-                    (const uint64_t*)cur.key, (const idx_t*)cur.sa, cur.key, cur.sa, cur.lcp, fin, range_lo, range_hi, redo);
-    if (!from_text)
-        CAPS_LAUNCH((tile_sort_general_kernel<idx_t, BITS, false>), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode,
-                    (const uint64_t*)cur.key, (const idx_t*)cur.sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo);
+    } else {
+        CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
+                    in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, range_lo, range_hi, redo);
+        CAPS_LAUNCH((tile_sort_general_kernel<idx_t, BITS, false>), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
+                    in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo);
+    }
     BackendEvent t1 = be.record();
     mark("tile sort");
     if (o.tile_clock) { o.tile_clock->spans.push_back({t0, t1}); o.tile_clock->elems.push_back(n_elems); }
@@ -492,6 +549,7 @@ private:
     KernelClock count_clock_;
     KernelClock collate_clock_;
     uint32_t pass_base_ = 0;
+    uint32_t slot_stats_[2] = {0, 0};
 
     // timed: the full-size sorts (phase 1, phase 2) feed the kernel clocks of caps_sa_stats;
     // their passes count the elements they really move in pl_.pass_elems[pass_base_ ...]
@@ -505,6 +563,8 @@ private:
             o.scatter_clock = &scatter_clock_;
             o.count_clock = &count_clock_;
             o.pass_counters = pl_.pass_elems + pass_base_;
+            o.slot_stats = slot_stats_;
+            o.speculate = std::getenv("CAPS_SA_NO_SLOTS") == nullptr;      // debugging switch: always take the count pass
         }
         SortResult<idx_t> r = segmented_sort<idx_t, BITS>(be_, pl_.P, pl_.n, pl_.desc, s, n_tiles, max_len, cur, oth, n_elems, o);
         if (timed) pass_base_ += r.passes;
@@ -593,19 +653,42 @@ private:
             prepare_segments(pl_.seg2, n / TILE_E + p + 1);
             uint64_t out2[2];
             be_.d2h(out2, pl_.seg2.out2, sizeof out2);
-            uint32_t* first_part = reinterpret_cast<uint32_t*>(pl_.desc);      // [n_tiles1], the tile descriptors are idle here
-            BackendEvent k0 = be_.record();
-            CAPS_LAUNCH((collate_plan_kernel<idx_t>), (n_tiles1 + 255) / 256, 256, be_, pl_.seg1.desc(), p, (const idx_t*)pl_.Pm,
-                        first_part);
-            CAPS_LAUNCH((collate_kernel<idx_t>), n_tiles1, TILE_NT, be_, pl_.seg1.desc(), p, (const idx_t*)pl_.Pm,
-                        (const idx_t*)pl_.ruler, (const uint64_t*)pl_.seg2.seg_start, (const uint32_t*)first_part,
-                        (const uint64_t*)cur.key, (const idx_t*)cur.sa, oth.key, oth.sa);
-            BackendEvent k1 = be_.record();
-            collate_clock_.spans.push_back({k0, k1});
-            collate_clock_.elems.push_back(n);
             be_.sync();                                   // out2 = {#tiles, largest partition}
             const uint32_t n_tiles2 = (uint32_t)out2[0];
             max_part = out2[1];
+            // A partition longer than a tile is bucketed by key range before its tile sort; that
+            // bucket split can read the partition straight from the sorted subarrays (through the
+            // transposed partition matrix): no separate collate pass.  Otherwise (tiny inputs):
+            // collate as the reference does (cpp:343-358), then tile-sort the partitions.
+            const bool fused = max_part > TILE_E;
+            uint32_t* tile_plan = reinterpret_cast<uint32_t*>(pl_.desc);      // the tile descriptors are idle here
+            RunSrc<idx_t> rsrc;
+            ElemBuf<idx_t> in2 = cur, out2buf = oth;
+            if (fused) {
+                CAPS_LAUNCH((transpose_kernel<idx_t>), ((p + 31) / 32) * ((p + 1 + 31) / 32), 256, be_, (const idx_t*)pl_.Pm, p, p + 1,
+                            pl_.PmT);
+                CAPS_LAUNCH((transpose_kernel<idx_t>), ((p + 31) / 32) * ((p + 31) / 32), 256, be_, (const idx_t*)pl_.ruler, p, p,
+                            pl_.rulerT);
+                CAPS_LAUNCH((runs_plan_kernel<idx_t>), (n_tiles2 + 255) / 256, 256, be_, pl_.seg2.desc(), (const idx_t*)pl_.rulerT, p,
+                            tile_plan);
+                rsrc.PmT = pl_.PmT;
+                rsrc.rulerT = pl_.rulerT;
+                rsrc.sub_start = pl_.seg1.seg_start;
+                rsrc.first_run = tile_plan;
+                rsrc.G1 = p;
+            } else {
+                BackendEvent k0 = be_.record();
+                CAPS_LAUNCH((collate_plan_kernel<idx_t>), (n_tiles1 + 255) / 256, 256, be_, pl_.seg1.desc(), p, (const idx_t*)pl_.Pm,
+                            tile_plan);
+                CAPS_LAUNCH((collate_kernel<idx_t>), n_tiles1, TILE_NT, be_, pl_.seg1.desc(), p, (const idx_t*)pl_.Pm,
+                            (const idx_t*)pl_.ruler, (const uint64_t*)pl_.seg2.seg_start, (const uint32_t*)tile_plan,
+                            (const uint64_t*)cur.key, (const idx_t*)cur.sa, oth.key, oth.sa);
+                BackendEvent k1 = be_.record();
+                collate_clock_.spans.push_back({k0, k1});
+                collate_clock_.elems.push_back(n);
+                in2 = oth;
+                out2buf = cur;
+            }
             e5 = be_.record();
 
             // ---- phase 2 (a10): sort every partition; a partition's last step emits its LCPs
@@ -615,8 +698,9 @@ private:
             o2.bk = &pl_.bk;                    // partition j holds keys in [pivot j-1, pivot j]
             o2.range_mode = 1;
             o2.pkey = pl_.pkey;
+            if (fused) o2.runs = &rsrc;
             set_final(o2, dSA, dLCP);
-            SortResult<idx_t> r2 = seg_sort<BITS>(pl_.seg2, n_tiles2, max_part, oth, cur, n, o2, true);
+            SortResult<idx_t> r2 = seg_sort<BITS>(pl_.seg2, n_tiles2, max_part, in2, out2buf, n, o2, true);
             passes2 = r2.passes;
             e6 = be_.record();
 
@@ -659,6 +743,8 @@ private:
             sum(scatter_clock_, &st->bucket_scatter_ms, &st->bucket_scatter_launches, &st->bucket_scatter_elems);
             sum(count_clock_, &st->bucket_count_ms, &dummy_l, &dummy_e);
             sum(collate_clock_, &st->collate_ms, &dummy_l, &dummy_e);
+            st->slot_splits = slot_stats_[0];
+            st->slot_splits_redone = slot_stats_[1];
             st->merge_pass_elems = 0;                      // elements the timed passes really merged
             for (uint32_t i = 0; i < pass_base_ && i < kMaxPasses; ++i) st->merge_pass_elems += pass_elems[i];
         }

@@ -335,7 +335,7 @@ private:
         s.G = G;
         s.seg_start = get<uint64_t>((size_t)G + 1);
         s.tile_off = get<uint32_t>((size_t)G + 1);
-        s.tile_seg = get<uint32_t>(cap);
+        s.tile_rec = get<TileInfo>(cap);
         s.out2 = get<uint64_t>(2);
         return s;
     }

@@ -63,6 +63,8 @@ typedef struct caps_sa_stats {
     double bucket_scatter_ms; uint64_t bucket_scatter_launches; uint64_t bucket_scatter_elems;
     double bucket_count_ms;
     double collate_ms;
+    /* bucket splits done without a count pass (fixed-capacity slots) / splits that had to be redone with one */
+    uint32_t slot_splits, slot_splits_redone;
 } caps_sa_stats;
 
 int caps_sa_hip_device_count(void);

@@ -17,3 +17,18 @@ def emul():
         import caps_sa_amd
         _emul = caps_sa_amd.CapsLib(os.path.join(EMUL_DIR, "libcaps_sa_emul.so"), "caps_sa_emul_")
     return _emul
+
+
+_small = None
+
+
+def emul_small():
+    """The same kernel sources compiled with 256-element tiles (64-thread workgroups)."""
+    global _small
+    if _small is None:
+        subprocess.check_call(["make", "-s", "-C", EMUL_DIR, "libcaps_sa_emul_small.so"])
+        if ROOT not in sys.path:
+            sys.path.insert(0, ROOT)
+        import caps_sa_amd
+        _small = caps_sa_amd.CapsLib(os.path.join(EMUL_DIR, "libcaps_sa_emul_small.so"), "caps_sa_emul_")
+    return _small

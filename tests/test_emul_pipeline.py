@@ -145,3 +145,52 @@ def test_uniform_keys_take_the_bucket_sort_fast_path(oracle):
     assert st["merge_passes_phase1"] == 0 and st["merge_passes_phase2"] == 0
     SAo, LCPo = oracle.build_sa_lcp(T, p=20)
     assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo)
+
+
+# ---- the same kernel sources with 256-element tiles: many tiles, merge passes, partitions that
+# ---- span hundreds of runs, at sizes the naive oracle still checks in a blink
+def _skewed(rs, n):
+    """Markov-ish DNA with long poly-A stretches and a planted repeat: leaves every interpolation fast path."""
+    T = rs.choice(DNA, size=n, p=[0.55, 0.15, 0.15, 0.15])
+    T[n // 3:n // 3 + n // 20] = ord("A")
+    rep = T[100:100 + n // 10].copy()
+    T[n // 2:n // 2 + rep.size] = rep
+    return T
+
+
+@pytest.mark.parametrize("n,p", [(5000, 3), (40000, 300), (60000, 7), (200000, 400), (400000, 1000), (30011, 0), (257, 2),
+                                 (256 * 9 + 1, 9)])
+def test_small_tiles_random_dna(oracle, n, p):
+    from emul_util import emul_small
+    rs = np.random.RandomState(n % 97 + p)
+    T = rs.choice(DNA, size=n)
+    SA, LCP, st = emul_small().build(T, p=p)
+    SAo, LCPo = oracle.build_sa_lcp(T, p=p)[:2]
+    assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo)
+
+
+@pytest.mark.parametrize("n,p", [(20000, 5), (50000, 64), (120000, 300), (90000, 1200)])
+def test_small_tiles_skewed_and_repetitive(oracle, n, p):
+    from emul_util import emul_small
+    rs = np.random.RandomState(n % 89 + p)
+    E = emul_small()
+    for T in (_skewed(rs, n), np.tile(rs.choice(DNA, size=61), n // 61 + 1)[:n],
+              rs.choice(np.frombuffer(b"abcdefgh\x80\xff", dtype=np.uint8), size=n, p=[0.4] + [0.6 / 9] * 9)):
+        SA, LCP, st = E.build(T, p=p)
+        SAo, LCPo = oracle.build_sa_lcp(T, p=p)[:2]
+        assert np.array_equal(SA, SAo), (n, p)
+        assert np.array_equal(LCP, LCPo), (n, p)
+
+
+def test_small_tiles_u64_and_segments(oracle):
+    from emul_util import emul_small
+    rs = np.random.RandomState(77)
+    E = emul_small()
+    T = _skewed(rs, 70000)
+    SA, LCP, _ = E.build(T, p=333, idx_bits=64)
+    SAo, LCPo = oracle.build_sa_lcp(T, p=333, idx_bits=64)[:2]
+    assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo)
+    lens = [300, 0, 1, 256, 257, 0, 512, 513, 768, 3, 1280, 1281, 2048, 100, 0, 1025, 7, 5000]
+    seg = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    idx = rs.permutation(70000)[:int(seg[-1])].astype(np.uint32)
+    _check_segments(E, oracle, T, idx, seg)
