@@ -57,6 +57,7 @@ static inline uint64_t caps_fetch_add_u64(uint64_t* p, uint64_t v) { const uint6
 static inline uint32_t caps_fetch_add(uint32_t* p, uint32_t v) { return caps_fetch_add_u32(p, v); }
 static inline uint64_t caps_fetch_add(uint64_t* p, uint64_t v) { return caps_fetch_add_u64(p, v); }
 static inline uint64_t caps_umul64hi(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
+static inline uint32_t caps_umul32hi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 static inline int caps_clz64(uint64_t x) { return __builtin_clzll(x); }
 static inline uint32_t caps_bswap32(uint32_t x) { return __builtin_bswap32(x); }
 #else
@@ -104,6 +105,7 @@ static __device__ __forceinline__ void caps_block_minmax_u64(uint64_t* pmin, uin
 static __device__ __forceinline__ uint32_t caps_fetch_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 static __device__ __forceinline__ uint64_t caps_fetch_add(uint64_t* p, uint64_t v) { return (uint64_t)atomicAdd((unsigned long long*)p, (unsigned long long)v); }
 static __device__ __forceinline__ uint64_t caps_umul64hi(uint64_t a, uint64_t b) { return __umul64hi(a, b); }
+static __device__ __forceinline__ uint32_t caps_umul32hi(uint32_t a, uint32_t b) { return __umulhi(a, b); }
 static __host__ __device__ __forceinline__ int caps_clz64(uint64_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __clzll((long long)x);

@@ -443,31 +443,34 @@ HD uint32_t pow2_above(uint32_t x) { return 1u << (32 - (x ? __builtin_clz(x) : 
 
 struct BucketParams {        // per parent segment
     uint64_t kmin;           // smallest key of the segment's range
-    uint64_t bq;             // bucket = mulhi((key - kmin) << shift, bq) >> post, clamped to B - 1
-    uint32_t shift;
+    uint64_t range;          // largest key - smallest key
+    uint32_t shift;          // normalisation: ((key - kmin) << shift) >> 32 spans [0, R32], R32 in [2^31, 2^32)
     uint32_t B;
-    uint32_t post;
-    uint32_t pad;
+    uint32_t post;           // bucket = mulhi32(d32, m) >> post, clamped to B - 1
+    uint32_t m;
 };
 
-// Monotone linear map of [kmin, kmin + range] onto B buckets: with d_s = (key - kmin) << shift
-// (range normalised to [2^63, 2^64)), bucket = d_s * B / (range_s + 1).  The factor
-// B * 2^64 / (range_s + 1) lies in [B, 2B]; it is kept as a 63-bit fixed-point number
-// (scaled by 2^post) so that bucket boundaries are exact to ~2^-40 of the range.
+// Monotone linear map of [kmin, kmin + range] onto B buckets, in 32-bit arithmetic (the maps run once
+// per suffix in four kernels, and a 64 x 64 -> 128 multiply is ~10 quarter-rate VALU instructions):
+// d32 = the top 32 bits of the difference, range normalised to [2^31, 2^32); bucket = d32 * B / (R32 + 1).
+// The factor B * 2^32 / (R32 + 1) lies in [B, 2B]; it is kept as a 31..32-bit fixed-point number
+// (scaled by 2^post), so bucket boundaries are exact to ~2^-31 of the range -- a multiplier with only
+// log2(B) significant bits shifts the boundaries by up to 1/B of the range, and the key ranges that
+// bucket_ranges_kernel hands to the tile sort no longer match the buckets.
 HD BucketParams make_bucket_params(uint64_t kmin, uint64_t kmax, uint32_t B)
 {
     BucketParams q;
     q.kmin = kmin;
     q.B = B;
-    q.pad = 0;
-    const uint64_t range = kmax > kmin ? kmax - kmin : 0;
-    q.shift = range ? (uint32_t)caps_clz64(range) : 0u;
-    const double rs = (double)(range << q.shift) + 1.0;                 // in [2^63, 2^64]
-    const double f = (double)B * 18446744073709551616.0 / rs;           // in [B, 2B]
+    q.range = kmax > kmin ? kmax - kmin : 0;
+    q.shift = q.range ? (uint32_t)caps_clz64(q.range) : 0u;
+    const uint64_t r32 = (q.range << q.shift) >> 32;                    // in [2^31, 2^32) unless range == 0
     uint32_t bits = 1;
     while ((2ull * B) >> bits) ++bits;                                  // 2B < 2^bits
-    q.post = 63 - bits;
-    q.bq = (uint64_t)(f * (double)(1ull << q.post));
+    q.post = bits < 32 ? 32 - bits : 0;
+    // floor(B * 2^(32 + post) / (r32 + 1)) < 2^32; the numerator is < 2^63 (B < 2^(bits - 1))
+    const uint64_t num = (uint64_t)B << (32 + q.post);
+    q.m = q.range ? (uint32_t)(num / (r32 + 1)) : 0u;
     return q;
 }
 
@@ -476,9 +479,10 @@ DEV_INLINE uint32_t bucket_of(const BucketParams& bp, uint64_t key)
     if (bp.B <= 1) return 0;
     if (key <= bp.kmin) return 0;
     const uint64_t d = key - bp.kmin;
-    if (bp.shift && (d >> (64 - bp.shift))) return bp.B - 1;          // above the nominal range
-    const uint64_t b = caps_umul64hi(d << bp.shift, bp.bq) >> bp.post;
-    return b < bp.B ? (uint32_t)b : bp.B - 1;
+    if (d >= bp.range) return bp.B - 1;                               // at or above the top of the nominal range
+    const uint32_t d32 = (uint32_t)((d << bp.shift) >> 32);
+    const uint32_t b = caps_umul32hi(d32, bp.m) >> bp.post;
+    return b < bp.B ? b : bp.B - 1;
 }
 
 // Exclusive scan of NBINS counters in LDS, in place; h[NBINS] = total.
@@ -597,10 +601,11 @@ constexpr uint32_t TILE_BIN_LIMIT = CAPS_TILE_BIN_LIMIT;
         }                                                                                                       \
     }
 
-// Key range of the tile: known in advance when the tile belongs to a key-range bucket
-// (seg_lo / seg_hi from bucket_ranges_kernel), otherwise min / max over the tile.
+// Bin map of the tile: prepared in advance when the tile belongs to a key-range bucket (seg_map, from
+// bucket_ranges_kernel: its 64-bit division would otherwise be repeated by every thread of every
+// tile), otherwise from the min / max over the tile.
 #define TILE_SORT_RANGE                                                                                         \
-    const bool known_range = seg_lo != nullptr;                                                                 \
+    const bool known_range = seg_map != nullptr;                                                                \
     if (!known_range) {                                                                                         \
         SYNC(); /* kmm initialised */                                                                           \
         PAR(tid) {                                                                                              \
@@ -618,9 +623,7 @@ constexpr uint32_t TILE_BIN_LIMIT = CAPS_TILE_BIN_LIMIT;
         }                                                                                                       \
     }                                                                                                           \
     SYNC();                                                                                                     \
-    const uint64_t tile_kmin = known_range ? seg_lo[g] : kmm[0];                                                \
-    const uint64_t tile_kmax = known_range ? seg_hi[g] : kmm[1];                                                \
-    const BucketParams tb = make_bucket_params(tile_kmin, tile_kmax, TILE_BINS); /* block-uniform */
+    const BucketParams tb = known_range ? seg_map[g] : make_bucket_params(kmm[0], kmm[1], TILE_BINS); /* block-uniform */
 
 // registers -> final slots TL(rd) in LDS
 #define TILE_SORT_PLACE_FINAL                                                                                   \
@@ -674,8 +677,8 @@ template <typename idx_t, int BITS, bool FROM_TEXT>
 GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
                                                   uint64_t text_base, uint32_t lcp_mode, uint32_t slot_cap, const uint64_t* in_key,
                                                   const idx_t* in_sa, uint64_t* out_key, idx_t* out_sa, idx_t* out_lcp,
-                                                  FinalOut<idx_t> fin, const uint64_t* __restrict__ seg_lo,
-                                                  const uint64_t* __restrict__ seg_hi, uint32_t* __restrict__ redo)
+                                                  FinalOut<idx_t> fin, const BucketParams* __restrict__ seg_map,
+                                                  uint32_t* __restrict__ redo)
 {
     TILE_SORT_PROLOGUE
     SHARED_ARRAY(uint64_t, skey, TILE_E);
@@ -690,7 +693,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
 
     TILE_SORT_LOAD
     TILE_SORT_RANGE
-    bool fast = cnt > 1 && tile_kmax > tile_kmin;
+    bool fast = cnt > 1 && tb.range > 0;
     if (fast) {
         PAR(tid) {
             UNROLL
@@ -737,8 +740,11 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
                     const uint64_t key = TL(rk, tid, k);
                     const uint64_t sa = (uint64_t)TL(rs, tid, k);
                     uint32_t less = 0;                        // members of my bin that sort before me
-                    for (uint32_t j = bs; j < be; ++j)
-                        if (j != slot && suffix_less<BITS>(P, n, skey[j], (uint64_t)ssa[j], key, sa)) ++less;
+                    for (uint32_t j = bs; j < be; ++j) {
+                        const uint64_t kj = skey[j];
+                        less += kj < key ? 1u : 0u;
+                        if (kj == key && j != slot && suffix_less_tie<BITS>(P, n, (uint64_t)ssa[j], sa)) ++less;   // rare: text
+                    }
                     TL(rd, tid, k) = bs + less;
                 }
             }
@@ -1455,11 +1461,12 @@ GLOBAL_FN LAUNCH_BOUNDS(256) bucket_plan_kernel(KCTX const uint64_t* __restrict_
 }
 
 // Key range of every bucket (inverse of bucket_of, to within rounding: keys just outside are
-// clamped into the edge bins of the tile sort, which stays correct).  One thread per bucket.
+// clamped into the edge bins of the tile sort, which stays correct), stored as the tile sort's
+// bin map over that range.  One thread per bucket.
 GLOBAL_FN LAUNCH_BOUNDS(256) bucket_ranges_kernel(KCTX const uint64_t* __restrict__ bstart, uint32_t G,
                                                   const BucketParams* __restrict__ bps, const uint64_t* __restrict__ pkey,
                                                   uint32_t range_mode, uint32_t part_off, uint32_t part_total,
-                                                  uint64_t* __restrict__ lo, uint64_t* __restrict__ hi)
+                                                  BucketParams* __restrict__ tile_map)
 {
     PAR(tid) {
         const uint64_t i = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
@@ -1486,8 +1493,7 @@ GLOBAL_FN LAUNCH_BOUNDS(256) bucket_ranges_kernel(KCTX const uint64_t* __restric
                 if (bk + 1 < bp.B) h = kmin + (uint64_t)dh;
                 if (h < l) h = l;
             }
-            lo[i] = l;
-            hi[i] = h;
+            tile_map[i] = make_bucket_params(l, h, TILE_BINS);      // the tile sort's bin map over the bucket's key range
         }
     }
 }

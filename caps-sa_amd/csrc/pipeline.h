@@ -74,7 +74,7 @@ struct BucketBufs {
     void* cursor = nullptr;           // [nb_cap] idx_t
     uint64_t* scan_tmp = nullptr;     // [2 * (nb_cap / SCAN_CHUNK + 2)]
     uint64_t *first_key = nullptr, *last_key = nullptr;   // [nb_cap] boundary records of the sorted segments
-    uint64_t *range_lo = nullptr, *range_hi = nullptr;    // [nb_cap] key range of every bucket
+    BucketParams* tile_map = nullptr;                     // [nb_cap] bin map of the tile sort over every bucket's key range
     void *first_sa = nullptr, *last_sa = nullptr;         // [nb_cap] idx_t
     SegBufs sub;                      // the buckets as segments (G = nb_cap, trailing ones empty)
     uint32_t nb_cap = 0;
@@ -175,8 +175,7 @@ Plan<idx_t> make_plan(uint64_t n, uint64_t p_arg, char* base)
     pl.bk.count = ar.take<uint64_t>(pl.bk.nb_cap);
     pl.bk.cursor = ar.take<idx_t>(pl.bk.nb_cap);
     pl.bk.scan_tmp = ar.take<uint64_t>(2 * ((size_t)pl.bk.nb_cap / SCAN_CHUNK + 2));
-    pl.bk.range_lo = ar.take<uint64_t>(pl.bk.nb_cap);
-    pl.bk.range_hi = ar.take<uint64_t>(pl.bk.nb_cap);
+    pl.bk.tile_map = ar.take<BucketParams>(pl.bk.nb_cap);
     pl.bk.first_key = ar.take<uint64_t>(pl.bk.nb_cap);
     pl.bk.last_key = ar.take<uint64_t>(pl.bk.nb_cap);
     pl.bk.first_sa = ar.take<idx_t>(pl.bk.nb_cap);
@@ -337,7 +336,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
     const bool dbg = std::getenv("CAPS_SA_DEBUG") != nullptr;
     auto mark = [&](const char* what) { if (dbg) { be.sync(); std::fprintf(stderr, "[sort] %s\n", what); } };
     bool from_text = o.from_text;
-    const uint64_t *range_lo = nullptr, *range_hi = nullptr;      // key ranges of the sorted segments, if bucketed
+    const BucketParams* seg_map = nullptr;                        // bin maps of the sorted segments, if bucketed
     SegBufs segs = s;
     bool skip = o.skip_finished;
     uint32_t slot_cap = 0;                           // != 0: the tile sort's input sits in fixed-capacity slots
@@ -352,9 +351,8 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         CAPS_LAUNCH(scan_sizes_kernel, 1, 1024, be, (const uint64_t*)bk.segB, s.G, bk.bstart);
         CAPS_LAUNCH(bucket_ranges_kernel, (bk.nb_cap + 255) / 256, 256, be, (const uint64_t*)bk.bstart, s.G,
                     (const BucketParams*)bk.params, o.pkey, o.range_mode, o.part_off, o.part_total ? o.part_total : s.G,
-                    bk.range_lo, bk.range_hi);
-        range_lo = bk.range_lo;
-        range_hi = bk.range_hi;
+                    bk.tile_map);
+        seg_map = bk.tile_map;
         mark("bucket plan");
         const uint32_t pgrid = n_tiles < be.persistent_blocks() ? n_tiles : be.persistent_blocks();
         const bool runs = o.runs != nullptr;             // phase 2 reading the sorted subarrays through the partition matrix
@@ -468,12 +466,12 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
     const idx_t* in_sa = slot_cap ? slot_sa : cur.sa;
     if (from_text) {
         CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, sd, P, n, o.text_base, lcp_mode, 0u,
-                    (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, range_lo, range_hi, redo);
+                    (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, seg_map, redo);
         CAPS_LAUNCH((tile_sort_general_kernel<idx_t, BITS, true>), ggrid, TILE_NT, be, sd, P, n, o.text_base, lcp_mode, 0u,
                     (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo);
     } else {
         CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
-                    in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, range_lo, range_hi, redo);
+                    in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, redo);
         CAPS_LAUNCH((tile_sort_general_kernel<idx_t, BITS, false>), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
                     in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo);
     }

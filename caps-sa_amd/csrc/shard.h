@@ -389,8 +389,7 @@ private:
         k.count = get<uint64_t>(k.nb_cap);
         k.cursor = get<idx_t>(k.nb_cap);
         k.scan_tmp = get<uint64_t>(2 * ((size_t)k.nb_cap / SCAN_CHUNK + 2));
-        k.range_lo = get<uint64_t>(k.nb_cap);
-        k.range_hi = get<uint64_t>(k.nb_cap);
+        k.tile_map = get<BucketParams>(k.nb_cap);
         k.first_key = get<uint64_t>(k.nb_cap);
         k.last_key = get<uint64_t>(k.nb_cap);
         k.first_sa = get<idx_t>(k.nb_cap);
