@@ -323,10 +323,15 @@ private:
     }
     ElemBuf<idx_t> elems(uint64_t cnt)
     {
+        // one allocation (key | sa | lcp): a speculative bucket split views it as its slot buffer
         ElemBuf<idx_t> b;
-        b.key = get<uint64_t>(cnt);
-        b.sa = get<idx_t>(cnt);
-        b.lcp = get<idx_t>(cnt);
+        const size_t c = cnt ? cnt : 1;
+        const size_t key_bytes = (c * sizeof(uint64_t) + 255) & ~size_t(255), idx_bytes = (c * sizeof(idx_t) + 255) & ~size_t(255);
+        char* base = get<char>(key_bytes + 2 * idx_bytes);
+        b.key = reinterpret_cast<uint64_t*>(base);
+        b.sa = reinterpret_cast<idx_t*>(base + key_bytes);
+        b.lcp = reinterpret_cast<idx_t*>(base + key_bytes + idx_bytes);
+        b.region_bytes = key_bytes + 2 * idx_bytes;
         return b;
     }
     SegBufs segs(uint32_t G, uint64_t cap)
@@ -376,6 +381,7 @@ private:
         o.skip_finished = skip_finished;
         o.bk = bk;
         o.unify = unify;
+        o.speculate = bk != nullptr && std::getenv("CAPS_SA_NO_SLOTS") == nullptr;   // as in Builder::seg_sort
         return segmented_sort<idx_t, BITS>(be_, P_, n_, tdesc_, s, n_tiles, max_len, a, b, n_elems, o);
     }
     BucketBufs buckets(uint64_t n_elems, uint32_t G)
