@@ -312,3 +312,24 @@ def test_genome_like_markov_with_repeats_device(L):
     st = L.build_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr(), p=1000)
     assert L.verify_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr()) == 0
     assert int(LCP.max().item()) > 200          # the planted repeats are there
+
+
+def test_slot_splits_kept_on_uniform_keys_and_redone_on_skew(L, oracle):
+    """The bucket splits of phase 1 and phase 2 first scatter into fixed-capacity slots (no count pass).
+    Uniform keys: both are kept (and C2 / C3 rely on that for their speed).  Skewed keys: a bucket
+    overflows its slot, the split is redone with the count pass; both ways the result is exact."""
+    st = _device_build_and_verify(L, 60_000_001, 200, 5)
+    assert st["slot_splits"] == 2 and st["slot_splits_redone"] == 0, st
+    assert st["merge_passes_phase1"] == 0 and st["merge_passes_phase2"] == 0
+    rs = np.random.RandomState(22)
+    T = rs.choice(DNA, size=4_000_000, p=[0.6, 0.2, 0.1, 0.1])
+    st = _same(L, oracle, T, 16)
+    assert st["slot_splits_redone"] >= 1, st
+
+
+def test_partitions_spanning_more_runs_than_a_tile_stages(L):
+    """p = 8000 on 40 M bases: a 4096-element tile of a 5000-element partition spans more than 4096
+    of the p sorted subarrays' runs, so the phase-2 scatter resolves runs by binary search in global
+    memory instead of in its LDS stage (bucket_scatter_kernel<SRC_RUNS>, !runs_staged)."""
+    st = _device_build_and_verify(L, 40_000_001, 8000, 6)
+    assert st["p_eff"] == 8000 and st["max_partition"] > 4096
