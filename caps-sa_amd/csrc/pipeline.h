@@ -319,8 +319,11 @@ struct SortOpts {
 
 // Sort every segment of `s`:  [bucket split]  ->  tile sort  ->  LCP-merge passes.
 //   not bucketed: input (unless from_text) is in `cur`, sorted in place, passes ping-pong cur <-> oth;
-//   bucketed:     input (unless from_text) is in `cur`, scattered by bucket into `oth`, which then
-//                 plays the role of `cur`; the buckets become the segments (result.segs).
+//   bucketed:     the buckets become the segments (result.segs).  Slot split (o.speculate, `oth` large enough):
+//                 input -> fixed-capacity slots viewed over `oth` -> tile sort -> compact in `cur`.
+//                 Count split (a slot overflowed, or no speculation): input (unless from_text) is in `cur`,
+//                 scattered by bucket into `oth`, which then plays the role of `cur`.
+//                 o.runs: the input elements are still spread over the sorted subarrays in `cur` (phase 2).
 // n_tiles / max_len describe `s` (host-known for phase 1 and the samples, read back for phase 2).
 template <typename idx_t, int BITS>
 SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, TileDesc* desc, const SegBufs& s, uint32_t n_tiles,
