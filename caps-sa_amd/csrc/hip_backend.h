@@ -79,6 +79,8 @@ public:
     void check_launch(const char* name)
     {
         hipError_t e = hipGetLastError();
+        if (e == hipErrorOutOfMemory)            // memory is committed lazily: an allocation too large can surface here
+            throw OomError(std::string("launch of ") + name + ": " + hipGetErrorString(e));
         if (e != hipSuccess) throw HipError(std::string("launch of ") + name + ": " + hipGetErrorString(e));
     }
 
@@ -87,12 +89,30 @@ private:
     uint32_t pblocks_ = 0;
 };
 
+// A dispatch holds its size in WORK-ITEMS as 32 bits (AQL grid_size_x): grid * block >= 2^32 does not fail, it
+// silently runs a truncated grid (seen with locate_kernel at p = 72,845: p^2 threads).  Kernels whose natural
+// grid can get there loop over their logical blocks; everything else is refused here.
+inline uint32_t checked_grid(uint64_t grid, uint64_t block, const char* name)
+{
+    if (grid == 0 || grid * block > 0xFFFFFFFFull)
+        throw HipError(std::string(name) + ": launch of " + std::to_string(grid) + " x " + std::to_string(block) +
+                       " work-items does not fit a dispatch");
+    return (uint32_t)grid;
+}
+// largest grid (in workgroups of `block` threads) of a kernel that loops over its logical blocks
+inline uint32_t capped_grid(uint64_t want, uint32_t block)
+{
+    const uint64_t cap = 0xFFFFFFFFull / block;
+    return (uint32_t)(want < cap ? (want ? want : 1) : cap);
+}
+
 }  // namespace caps
 
 // Launch on the backend's stream.  Host code checks operand shapes before every launch
 // (grid sizes are derived from the same n/p that size the buffers).
 #define CAPS_LAUNCH(kernel, grid, block, be, ...)                                                        \
     do {                                                                                                 \
-        hipLaunchKernelGGL(kernel, dim3((uint32_t)(grid)), dim3((uint32_t)(block)), 0, (be).stream, __VA_ARGS__); \
+        hipLaunchKernelGGL(kernel, dim3(::caps::checked_grid((grid), (block), #kernel)), dim3((uint32_t)(block)), 0, (be).stream, \
+                           __VA_ARGS__);                                                                 \
         (be).check_launch(#kernel);                                                                      \
     } while (0)

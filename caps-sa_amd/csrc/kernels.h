@@ -1329,17 +1329,21 @@ GLOBAL_FN LAUNCH_BOUNDS(256) transpose_kernel(KCTX const idx_t* __restrict__ in,
 {
     SHARED_ARRAY(idx_t, tile, 32 * 33);
     const uint32_t tc = (cols + 31) / 32;
-    const uint32_t r0 = (K_BLOCK_IDX / tc) * 32, c0 = (K_BLOCK_IDX % tc) * 32;
-    PAR(tid) {
-        const uint32_t x = tid & 31, y = tid >> 5;             // 8 rows of 32 per step
-        for (uint32_t yy = y; yy < 32; yy += 8)
-            if (r0 + yy < rows && c0 + x < cols) tile[yy * 33 + x] = in[(uint64_t)(r0 + yy) * cols + c0 + x];
-    }
-    SYNC();
-    PAR(tid) {
-        const uint32_t x = tid & 31, y = tid >> 5;
-        for (uint32_t yy = y; yy < 32; yy += 8)
-            if (c0 + yy < cols && r0 + x < rows) out[(uint64_t)(c0 + yy) * rows + r0 + x] = tile[x * 33 + yy];
+    const uint64_t total = (uint64_t)tc * ((rows + 31) / 32);
+    for (uint64_t v = K_BLOCK_IDX; v < total; v += K_GRID_DIM) {
+        const uint32_t r0 = (uint32_t)(v / tc) * 32, c0 = (uint32_t)(v % tc) * 32;
+        PAR(tid) {
+            const uint32_t x = tid & 31, y = tid >> 5;             // 8 rows of 32 per step
+            for (uint32_t yy = y; yy < 32; yy += 8)
+                if (r0 + yy < rows && c0 + x < cols) tile[yy * 33 + x] = in[(uint64_t)(r0 + yy) * cols + c0 + x];
+        }
+        SYNC();
+        PAR(tid) {
+            const uint32_t x = tid & 31, y = tid >> 5;
+            for (uint32_t yy = y; yy < 32; yy += 8)
+                if (c0 + yy < cols && r0 + x < rows) out[(uint64_t)(c0 + yy) * rows + r0 + x] = tile[x * 33 + yy];
+        }
+        SYNC();
     }
 }
 
@@ -1806,7 +1810,9 @@ GLOBAL_FN LAUNCH_BOUNDS(256) locate_kernel(KCTX const uint32_t* __restrict__ P, 
                                            idx_t* __restrict__ Pm)
 {
     const uint32_t bpr = (np + K_BLOCK_DIM - 1) / K_BLOCK_DIM;            // blocks per segment row
-    const uint64_t L = xcd_swizzle(K_BLOCK_IDX, (uint64_t)G * bpr);
+    const uint64_t total = (uint64_t)G * bpr;                             // logical blocks (~p^2 / 256: may exceed a dispatch)
+    for (uint64_t v = K_BLOCK_IDX; v < total; v += K_GRID_DIM) {
+    const uint64_t L = K_GRID_DIM == total ? xcd_swizzle(v, total) : v;
     const uint32_t g = (uint32_t)(L / bpr), jb = (uint32_t)(L % bpr);
     const uint64_t s0 = seg_start[g], len = seg_start[g + 1] - s0;
     PAR(tid) {
@@ -1823,6 +1829,7 @@ GLOBAL_FN LAUNCH_BOUNDS(256) locate_kernel(KCTX const uint32_t* __restrict__ P, 
             row[j + 1] = (idx_t)lo;
         }
         if (j == 0) { row[0] = 0; row[np + 1] = (idx_t)len; }
+    }
     }
 }
 

@@ -641,7 +641,7 @@ private:
             // ---- locate (a7/a8)
             const uint32_t np = p - 1;
             const uint32_t bpr = (np + 255) / 256;
-            CAPS_LAUNCH((locate_kernel<idx_t, BITS>), p * bpr, 256, be_, (const uint32_t*)pl_.P, n,
+            CAPS_LAUNCH((locate_kernel<idx_t, BITS>), capped_grid((uint64_t)p * bpr, 256), 256, be_, (const uint32_t*)pl_.P, n,
                         (const uint64_t*)pl_.seg1.seg_start, p, (const uint64_t*)cur.key, (const idx_t*)cur.sa,
                         (const uint64_t*)pl_.pkey, (const idx_t*)pl_.psa, np, pl_.Pm);
             e4 = be_.record();
@@ -666,9 +666,9 @@ private:
             RunSrc<idx_t> rsrc;
             ElemBuf<idx_t> in2 = cur, out2buf = oth;
             if (fused) {
-                CAPS_LAUNCH((transpose_kernel<idx_t>), ((p + 31) / 32) * ((p + 1 + 31) / 32), 256, be_, (const idx_t*)pl_.Pm, p, p + 1,
+                CAPS_LAUNCH((transpose_kernel<idx_t>), capped_grid((uint64_t)((p + 31) / 32) * ((p + 1 + 31) / 32), 256), 256, be_, (const idx_t*)pl_.Pm, p, p + 1,
                             pl_.PmT);
-                CAPS_LAUNCH((transpose_kernel<idx_t>), ((p + 31) / 32) * ((p + 31) / 32), 256, be_, (const idx_t*)pl_.ruler, p, p,
+                CAPS_LAUNCH((transpose_kernel<idx_t>), capped_grid((uint64_t)((p + 31) / 32) * ((p + 31) / 32), 256), 256, be_, (const idx_t*)pl_.ruler, p, p,
                             pl_.rulerT);
                 CAPS_LAUNCH((runs_plan_kernel<idx_t>), (n_tiles2 + 255) / 256, 256, be_, pl_.seg2.desc(), (const idx_t*)pl_.rulerT, p,
                             tile_plan);

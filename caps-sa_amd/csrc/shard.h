@@ -140,10 +140,10 @@ public:
         const uint32_t np = p_ - 1, bpr = (np + 255) / 256;
         if (G_) {
             if (bits_ == 2)
-                CAPS_LAUNCH((locate_kernel<idx_t, 2>), G_ * bpr, 256, be_, (const uint32_t*)P_, n_, (const uint64_t*)seg1_.seg_start, G_,
+                CAPS_LAUNCH((locate_kernel<idx_t, 2>), capped_grid((uint64_t)G_ * bpr, 256), 256, be_, (const uint32_t*)P_, n_, (const uint64_t*)seg1_.seg_start, G_,
                             (const uint64_t*)cur_.key, (const idx_t*)cur_.sa, (const uint64_t*)pkey_, (const idx_t*)psa_, np, Pm_);
             else
-                CAPS_LAUNCH((locate_kernel<idx_t, 8>), G_ * bpr, 256, be_, (const uint32_t*)P_, n_, (const uint64_t*)seg1_.seg_start, G_,
+                CAPS_LAUNCH((locate_kernel<idx_t, 8>), capped_grid((uint64_t)G_ * bpr, 256), 256, be_, (const uint32_t*)P_, n_, (const uint64_t*)seg1_.seg_start, G_,
                             (const uint64_t*)cur_.key, (const idx_t*)cur_.sa, (const uint64_t*)pkey_, (const idx_t*)psa_, np, Pm_);
         }
         CAPS_LAUNCH((partition_partial_kernel<idx_t>), ((p_ + 255) / 256) * PART_CHUNKS, 256, be_, (const idx_t*)Pm_, G_, p_, partial_);

@@ -333,3 +333,12 @@ def test_partitions_spanning_more_runs_than_a_tile_stages(L):
     memory instead of in its LDS stage (bucket_scatter_kernel<SRC_RUNS>, !runs_staged)."""
     st = _device_build_and_verify(L, 40_000_001, 8000, 6)
     assert st["p_eff"] == 8000 and st["max_partition"] > 4096
+
+
+def test_more_subproblems_than_a_dispatch_has_threads(L, oracle):
+    """p = 72,845 (found by tools/stress_gpu.py): locate_kernel's natural grid of p^2 threads exceeds the
+    2^32 work-items of one dispatch, which HIP truncates silently; the kernel loops over its blocks."""
+    rs = np.random.RandomState(172)
+    n = 2_913_828
+    T = rs.choice(DNA, size=n, p=[0.55, 0.25, 0.15, 0.05])
+    _same(L, oracle, T, n // 40, bits=64)

@@ -1,0 +1,79 @@
+"""Randomised parity stress on the GPU: random sizes, subproblem counts, alphabets and text shapes,
+each build compared bit for bit with the oracle (test infrastructure).  usage: stress_gpu.py [seconds] [seed]"""
+import json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import torch  # noqa: F401  (first: one HIP runtime per process)
+import caps_sa_amd
+import oracle as O
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+if os.environ.get("STRESS_EMUL"):             # same random sequence through the host emulation (debugging a failure)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from emul_util import emul
+    L = emul()
+else:
+    L = caps_sa_amd.lib()
+DNA = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def text(kind, n):
+    if kind == "uniform":
+        return rs.choice(DNA, size=n)
+    if kind == "skew":
+        w = rs.dirichlet([0.4] * 4)
+        return rs.choice(DNA, size=n, p=w)
+    if kind == "two":
+        return rs.choice(np.frombuffer(b"AT", dtype=np.uint8), size=n, p=[0.8, 0.2])
+    if kind == "bytes":
+        k = int(rs.randint(5, 200))
+        return rs.randint(0, k, size=n).astype(np.uint8) + np.uint8(rs.randint(0, 256 - k))
+    if kind == "periodic":
+        per = int(rs.randint(1, 200))
+        return np.tile(rs.choice(DNA, size=per), n // per + 1)[:n]
+    if kind == "planted":
+        T = rs.choice(DNA, size=n)
+        for _ in range(int(rs.randint(1, 6))):
+            ln = int(rs.randint(10, max(11, n // 8)))
+            a, b = rs.randint(0, n - ln, size=2)
+            T[b:b + ln] = T[a:a + ln]
+        return T
+    if kind == "runs":
+        T = rs.choice(DNA, size=n)
+        a = int(rs.randint(0, n // 2)); ln = int(rs.randint(1, n // 3 + 2))
+        T[a:a + ln] = T[a]
+        return T
+    raise ValueError(kind)
+
+
+kinds = ["uniform", "skew", "two", "bytes", "periodic", "planted", "runs"]
+t0 = time.time(); done = 0; oom = 0; stats = {"slot_splits": 0, "slot_splits_redone": 0}
+while time.time() - t0 < budget:
+    kind = kinds[rs.randint(len(kinds))]
+    big = rs.rand() < 0.25
+    n = int(rs.randint(33, 3_000_000 if big else 60_000))
+    if kind == "periodic" or kind == "runs":
+        n = min(n, 40_000)                       # quadratic in the LCP, for the oracle too
+    p = int(rs.choice([0, 2, 3, 7, 16, 50, 333, 1000, 8000, max(2, n // 16), max(2, n // 40)]))
+    p_mem = min(p, 20000)                        # the p x p matrices (like the reference's) must fit
+    if os.environ.get("STRESS_CAP_P"): p = p_mem
+    bits = 64 if rs.rand() < 0.2 else 32
+    T = text(kind, n)
+    try:
+        SA, LCP, st = L.build(T, p=p, idx_bits=bits)
+    except caps_sa_amd.CapsSaError as e:         # p^2 matrices beyond the device memory (as in the reference: p^2 on the host)
+        if e.code != -4:
+            raise
+        oom += 1
+        continue
+    SAo, LCPo = O.build_sa_lcp(T, p=p, idx_bits=bits)[:2]
+    ok = np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo)
+    if not ok:
+        np.save(os.environ.get("STRESS_DUMP", "/tmp/stress_fail_T.npy"), T)
+        print(json.dumps({"FAIL": True, "kind": kind, "n": n, "p": p, "bits": bits}))
+        sys.exit(1)
+    for k in stats: stats[k] += st[k]
+    done += 1
+print(json.dumps({"builds": done, "out_of_memory": oom, "seconds": round(time.time() - t0, 1), **stats}))
