@@ -29,6 +29,8 @@ def main():
     cases.append((rs.choice(np.frombuffer(b"abcdefgh", dtype=np.uint8), size=60_000), 16, 64))
     cases.append((np.tile(rs.choice(dna, size=37), 300), 5, 32))            # deep LCPs, skewed partitions
     cases.append((rs.choice(dna, size=100), 0, 32))                          # p_eff = 6
+    cases.append((rs.choice(dna, size=600_000), 8, 32))                      # big enough for the slot splits (kept)
+    cases.append((rs.choice(dna, size=500_000, p=[0.6, 0.2, 0.1, 0.1]), 6, 64))   # ... and redone on skewed keys
     ok = True
     for T_np, p, bits in cases:
         T = torch.from_numpy(T_np.copy())
@@ -43,7 +45,7 @@ def main():
         SA_all = caps_sa_dist._all_gather_var(SA, counts).numpy()
         LCP_all = caps_sa_dist._all_gather_var(LCP, counts).numpy()
         dt = np.uint32 if bits == 32 else np.uint64
-        SAo, LCPo = O.naive_sa_lcp(T_np, idx_bits=bits)
+        SAo, LCPo = (O.naive_sa_lcp(T_np, idx_bits=bits) if T_np.size <= 200_000 else O.build_sa_lcp(T_np, p=p, idx_bits=bits)[:2])
         good = np.array_equal(SA_all.view(dt), SAo) and np.array_equal(LCP_all.view(dt), LCPo)
         if rank == 0:
             print(f"case n={T_np.size} p={p} bits={bits} counts={counts} {'OK' if good else 'MISMATCH'}", flush=True)

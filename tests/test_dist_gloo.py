@@ -11,7 +11,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,port,a2a_limit", [(2, 29531, 0), (3, 29532, 0), (2, 29534, 4096)])
+@pytest.mark.parametrize("world,port,a2a_limit", [(2, 29531, 0), (3, 29532, 0), (2, 29534, 4096), (4, 29535, 0)])
 def test_sharded_build_matches_oracle(world, port, a2a_limit):
     """a2a_limit > 0: exchange in rounds of that many bytes per peer (the path taken on GPUs when a
     sub-subarray block exceeds RCCL's safe message size)."""
@@ -24,4 +24,4 @@ def test_sharded_build_matches_oracle(world, port, a2a_limit):
         env["CAPS_A2A_MAX_BYTES"] = str(a2a_limit)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert r.stdout.count(" OK") == 5, r.stdout
+    assert r.stdout.count(" OK") == 7, r.stdout

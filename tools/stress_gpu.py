@@ -12,8 +12,8 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 if os.environ.get("STRESS_EMUL"):             # same random sequence through the host emulation (debugging a failure)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from emul_util import emul
-    L = emul()
+    from emul_util import emul, emul_small
+    L = emul_small() if os.environ["STRESS_EMUL"] == "small" else emul()
 else:
     L = caps_sa_amd.lib()
 DNA = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -53,7 +53,7 @@ t0 = time.time(); done = 0; oom = 0; stats = {"slot_splits": 0, "slot_splits_red
 while time.time() - t0 < budget:
     kind = kinds[rs.randint(len(kinds))]
     big = rs.rand() < 0.25
-    n = int(rs.randint(33, 3_000_000 if big else 60_000))
+    n = int(rs.randint(33, int(os.environ.get("STRESS_MAX_N", 3_000_000)) if big else 60_000))
     if kind == "periodic" or kind == "runs":
         n = min(n, 40_000)                       # quadratic in the LCP, for the oracle too
     p = int(rs.choice([0, 2, 3, 7, 16, 50, 333, 1000, 8000, max(2, n // 16), max(2, n // 40)]))
