@@ -24,7 +24,7 @@ class Stats(ctypes.Structure):
         ("merge_passes_phase1", ctypes.c_uint32),
         ("merge_passes_phase2", ctypes.c_uint32),
         ("merge_passes_samples", ctypes.c_uint32),
-        ("reserved0", ctypes.c_uint32),
+        ("long_runs", ctypes.c_uint32),
         ("max_partition", ctypes.c_uint64),
         ("workspace_bytes", ctypes.c_uint64),
         ("ms_total", ctypes.c_double),
@@ -54,7 +54,7 @@ class Stats(ctypes.Structure):
     ]
 
     def as_dict(self) -> dict:
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved0"}
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 class ShardInfo(ctypes.Structure):

@@ -168,7 +168,7 @@ inline DevText upload_text(Backend& be, DevAllocs& da, const char* T, uint64_t n
 {
     DevText t;
     t.raw = da.get<uint8_t>(n ? n : 1);
-    t.P = da.get<uint32_t>(packed_words(n ? n : 1, 8));
+    t.P = da.get<uint32_t>(text_alloc_words(n ? n : 1));
     uint32_t* present = da.get<uint32_t>(8);
     uint8_t* lut = da.get<uint8_t>(256);
     be.h2d(t.raw, T, n);
@@ -333,15 +333,15 @@ int merge_runs(const char* T, uint64_t n, const idx_t* X, uint64_t len_x, const 
         const uint32_t pg = nt < be.persistent_blocks() ? nt : be.persistent_blocks();
         if (t.bits == 2) {
             CAPS_LAUNCH((make_keys_kernel<idx_t, 2>), g, 256, be, (const uint32_t*)t.P, (const idx_t*)a.sa, cnt, a.key);
-            CAPS_LAUNCH((merge_partition_kernel<idx_t, 2>), (nt + 255) / 256, 256, be, sd, (const uint32_t*)t.P, n, (uint64_t)TILE_E,
+            CAPS_LAUNCH((merge_partition_kernel<idx_t, 2, true>), (nt + 255) / 256, 256, be, sd, (const uint32_t*)t.P, n, (uint64_t)TILE_E,
                         len_x, 0u, 1u, (const uint64_t*)a.key, (const idx_t*)a.sa, desc, (uint64_t*)nullptr);
-            CAPS_LAUNCH((merge_pass_kernel<idx_t, 2>), pg, TILE_NT, be, (const TileDesc*)desc, nt, (const uint32_t*)t.P, n,
+            CAPS_LAUNCH((merge_pass_kernel<idx_t, 2, true>), pg, TILE_NT, be, (const TileDesc*)desc, nt, (const uint32_t*)t.P, n,
                         (const uint64_t*)a.key, (const idx_t*)a.sa, b.key, b.sa, b.lcp);
         } else {
             CAPS_LAUNCH((make_keys_kernel<idx_t, 8>), g, 256, be, (const uint32_t*)t.P, (const idx_t*)a.sa, cnt, a.key);
-            CAPS_LAUNCH((merge_partition_kernel<idx_t, 8>), (nt + 255) / 256, 256, be, sd, (const uint32_t*)t.P, n, (uint64_t)TILE_E,
+            CAPS_LAUNCH((merge_partition_kernel<idx_t, 8, true>), (nt + 255) / 256, 256, be, sd, (const uint32_t*)t.P, n, (uint64_t)TILE_E,
                         len_x, 0u, 1u, (const uint64_t*)a.key, (const idx_t*)a.sa, desc, (uint64_t*)nullptr);
-            CAPS_LAUNCH((merge_pass_kernel<idx_t, 8>), pg, TILE_NT, be, (const TileDesc*)desc, nt, (const uint32_t*)t.P, n,
+            CAPS_LAUNCH((merge_pass_kernel<idx_t, 8, true>), pg, TILE_NT, be, (const TileDesc*)desc, nt, (const uint32_t*)t.P, n,
                         (const uint64_t*)a.key, (const idx_t*)a.sa, b.key, b.sa, b.lcp);
         }
         be.d2h(Z, b.sa, cnt * sizeof(idx_t));

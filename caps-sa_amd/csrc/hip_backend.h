@@ -30,6 +30,7 @@ struct BackendEvent { hipEvent_t ev = nullptr; };
 class Backend {
 public:
     hipStream_t stream = nullptr;
+    bool long_runs = false;       // the text prepared last holds a periodic stretch >= RUN_LONG chars (text.h): comparators with the run table
     explicit Backend(hipStream_t s) : stream(s) {}
     ~Backend() { release_events(); }
 

@@ -191,6 +191,157 @@ GLOBAL_FN LAUNCH_BOUNDS(256) pack_kernel(KCTX const uint8_t* __restrict__ T, uin
     }
 }
 
+// Run table (text.h), step 1: one entry per aligned block of KCH chars.  A block with smallest
+// period d whose d-periodic stretch ends inside the next block (or at the end of the text) gets
+// its final value; one whose stretch covers the whole next block gets RUN_LINKED (= "the value
+// of the block after me": that block then has the same smallest period) and raises *flag.
+// Blocks that are aperiodic or reach past the text get 0.
+template <int BITS>
+GLOBAL_FN LAUNCH_BOUNDS(256) run_blocks_kernel(KCTX const uint32_t* __restrict__ P, uint64_t n, uint64_t entries,
+                                               uint64_t* __restrict__ R, uint64_t* __restrict__ flag)
+{
+    constexpr uint32_t KCH = TextTraits<BITS>::KCH;
+    PAR(tid) {
+        const uint64_t full = n / KCH;                            // blocks that lie inside the text
+        const uint64_t stride = (uint64_t)K_GRID_DIM * K_BLOCK_DIM;
+        bool linked = false;
+        for (uint64_t b = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid; b < entries; b += stride) {
+            uint64_t r = 0;
+            if (b < full) {
+                const uint64_t w0 = ((uint64_t)P[2 * b] << 32) | P[2 * b + 1];
+                const uint32_t d = block_period<BITS>(w0);
+                if (d) {
+                    const uint64_t w1 = ((uint64_t)P[2 * b + 2] << 32) | P[2 * b + 3];
+                    const uint32_t sh = d * BITS;
+                    const uint64_t x = w1 ^ ((w0 << (64 - sh)) | (w1 >> sh));   // T[q] ^ T[q - d] over the next block
+                    const uint64_t cand = x ? KCH * (b + 1) + (uint32_t)caps_clz64(x) / BITS : KCH * (b + 2);
+                    if (cand >= n) r = ((uint64_t)d << 56) | n;
+                    else if (!x) { r = RUN_LINKED; linked = true; }
+                    else r = ((uint64_t)d << 56) | cand;
+                }
+            }
+            R[b] = r;
+        }
+        if (linked) *flag = 1;                                     // benign race: every writer stores 1
+    }
+}
+
+// Run table, steps 2-4: R[b] = R[first block >= b that is not RUN_LINKED], a suffix scan with the
+// operator "mine unless linked".  Chunks of RUN_CHUNK blocks: (2) first unlinked value of every
+// chunk, (3) one workgroup carries them from the right, (4) every chunk resolves its entries.
+// All three return at once when no block is linked (any text without a periodic stretch of
+// 2 * KCH chars: step 1 has already written final values).
+GLOBAL_FN LAUNCH_BOUNDS(256) run_chunk_heads_kernel(KCTX const uint64_t* __restrict__ R, uint64_t entries,
+                                                    const uint64_t* __restrict__ flag, uint64_t* __restrict__ head)
+{
+    SHARED_ARRAY(uint32_t, first, 1);
+    if (!*flag) return;
+    PAR(tid) { if (tid == 0) first[0] = RUN_CHUNK; }
+    SYNC();
+    const uint64_t base = (uint64_t)K_BLOCK_IDX * RUN_CHUNK;
+    PAR(tid) {
+        for (uint32_t k = 0; k < RUN_PER; ++k) {
+            const uint64_t b = base + (uint64_t)tid * RUN_PER + k;
+            if (b < entries && R[b] != RUN_LINKED) {
+#ifdef CAPS_EMUL
+                if (tid * RUN_PER + k < first[0]) first[0] = tid * RUN_PER + k;
+#else
+                atomicMin(&first[0], tid * RUN_PER + k);
+#endif
+                break;
+            }
+        }
+    }
+    SYNC();
+    PAR(tid) {
+        if (tid == 0) head[K_BLOCK_IDX] = first[0] < RUN_CHUNK ? R[base + first[0]] : RUN_LINKED;
+    }
+}
+
+// carry[c] = first unlinked value right of chunk c (exclusive); one workgroup, right to left.
+GLOBAL_FN LAUNCH_BOUNDS(1024) run_carry_kernel(KCTX const uint64_t* __restrict__ head, uint32_t chunks,
+                                               const uint64_t* __restrict__ flag, uint64_t* __restrict__ carry)
+{
+    SHARED_ARRAY(uint64_t, v, 2 * 1024);
+    SHARED_ARRAY(uint64_t, from_right, 1);
+    if (!*flag) return;
+    PAR(tid) { if (tid == 0) from_right[0] = 0; }              // the last entries of the table are 0, never linked
+    SYNC();
+    for (uint64_t hi = chunks; hi > 0; hi -= (hi < 1024 ? hi : 1024)) {
+        const uint32_t cnt = (uint32_t)(hi < 1024 ? hi : 1024);
+        const uint64_t lo = hi - cnt;                              // this round: chunks [lo, hi)
+        PAR(tid) { v[tid] = tid < cnt ? head[lo + tid] : RUN_LINKED; }
+        SYNC();
+        uint32_t src = 0;
+        for (uint32_t d = 1; d < 1024; d <<= 1) {                  // inclusive suffix scan, ping-pong halves
+            PAR(tid) {
+                const uint64_t mine = v[src * 1024 + tid];
+                v[(src ^ 1) * 1024 + tid] = (mine == RUN_LINKED && tid + d < 1024) ? v[src * 1024 + tid + d] : mine;
+            }
+            SYNC();
+            src ^= 1;
+        }
+        PAR(tid) {
+            if (tid < cnt) {
+                const uint64_t right = tid + 1 < cnt ? v[src * 1024 + tid + 1] : RUN_LINKED;   // inclusive value of the chunk to my right
+                carry[lo + tid] = right != RUN_LINKED ? right : from_right[0];
+            }
+        }
+        SYNC();
+        PAR(tid) {
+            if (tid == 0 && v[src * 1024] != RUN_LINKED) from_right[0] = v[src * 1024];
+        }
+        SYNC();
+    }
+}
+
+// Also: longest[0] = max over blocks of (end of its stretch - start of the block).
+GLOBAL_FN LAUNCH_BOUNDS(256) run_resolve_kernel(KCTX uint64_t* __restrict__ R, uint64_t entries, const uint64_t* __restrict__ flag,
+                                                const uint64_t* __restrict__ carry, uint32_t kch, uint64_t* __restrict__ longest)
+{
+    SHARED_ARRAY(uint64_t, v, 2 * RUN_NT);
+    SHARED_ARRAY(uint64_t, lmax, 1);
+    if (!*flag) return;
+    PAR(tid) { if (tid == 0) lmax[0] = 0; }
+    const uint64_t base = (uint64_t)K_BLOCK_IDX * RUN_CHUNK;
+    TL_DECL(uint64_t, r, RUN_PER);
+    PAR(tid) {
+        uint64_t head = RUN_LINKED;                                // first unlinked value among my blocks
+        for (uint32_t k = 0; k < RUN_PER; ++k) {
+            const uint64_t b = base + (uint64_t)tid * RUN_PER + k;
+            TL(r, tid, k) = b < entries ? R[b] : 0;
+        }
+        for (int k = RUN_PER - 1; k >= 0; --k) if (TL(r, tid, k) != RUN_LINKED) head = TL(r, tid, k);
+        v[tid] = head;
+    }
+    SYNC();
+    uint32_t src = 0;
+    for (uint32_t d = 1; d < RUN_NT; d <<= 1) {
+        PAR(tid) {
+            const uint64_t mine = v[src * RUN_NT + tid];
+            v[(src ^ 1) * RUN_NT + tid] = (mine == RUN_LINKED && tid + d < RUN_NT) ? v[src * RUN_NT + tid + d] : mine;
+        }
+        SYNC();
+        src ^= 1;
+    }
+    PAR(tid) {
+        uint64_t right = tid + 1 < RUN_NT ? v[src * RUN_NT + tid + 1] : RUN_LINKED;
+        if (right == RUN_LINKED) right = carry[K_BLOCK_IDX];
+        uint64_t ext = 0;
+        for (int k = RUN_PER - 1; k >= 0; --k) {
+            const uint64_t b = base + (uint64_t)tid * RUN_PER + k;
+            if (TL(r, tid, k) == RUN_LINKED) {
+                if (b < entries) R[b] = right;
+                const uint64_t e = (right & RUN_POS_MASK) - b * kch;
+                ext = e > ext ? e : ext;
+            } else right = TL(r, tid, k);
+        }
+        if (ext >= RUN_LONG) ATOMIC_MAX_LDS_U64(&lmax[0], ext);
+    }
+    SYNC();
+    PAR(tid) { if (tid == 0 && lmax[0]) ATOMIC_MAX_U64(longest, lmax[0]); }
+}
+
 // key/sa for an arbitrary list of suffix positions (sample sort, stand-alone entry points).
 template <typename idx_t, int BITS>
 GLOBAL_FN LAUNCH_BOUNDS(256) make_keys_kernel(KCTX const uint32_t* __restrict__ P, const idx_t* __restrict__ sa, uint64_t cnt,
@@ -411,7 +562,7 @@ GLOBAL_FN LAUNCH_BOUNDS(256) tile_map_kernel(KCTX const uint64_t* __restrict__ s
 // flight together.  Only keys are compared there (equal key = "not smaller"); a suffix whose
 // key also occurs in the range finishes with the exact comparator over the remaining
 // candidates -- never on random DNA, routinely on repeats.
-template <typename idx_t, int BITS, int K>
+template <typename idx_t, int BITS, int K, bool RUNS = true>
 DEV_INLINE void multi_lower_bound(const uint32_t* __restrict__ P, uint64_t n, const uint64_t* skey, const idx_t* ssa,
                                   const uint64_t (&key)[K], const idx_t (&sa)[K], uint32_t (&lo)[K], const uint32_t (&hi)[K],
                                   uint32_t top)
@@ -430,7 +581,7 @@ DEV_INLINE void multi_lower_bound(const uint32_t* __restrict__ P, uint64_t n, co
             uint32_t a = lo[k], b = hi[k];
             while (a < b) {
                 const uint32_t mid = (a + b) >> 1;
-                if (suffix_less<BITS>(P, n, skey[mid], (uint64_t)ssa[mid], key[k], (uint64_t)sa[k])) a = mid + 1;
+                if (suffix_less<BITS, RUNS>(P, n, skey[mid], (uint64_t)ssa[mid], key[k], (uint64_t)sa[k])) a = mid + 1;
                 else b = mid;
             }
             lo[k] = a;
@@ -650,7 +801,7 @@ constexpr uint32_t TILE_BIN_LIMIT = CAPS_TILE_BIN_LIMIT;
                 const uint64_t key = skey[e];                                                                   \
                 const idx_t sa = ssa[e];                                                                        \
                 uint64_t l = 0;                                                                                 \
-                if (with_lcp && e) l = pair_lcp<BITS>(P, n, skey[e - 1], (uint64_t)ssa[e - 1], key, (uint64_t)sa); \
+                if (with_lcp && e) l = pair_lcp<BITS, TILE_RUNS>(P, n, skey[e - 1], (uint64_t)ssa[e - 1], key, (uint64_t)sa); \
                 if (direct) {                                                                                   \
                     fin.sa[start + e] = sa;                                                                     \
                     fin.lcp[start + e] = (idx_t)l;                                                              \
@@ -680,6 +831,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
                                                   FinalOut<idx_t> fin, const BucketParams* __restrict__ seg_map,
                                                   uint32_t* __restrict__ redo)
 {
+    constexpr bool TILE_RUNS = false;        // ties here are shallow (suffix_less_tie_bounded), so are the LCPs
     TILE_SORT_PROLOGUE
     SHARED_ARRAY(uint64_t, skey, TILE_E);
     SHARED_ARRAY(idx_t, ssa, TILE_E);
@@ -743,14 +895,21 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
                     for (uint32_t j = bs; j < be; ++j) {
                         const uint64_t kj = skey[j];
                         less += kj < key ? 1u : 0u;
-                        if (kj == key && j != slot && suffix_less_tie<BITS>(P, n, (uint64_t)ssa[j], sa)) ++less;   // rare: text
+                        if (kj == key && j != slot) {                                                               // rare: text
+                            const uint32_t c = suffix_less_tie_bounded<BITS>(P, n, (uint64_t)ssa[j], sa);
+                            if (c == 2u) flag[0] = 1;                                                               // a deep tie: not here
+                            less += c & 1u;
+                        }
                     }
                     TL(rd, tid, k) = bs + less;
                 }
             }
         }
         SYNC();
-        TILE_SORT_PLACE_FINAL
+        fast = flag[0] == 0;
+        if (fast) {
+            TILE_SORT_PLACE_FINAL
+        }
     }
 #ifdef CAPS_EMUL
     caps_emul_count_tile(fast, known_range);
@@ -780,7 +939,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
 // Markov-skewed DNA it rescued < 20 % of the tiles and cost more than it saved.)
 constexpr uint32_t TILE_SAMPLE_LIMIT = 64;
 
-template <typename idx_t, int BITS, bool FROM_TEXT>
+template <typename idx_t, int BITS, bool FROM_TEXT, bool RUNS>
 GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_general_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
                                                           uint64_t text_base, uint32_t lcp_mode, uint32_t slot_cap, const uint64_t* in_key,
                                                           const idx_t* in_sa, uint64_t* out_key, idx_t* out_sa, idx_t* out_lcp,
@@ -799,6 +958,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_general_kernel(
     TL_DECL(uint64_t, sk1, 1);                      // the thread's sample while the samples are sorted
     TL_DECL(idx_t, ss1, 1);
     TL_DECL(uint32_t, sd1, 1);
+    constexpr bool TILE_RUNS = RUNS;
     const uint32_t n_redo = redo[0];
     for (uint32_t qi = K_BLOCK_IDX; qi < n_redo; qi += K_GRID_DIM) {
     const uint32_t b = redo[1 + qi];
@@ -858,7 +1018,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_general_kernel(
                     hi1[0] = sib + R < S ? sib + R : S;
                     dbase = (run & ~1u) * R + (tid - run * R) - sib;
                 }
-                multi_lower_bound<idx_t, BITS, 1>(P, n, smk, sms, key1, sa1, lo1, hi1, 2 * R);
+                multi_lower_bound<idx_t, BITS, 1, RUNS>(P, n, smk, sms, key1, sa1, lo1, hi1, 2 * R);
                 TL(sk1, tid, 0) = key1[0];
                 TL(ss1, tid, 0) = sa1[0];
                 TL(sd1, tid, 0) = dbase + lo1[0];
@@ -885,7 +1045,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_general_kernel(
                     lo[k] = 0;
                     hi[k] = e < cnt ? S : 0u;
                 }
-                multi_lower_bound<idx_t, BITS, LOCK_K>(P, n, smk, sms, key, sa, lo, hi, top);
+                multi_lower_bound<idx_t, BITS, LOCK_K, RUNS>(P, n, smk, sms, key, sa, lo, hi, top);
                 UNROLL
                 for (uint32_t k = 0; k < LOCK_K; ++k) {
                     const uint32_t e = tid + (gg + k) * TILE_NT;
@@ -925,7 +1085,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_general_kernel(
                         const uint64_t sa = (uint64_t)TL(rs, tid, k);
                         uint32_t less = 0;                        // members of my bin that sort before me
                         for (uint32_t j = bs; j < be; ++j)
-                            if (j != slot && suffix_less<BITS>(P, n, skey[j], (uint64_t)ssa[j], key, sa)) ++less;
+                            if (j != slot && suffix_less<BITS, RUNS>(P, n, skey[j], (uint64_t)ssa[j], key, sa)) ++less;
                         TL(rd, tid, k) = bs + less;
                     }
                 }
@@ -973,7 +1133,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_general_kernel(
                         dbase[k] = (run & ~1u) * R + (e - run * R) - sib_start;
                     }
                 }
-                multi_lower_bound<idx_t, BITS, LOCK_K>(P, n, skey, ssa, key, sa, lo, hi, 2 * R);
+                multi_lower_bound<idx_t, BITS, LOCK_K, RUNS>(P, n, skey, ssa, key, sa, lo, hi, 2 * R);
                 UNROLL
                 for (uint32_t k = 0; k < LOCK_K; ++k) {
                     TL(rk, tid, gg + k) = key[k];
@@ -1029,7 +1189,7 @@ HD uint32_t passes_for(uint64_t len)
     return tiles <= 1 ? 0u : (uint32_t)(64 - caps_clz64(tiles - 1));
 }
 
-template <typename idx_t, int BITS>
+template <typename idx_t, int BITS, bool RUNS = true>
 DEV_INLINE uint64_t merge_path_split(const uint32_t* __restrict__ P, uint64_t n, const uint64_t* __restrict__ key,
                                      const idx_t* __restrict__ sa, uint64_t A, uint64_t la, uint64_t B, uint64_t lb, uint64_t d)
 {
@@ -1038,13 +1198,13 @@ DEV_INLINE uint64_t merge_path_split(const uint32_t* __restrict__ P, uint64_t n,
     while (lo < hi) {                                      // #elements of A among the first d outputs
         const uint64_t mid = (lo + hi) >> 1;
         const uint64_t ia = A + mid, ib = B + (d - 1 - mid);
-        if (suffix_less<BITS>(P, n, key[ia], (uint64_t)sa[ia], key[ib], (uint64_t)sa[ib])) lo = mid + 1;
+        if (suffix_less<BITS, RUNS>(P, n, key[ia], (uint64_t)sa[ia], key[ib], (uint64_t)sa[ib])) lo = mid + 1;
         else hi = mid;
     }
     return lo;
 }
 
-template <typename idx_t, int BITS>
+template <typename idx_t, int BITS, bool RUNS>
 GLOBAL_FN LAUNCH_BOUNDS(256) merge_partition_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
                                                     uint64_t R, uint64_t single_la, uint32_t skip_finished, uint32_t need_lcp,
                                                     const uint64_t* __restrict__ key, const idx_t* __restrict__ sa,
@@ -1067,8 +1227,8 @@ GLOBAL_FN LAUNCH_BOUNDS(256) merge_partition_kernel(KCTX SegDesc sd, const uint3
                 const uint64_t tot = pr.la + pr.lb;
                 const uint64_t d1 = pr.d0 + TILE_E < tot ? pr.d0 + TILE_E : tot;
                 const uint64_t A = pr.a0, B = pr.a0 + pr.la;
-                const uint64_t i0 = merge_path_split<idx_t, BITS>(P, n, key, sa, A, pr.la, B, pr.lb, pr.d0);
-                const uint64_t i1 = d1 < tot ? merge_path_split<idx_t, BITS>(P, n, key, sa, A, pr.la, B, pr.lb, d1) : pr.la;
+                const uint64_t i0 = merge_path_split<idx_t, BITS, RUNS>(P, n, key, sa, A, pr.la, B, pr.lb, pr.d0);
+                const uint64_t i1 = d1 < tot ? merge_path_split<idx_t, BITS, RUNS>(P, n, key, sa, A, pr.la, B, pr.lb, d1) : pr.la;
                 const uint64_t j0 = pr.d0 - i0, j1 = d1 - i1;
                 d.srcA = A + i0;
                 d.srcB = B + j0;
@@ -1086,7 +1246,7 @@ GLOBAL_FN LAUNCH_BOUNDS(256) merge_partition_kernel(KCTX SegDesc sd, const uint3
     PAR(tid) { if (tid == 0 && moved && acc[0]) ATOMIC_ADD_U64(moved, acc[0]); }
 }
 
-template <typename idx_t, int BITS>
+template <typename idx_t, int BITS, bool RUNS>
 GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) merge_pass_kernel(KCTX const TileDesc* __restrict__ desc, uint32_t n_tiles,
                                                    const uint32_t* __restrict__ P, uint64_t n,
                                                    const uint64_t* __restrict__ in_key, const idx_t* __restrict__ in_sa,
@@ -1163,7 +1323,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) merge_pass_kernel(KCTX co
                         hi[k] = fromA ? cnt : na;
                     }
                 }
-                multi_lower_bound<idx_t, BITS, LOCK_K>(P, n, skey, ssa, key, sa, lo, hi, top);
+                multi_lower_bound<idx_t, BITS, LOCK_K, RUNS>(P, n, skey, ssa, key, sa, lo, hi, top);
                 UNROLL
                 for (uint32_t k = 0; k < LOCK_K; ++k) {
                     // slot = own rank + rank in the other piece = (x - na) + lo for both pieces
@@ -1200,10 +1360,10 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) merge_pass_kernel(KCTX co
                         const uint64_t key = skey[x];
                         const uint64_t sa = (uint64_t)ssa[x];
                         uint64_t l = 0;
-                        if (x) l = pair_lcp<BITS>(P, n, skey[x - 1], (uint64_t)ssa[x - 1], key, sa);
+                        if (x) l = pair_lcp<BITS, RUNS>(P, n, skey[x - 1], (uint64_t)ssa[x - 1], key, sa);
                         else {
-                            if (hA) l = pair_lcp<BITS>(P, n, hAk, hAs, key, sa);
-                            if (hB) { const uint64_t l2 = pair_lcp<BITS>(P, n, hBk, hBs, key, sa); l = l2 > l ? l2 : l; }
+                            if (hA) l = pair_lcp<BITS, RUNS>(P, n, hAk, hAs, key, sa);
+                            if (hB) { const uint64_t l2 = pair_lcp<BITS, RUNS>(P, n, hBk, hBs, key, sa); l = l2 > l ? l2 : l; }
                         }
                         out_key[d.dst + x] = key;
                         out_sa[d.dst + x] = (idx_t)sa;

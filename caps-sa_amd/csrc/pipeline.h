@@ -135,7 +135,7 @@ Plan<idx_t> make_plan(uint64_t n, uint64_t p_arg, char* base)
     pl.bk.nb_cap = BucketBufs::bucket_bound(nn, p);
     pl.bk.tile_cap = nn / TILE_E + pl.bk.nb_cap + 2;
     pl.tile_cap = pl.bk.tile_cap;
-    pl.P = ar.take<uint32_t>(packed_words(nn, 8));
+    pl.P = ar.take<uint32_t>(text_alloc_words(nn));
     for (ElemBuf<idx_t>* b : {&pl.A, &pl.B}) {
         b->key = ar.take<uint64_t>(nn);
         const size_t at = ar.off - nn * sizeof(uint64_t);
@@ -212,6 +212,41 @@ inline int build_lut(const uint32_t present[8], uint8_t lut[256])
     return 8;
 }
 
+// Launch of a kernel that exists with and without the run-table comparators (text.h): the build
+// for the text prepared last (Backend::long_runs).  targs: the leading template arguments, in parentheses.
+#define CAPS_UNPAREN(...) __VA_ARGS__
+#define CAPS_LAUNCH_RUNS(kernel, targs, grid, block, be, ...)                                            \
+    do {                                                                                                 \
+        if ((be).long_runs) CAPS_LAUNCH((kernel<CAPS_UNPAREN targs, true>), grid, block, be, __VA_ARGS__); \
+        else CAPS_LAUNCH((kernel<CAPS_UNPAREN targs, false>), grid, block, be, __VA_ARGS__);             \
+    } while (0)
+
+// Run table of the packed text (text.h): per-block values, then -- only if some periodic stretch
+// spans two whole blocks, decided on the device -- the three-kernel suffix scan that resolves them.
+inline void build_run_table(Backend& be, uint32_t* P, uint64_t n, int bits)
+{
+    const uint64_t entries = run_table_entries(n, bits);
+    const uint32_t chunks = (uint32_t)run_table_chunks(entries);
+    uint64_t* R = run_table_mut(P, n);
+    uint64_t* flag = R - 2;
+    uint64_t* longest = R - 1;
+    uint64_t* head = R + run_table_entries(n, 8);
+    uint64_t* carry = head + run_table_chunks(run_table_entries(n, 8));
+    be.memset(flag, 0, 2 * sizeof(uint64_t));
+    const uint64_t want = (entries + 255) / 256;
+    const uint32_t grid = (uint32_t)(want < 16384 ? want : 16384);
+    if (bits == 2) CAPS_LAUNCH(run_blocks_kernel<2>, grid, 256, be, (const uint32_t*)P, n, entries, R, flag);
+    else CAPS_LAUNCH(run_blocks_kernel<8>, grid, 256, be, (const uint32_t*)P, n, entries, R, flag);
+    CAPS_LAUNCH(run_chunk_heads_kernel, chunks, RUN_NT, be, (const uint64_t*)R, entries, (const uint64_t*)flag, head);
+    CAPS_LAUNCH(run_carry_kernel, 1, 1024, be, (const uint64_t*)head, chunks, (const uint64_t*)flag, carry);
+    CAPS_LAUNCH(run_resolve_kernel, chunks, RUN_NT, be, R, entries, (const uint64_t*)flag, (const uint64_t*)carry,
+                (uint32_t)(64 / bits), longest);
+    uint64_t longest_host = 0;
+    be.d2h(&longest_host, longest, sizeof longest_host);
+    be.sync();
+    be.long_runs = longest_host >= RUN_LONG;
+}
+
 // Alphabet scan + packing of the raw device text dT into P (input
 // preparation on device).  present_dev: 8 x u32, lut_dev: 256 bytes.  Returns BITS.
 inline int prepare_text(Backend& be, const uint8_t* dT, uint64_t n, uint32_t* P, uint32_t* present_dev, uint8_t* lut_dev)
@@ -233,7 +268,7 @@ inline int prepare_text(Backend& be, const uint8_t* dT, uint64_t n, uint32_t* P,
     const uint32_t grid = (uint32_t)(want < 65536 ? want : 65536);
     if (bits == 2) CAPS_LAUNCH(pack_kernel<2>, grid, 256, be, dT, n, (const uint8_t*)lut_dev, P, n_words);
     else CAPS_LAUNCH(pack_kernel<8>, grid, 256, be, dT, n, (const uint8_t*)lut_dev, P, n_words);
-    be.sync();                                    // lut[] lives on this stack frame
+    build_run_table(be, P, n, bits);              // ends with a sync (lut[] lives on this stack frame)
     return bits;
 }
 
@@ -470,12 +505,12 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
     if (from_text) {
         CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, sd, P, n, o.text_base, lcp_mode, 0u,
                     (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, seg_map, redo);
-        CAPS_LAUNCH((tile_sort_general_kernel<idx_t, BITS, true>), ggrid, TILE_NT, be, sd, P, n, o.text_base, lcp_mode, 0u,
+        CAPS_LAUNCH_RUNS(tile_sort_general_kernel, (idx_t, BITS, true), ggrid, TILE_NT, be, sd, P, n, o.text_base, lcp_mode, 0u,
                     (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo);
     } else {
         CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
                     in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, redo);
-        CAPS_LAUNCH((tile_sort_general_kernel<idx_t, BITS, false>), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
+        CAPS_LAUNCH_RUNS(tile_sort_general_kernel, (idx_t, BITS, false), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
                     in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo);
     }
     BackendEvent t1 = be.record();
@@ -484,11 +519,11 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
     const uint32_t grid = n_tiles < be.persistent_blocks() ? n_tiles : be.persistent_blocks();
     ElemBuf<idx_t> a = cur, b = oth;
     for (uint64_t R = TILE_E; R < max_len; R *= 2) {
-        CAPS_LAUNCH((merge_partition_kernel<idx_t, BITS>), (n_tiles + 255) / 256, 256, be, sd, P, n, R, ~0ull, skip ? 1u : 0u,
+        CAPS_LAUNCH_RUNS(merge_partition_kernel, (idx_t, BITS), (n_tiles + 255) / 256, 256, be, sd, P, n, R, ~0ull, skip ? 1u : 0u,
                     lcp_mode, (const uint64_t*)a.key, (const idx_t*)a.sa, desc,
                     o.pass_counters ? o.pass_counters + r.passes : (uint64_t*)nullptr);
         BackendEvent m0 = be.record();
-        CAPS_LAUNCH((merge_pass_kernel<idx_t, BITS>), grid, TILE_NT, be, (const TileDesc*)desc, n_tiles, P, n,
+        CAPS_LAUNCH_RUNS(merge_pass_kernel, (idx_t, BITS), grid, TILE_NT, be, (const TileDesc*)desc, n_tiles, P, n,
                     (const uint64_t*)a.key, (const idx_t*)a.sa, b.key, b.sa, b.lcp);
         BackendEvent m1 = be.record();
         if (o.merge_clock) { o.merge_clock->spans.push_back({m0, m1}); o.merge_clock->elems.push_back(n_elems); }
@@ -716,6 +751,7 @@ private:
 
         if (st) {
             st->bits_per_char = BITS;
+            st->long_runs = be_.long_runs ? 1u : 0u;
             st->ppp = pl_.ppp;
             st->max_partition = max_part;
             st->merge_passes_phase1 = passes1;

@@ -65,7 +65,7 @@ public:
             // for the larger of the two with 25 % slack for the imbalance of the partition ownership.
             const uint64_t share = n / (uint64_t)world + 1;
             cap_ = std::max<uint64_t>(local_n_, share + share / 4 + 16 * TILE_E);
-            P_ = get<uint32_t>(packed_words(n, 8));
+            P_ = get<uint32_t>(text_alloc_words(n));
             present_ = get<uint32_t>(8);
             lut_ = get<uint8_t>(256);
             A_ = elems(cap_);

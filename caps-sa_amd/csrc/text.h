@@ -44,27 +44,147 @@ HD uint64_t window64(const uint32_t* __restrict__ P, uint64_t pos)
     return (((x0 << 32) | x1) << sh) | ((x2 << sh) >> 32);
 }
 
+// ---------------------------------------------------------------------------------
+// Run table: constant-time skipping of periodic stretches ("runs") in deep comparisons.
+//
+// Two suffixes inside one long run of a short period d (a^n, an N-block, a poly-A tail,
+// (AC)^k ...) share a prefix as long as the run itself, and every comparison between
+// them walks it window by window: Theta(n^2) on T = a^n, for the reference
+// (include/Suffix_Array.hpp:195-241 scans char blocks) as for a plain window loop.
+// The table removes that: the text is cut into aligned BLOCKS of KCH chars (one 64-bit
+// word of P); entry R[b] of a block whose content has a smallest period d <= KCH/2 is
+//     (d << 56) | e,   e = first position q >= KCH*b + d with q == n or T[q] != T[q-d]
+// i.e. where the d-periodic stretch through the block ends; R[b] = 0 for an aperiodic
+// block or one that reaches past the text.  A comparison that has seen 2*KCH equal chars
+// U at positions x and y looks up the aligned blocks inside them: if both have the same
+// period d and U itself is d-periodic, then d is the smallest period of U, T is d-periodic
+// on [x, e_x) and on [y, e_y) with the same first d chars, so the two suffixes agree on
+// min(e_x - x, e_y - y) more chars -- and if the two ends differ, the very next char
+// differs (one stretch goes on, the other breaks).  Exact, never heuristic.
+//
+// The table lives behind the packed text in the same allocation, so that everything that
+// holds (P, n) can reach it: u64 words [flag | longest stretch | R[0 .. n/KCH + 2) | construction
+// scratch].  The kernels in which deep ties are frequent exist in two builds (template bool RUNS):
+// with the table, and with the plain window loop for texts whose longest stretch is below RUN_LONG
+// chars (there the table cannot save much and its code costs registers: -20 % on repeat-rich DNA).
+// ---------------------------------------------------------------------------------
+constexpr uint64_t RUN_LINKED = ~0ull;                       // build-time marker: "same value as the next block"
+constexpr uint64_t RUN_POS_MASK = (1ull << 56) - 1;
+constexpr uint64_t RUN_LONG = 1024;         // chars; below this the plain comparators are used
+constexpr uint32_t RUN_NT = 256;            // threads per workgroup of the run-table kernels
+constexpr uint32_t RUN_PER = 8;             // consecutive blocks per thread
+constexpr uint32_t RUN_CHUNK = RUN_NT * RUN_PER;
+
+HD uint64_t run_table_offset_words(uint64_t n) { return (packed_words(n, 8) + 1) & ~1ull; }   // u32 words from P
+HD uint64_t run_table_entries(uint64_t n, int bits) { return n / (64 / bits) + 2; }
+HD uint64_t run_table_chunks(uint64_t entries) { return (entries + RUN_CHUNK - 1) / RUN_CHUNK; }
+// u32 words of one text allocation: packed text + flag + run table (sized for BITS = 8, the larger
+// case) + the two per-chunk arrays of its construction
+HD uint64_t text_alloc_words(uint64_t n)
+{
+    const uint64_t e = run_table_entries(n, 8);
+    return run_table_offset_words(n) + 2 * (2 + e + 2 * run_table_chunks(e));
+}
+HD const uint64_t* run_table(const uint32_t* P, uint64_t n)
+{
+    return reinterpret_cast<const uint64_t*>(P + run_table_offset_words(n)) + 2;
+}
+HD uint64_t* run_table_mut(uint32_t* P, uint64_t n) { return reinterpret_cast<uint64_t*>(P + run_table_offset_words(n)) + 2; }
+
+// Smallest period d in [1, KCH/2] of the KCH chars of block word w; 0 if there is none.
+template <int BITS> HD uint32_t block_period(uint64_t w)
+{
+    constexpr uint32_t KCH = TextTraits<BITS>::KCH;
+    for (uint32_t d = 1; d <= KCH / 2; ++d) {
+        const uint32_t sh = d * BITS;
+        if (((w ^ (w << sh)) >> sh) == 0) return d;
+    }
+    return 0;
+}
+
+// Are the 2*KCH chars hi:lo d-periodic (1 <= d <= KCH/2)?
+template <int BITS> HD bool periodic128(uint64_t hi, uint64_t lo, uint32_t d)
+{
+    const uint32_t sh = d * BITS;                                 // BITS .. 32
+    return hi == ((hi << sh) | (lo >> (64 - sh))) && ((lo ^ (lo << sh)) >> sh) == 0;
+}
+
+// The common scan of the deep comparisons: suffixes a != b (both < n) agree on their first
+// `l` chars; advance l to the first char where they differ, or to maxlen = the length of the
+// shorter one.  On return with l < maxlen, wa / wb are windows at a + l' / b + l' (l' <= l)
+// that contain the differing char.  RUNS = false: plain window loop (kernels in which a tie can
+// only involve a handful of suffixes, see tile_sort_kernel).  RUNS = true: the first RUN_ENTER
+// windows are compared plainly (short ties: the common case on genomes); after that two windows
+// are taken per step and the run table is consulted.
+#ifndef CAPS_RUN_ENTER
+#define CAPS_RUN_ENTER 3
+#endif
+constexpr uint32_t RUN_ENTER = CAPS_RUN_ENTER;
+template <int BITS, bool RUNS>
+HD uint64_t deep_scan(const uint32_t* __restrict__ P, uint64_t n, uint64_t a, uint64_t b, uint64_t l, uint64_t maxlen,
+                      uint64_t& wa, uint64_t& wb)
+{
+    constexpr uint32_t KCH = TextTraits<BITS>::KCH;
+#ifdef CAPS_NO_RUN_TABLE       /* measurement variant: every comparator is the plain window loop */
+    constexpr bool plain = true;
+#else
+    constexpr bool plain = !RUNS;
+#endif
+    if (plain) {
+        for (; l < maxlen; l += KCH) {
+            wa = window64<BITS>(P, a + l);
+            wb = window64<BITS>(P, b + l);
+            if (wa != wb) return l + (uint32_t)caps_clz64(wa ^ wb) / BITS;
+        }
+        return maxlen;
+    }
+    for (uint32_t k = 0; k < RUN_ENTER && l < maxlen; ++k, l += KCH) {
+        wa = window64<BITS>(P, a + l);
+        wb = window64<BITS>(P, b + l);
+        if (wa != wb) return l + (uint32_t)caps_clz64(wa ^ wb) / BITS;
+    }
+    if (l >= maxlen) return maxlen;
+    const uint64_t* __restrict__ R = run_table(P, n);
+    while (l < maxlen) {
+        const uint64_t x = a + l, y = b + l;
+        wa = window64<BITS>(P, x);
+        wb = window64<BITS>(P, y);
+        if (wa != wb) return l + (uint32_t)caps_clz64(wa ^ wb) / BITS;
+        const uint64_t hi = wa;
+        wa = window64<BITS>(P, x + KCH);
+        wb = window64<BITS>(P, y + KCH);
+        if (wa != wb) return l + KCH + (uint32_t)caps_clz64(wa ^ wb) / BITS;
+        uint64_t step = 2 * KCH;
+        const uint64_t rx = R[(x + KCH - 1) / KCH];
+        if (rx) {
+            const uint64_t ry = R[(y + KCH - 1) / KCH];
+            const uint32_t d = (uint32_t)(rx >> 56);
+            if ((uint32_t)(ry >> 56) == d && periodic128<BITS>(hi, wa, d)) {
+                const uint64_t ex = (rx & RUN_POS_MASK) - x, ey = (ry & RUN_POS_MASK) - y;
+                step = ex < ey ? ex : ey;                              // >= KCH: always progress
+            }
+        }
+        l += step;
+    }
+    return maxlen;
+}
+
 // lcp(suffix a, suffix b) given that their first `from` chars are known equal
 // (from is a multiple of KCH or anything <= the true lcp).  Exact, clamped to the
 // length of the shorter suffix.
-template <int BITS>
+template <int BITS, bool RUNS = true>
 HD uint64_t deep_lcp(const uint32_t* __restrict__ P, uint64_t n, uint64_t a, uint64_t b, uint64_t from)
 {
-    constexpr uint32_t KCH = TextTraits<BITS>::KCH;
     if (a >= n || b >= n) return 0;              // corrupt index: do not scan
     const uint64_t maxlen = n - (a > b ? a : b);
-    uint64_t l = from;
-    while (l < maxlen) {
-        const uint64_t x = window64<BITS>(P, a + l) ^ window64<BITS>(P, b + l);
-        if (x) { l += (uint32_t)caps_clz64(x) / BITS; break; }
-        l += KCH;
-    }
+    uint64_t wa, wb;
+    const uint64_t l = deep_scan<BITS, RUNS>(P, n, a, b, from, maxlen, wa, wb);
     return l < maxlen ? l : maxlen;
 }
 
 // lcp of two distinct suffixes from their keys, falling back to the text when the
 // keys are equal.
-template <int BITS>
+template <int BITS, bool RUNS = true>
 HD uint64_t pair_lcp(const uint32_t* __restrict__ P, uint64_t n, uint64_t ka, uint64_t a, uint64_t kb, uint64_t b)
 {
     const uint64_t x = ka ^ kb;
@@ -73,34 +193,55 @@ HD uint64_t pair_lcp(const uint32_t* __restrict__ P, uint64_t n, uint64_t ka, ui
         const uint64_t l = (uint32_t)caps_clz64(x) / BITS;
         return l < maxlen ? l : maxlen;
     }
-    return deep_lcp<BITS>(P, n, a, b, TextTraits<BITS>::KCH);
+    return deep_lcp<BITS, RUNS>(P, n, a, b, TextTraits<BITS>::KCH);
 }
 
 // Order of two distinct suffixes whose KEYS are equal: continue in 64-bit windows of the
 // packed text (the rare path on low-LCP texts, the common one on repeats).  Inlined: a call
 // inside the merge kernels would force the registers that hold the prefetched next tile to
 // be spilled for the whole rank phase.
-template <int BITS>
+template <int BITS, bool RUNS = true>
 HD bool suffix_less_tie(const uint32_t* __restrict__ P, uint64_t n, uint64_t a, uint64_t b)
 {
-    constexpr uint32_t KCH = TextTraits<BITS>::KCH;
     if (a >= n || b >= n) return a > b;          // never loop on a corrupt index (keeps a bad input from hanging the GPU)
     const uint64_t maxlen = n - (a > b ? a : b);
-    for (uint64_t l = KCH; l < maxlen; l += KCH) {
+    uint64_t wa = 0, wb = 0;
+    const uint64_t l = deep_scan<BITS, RUNS>(P, n, a, b, TextTraits<BITS>::KCH, maxlen, wa, wb);
+    if (l < maxlen) return wa < wb;              // the windows that hold the first differing char
+    return a > b;                                // one is a prefix of the other: the shorter first
+}
+
+// Bounded tie-break for tile_sort_kernel (the hot kernel keeps the cheap plain loop and its
+// register budget): at most TIE_WINDOWS windows past the key.  1 / 0 = a sorts before b / not;
+// 2 = still equal after that -- the tile is then handed to tile_sort_general_kernel, whose
+// comparator uses the run table.
+#ifndef CAPS_TIE_WINDOWS
+#define CAPS_TIE_WINDOWS 64
+#endif
+constexpr uint32_t TIE_WINDOWS = CAPS_TIE_WINDOWS;
+template <int BITS>
+HD uint32_t suffix_less_tie_bounded(const uint32_t* __restrict__ P, uint64_t n, uint64_t a, uint64_t b)
+{
+    constexpr uint32_t KCH = TextTraits<BITS>::KCH;
+    if (a >= n || b >= n) return a > b ? 1u : 0u;
+    const uint64_t maxlen = n - (a > b ? a : b);
+    uint64_t l = KCH;
+    for (uint32_t k = 0; k < TIE_WINDOWS && l < maxlen; ++k, l += KCH) {
         const uint64_t wa = window64<BITS>(P, a + l), wb = window64<BITS>(P, b + l);
-        if (wa != wb) return wa < wb;
+        if (wa != wb) return wa < wb ? 1u : 0u;
     }
-    return a > b;
+    if (l >= maxlen) return a > b ? 1u : 0u;
+    return 2u;
 }
 
 // Strict total order on suffixes: true iff suffix a sorts before suffix b.
 // (a == b -> false.)  Shorter suffix first when one is a prefix of the other.
-template <int BITS>
+template <int BITS, bool RUNS = true>
 HD bool suffix_less(const uint32_t* __restrict__ P, uint64_t n, uint64_t ka, uint64_t a, uint64_t kb, uint64_t b)
 {
     if (ka != kb) return ka < kb;
     if (a == b) return false;
-    return suffix_less_tie<BITS>(P, n, a, b);
+    return suffix_less_tie<BITS, RUNS>(P, n, a, b);
 }
 
 }  // namespace caps

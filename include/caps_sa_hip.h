@@ -43,7 +43,8 @@ typedef struct caps_sa_stats {
     uint32_t ppp;                  /* samples per subarray, src/Suffix_Array.cpp:27 */
     uint32_t bits_per_char;        /* 2 (alphabet <= 4 symbols) or 8 */
     uint32_t merge_passes_phase1, merge_passes_phase2, merge_passes_samples;
-    uint32_t reserved0;
+    uint32_t long_runs;            /* 1: the text holds a periodic stretch (period <= 16 chars) of >= 1024 chars and the
+                                      comparators skipped such stretches through the run table (csrc/text.h) */
     uint64_t max_partition;        /* largest partition (elements) */
     uint64_t workspace_bytes;
     double ms_total;               /* whole build, device-resident interval */

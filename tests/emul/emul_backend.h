@@ -27,6 +27,7 @@ struct BackendEvent { double t = 0; };
 class Backend {
 public:
     void* stream = nullptr;
+    bool long_runs = false;       // the text prepared last holds a periodic stretch >= RUN_LONG chars (text.h): comparators with the run table
     explicit Backend(void* s) : stream(s) {}
     BackendEvent record()
     {

@@ -89,7 +89,7 @@ def test_byte_alphabets_and_signed_order(L, oracle):
 
 def test_deep_lcp_inputs(L, oracle):
     rs = np.random.RandomState(4)
-    n = 100_000                                   # BASELINE config 4 shape (a^n) at a size the quadratic path allows
+    n = 100_000                                   # BASELINE config 5 shape (a^n); full size: test_c5_unary_text_1e8_closed_form
     SA, LCP, _ = L.build(np.full(n, ord("a"), dtype=np.uint8), p=0)
     assert np.array_equal(SA, np.arange(n - 1, -1, -1, dtype=np.uint32))       # SURVEY 0.8 closed form
     assert np.array_equal(LCP, np.arange(n, dtype=np.uint32))
@@ -342,3 +342,84 @@ def test_more_subproblems_than_a_dispatch_has_threads(L, oracle):
     n = 2_913_828
     T = rs.choice(DNA, size=n, p=[0.55, 0.25, 0.15, 0.05])
     _same(L, oracle, T, n // 40, bits=64)
+
+
+# ---- BASELINE config 5 and the run table (csrc/text.h) ------------------------------------------
+def _check_independent(L, T, p, bits=32, long_runs=None):
+    """GPU build vs tests/sa_check.py (prefix doubling: not quadratic on repeats like the oracle)."""
+    from sa_check import sa_lcp
+    SA, LCP, st = L.build(T, p=p, idx_bits=bits)
+    SAo, LCPo = sa_lcp(T, bits)
+    assert np.array_equal(SA, SAo), f"SA mismatch n={T.size} p={p}"
+    assert np.array_equal(LCP, LCPo), f"LCP mismatch n={T.size} p={p}"
+    if long_runs is not None:
+        assert st["long_runs"] == int(long_runs)
+
+
+def test_c5_unary_text_1e8_closed_form(L):
+    """BASELINE config 5 at FULL size: T = 'a'^1e8, u32, default subproblem count.  The reference
+    (and a plain window loop) is Theta(n^2) here; SA[i] = n-1-i, LCP[i] = i."""
+    import torch
+    n = 100_000_000
+    T = torch.full((n,), ord("a"), dtype=torch.uint8, device="cuda")
+    SA = torch.empty(n, dtype=torch.int32, device="cuda")
+    LCP = torch.empty(n, dtype=torch.int32, device="cuda")
+    st = L.build_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr(), p=0)
+    assert st["p_eff"] == 8192 and st["long_runs"] == 1
+    ar = torch.arange(n, device="cuda", dtype=torch.int32)
+    assert bool((SA == (n - 1 - ar)).all())
+    assert bool((LCP == ar).all())
+    # u64 indices, smaller
+    n = 5_000_000
+    SA64 = torch.empty(n, dtype=torch.int64, device="cuda")
+    LCP64 = torch.empty(n, dtype=torch.int64, device="cuda")
+    L.build_device(T.data_ptr(), n, SA64.data_ptr(), LCP64.data_ptr(), p=100, idx_bits=64)
+    ar = torch.arange(n, device="cuda", dtype=torch.int64)
+    assert bool((SA64 == (n - 1 - ar)).all()) and bool((LCP64 == ar).all())
+
+
+def test_periodic_stretches_vs_independent_construction(L):
+    rs = np.random.RandomState(21)
+    b = lambda s: np.frombuffer(s, dtype=np.uint8)                              # noqa: E731
+    _check_independent(L, np.full(300_001, 0x80, np.uint8), 0, long_runs=True)   # code 0 = end-of-text padding
+    _check_independent(L, np.tile(b(b"AC"), 150_000), 3, long_runs=True)
+    _check_independent(L, np.tile(rs.choice(DNA, size=16), 20_000), 5, long_runs=True)
+    _check_independent(L, np.tile(rs.choice(DNA, size=17), 3_000), 5, long_runs=False)
+    _check_independent(L, np.tile(b(b"abcd"), 60_000), 4, long_runs=True)
+    parts = [np.full(50_000, ord("G"), np.uint8), rs.choice(DNA, size=70_000), np.tile(b(b"ACG"), 30_000), rs.choice(DNA, size=100),
+             np.full(90_000, ord("G"), np.uint8), rs.choice(DNA, size=3), np.tile(b(b"ACG"), 20_000), np.full(40_000, ord("A"), np.uint8)]
+    _check_independent(L, np.concatenate(parts), 64, long_runs=True)
+    _check_independent(L, np.concatenate(parts[::-1]), 0, bits=64, long_runs=True)
+    short = [rs.choice(DNA, size=300_000), np.full(700, ord("T"), np.uint8), rs.choice(DNA, size=200_000), np.tile(b(b"GA"), 400),
+             rs.choice(DNA, size=1500), np.full(900, ord("T"), np.uint8)]
+    _check_independent(L, np.concatenate(short), 50, long_runs=False)
+    for d in (1, 2, 3, 5, 8, 15, 16):                                              # stretch ends at every block offset
+        unit = rs.choice(DNA, size=d)
+        while d > 1 and len(set(unit.tolist())) == 1:
+            unit = rs.choice(DNA, size=d)
+        parts = []
+        for off in range(0, 33, 3):
+            parts += [rs.choice(DNA, size=40 + off), np.tile(unit, (1100 + 7 * off) // d + 1)[:1100 + 7 * off]]
+        _check_independent(L, np.concatenate(parts), 3, long_runs=True)
+
+
+def test_n_block_like_runs_in_256m_dna_device(L):
+    """Random DNA with a 1e6-long single-letter block (the CLI maps N to G: src/main.cpp:61-68),
+    tandem arrays and a run at the very end; exact device verifier (its own scan of the raw bytes
+    is linear in the sum of LCPs: ~5e11 char steps here)."""
+    import torch
+    n = 268_435_457
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda")
+    T = lut[torch.randint(0, 4, (n,), device="cuda", generator=g, dtype=torch.int64)]
+    T[50_000_000:51_000_000] = ord("G")
+    T[120_000_003:120_200_003] = torch.tensor(list(b"AC"), dtype=torch.uint8, device="cuda").repeat(100_000)
+    T[200_000_001:200_030_001] = torch.tensor(list(b"AATCG"), dtype=torch.uint8, device="cuda").repeat(6_000)
+    T[n - 100_000:] = ord("T")
+    SA = torch.empty(n, dtype=torch.int32, device="cuda")
+    LCP = torch.empty(n, dtype=torch.int32, device="cuda")
+    st = L.build_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr(), p=8000)
+    assert st["long_runs"] == 1
+    assert L.verify_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr()) == 0
+    assert int(LCP.max().item()) == 999_999
