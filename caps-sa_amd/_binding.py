@@ -7,6 +7,7 @@ sources (tests/emul/libcaps_sa_emul.so, prefix ``caps_sa_emul_``) through this c
 from __future__ import annotations
 
 import ctypes
+import weakref
 
 import numpy as np
 
@@ -81,7 +82,7 @@ class ShardInfo(ctypes.Structure):
 SHARD_EXPORTS = ["shard_create", "shard_destroy", "shard_info", "shard_phase1", "shard_pivots", "shard_collate",
                  "shard_phase2", "shard_last_sa", "shard_fix_first_lcp"]
 
-EXPORTS = ["device_count", "last_error", "version", "workspace_bytes"] + SHARD_EXPORTS + [
+EXPORTS = ["device_count", "last_error", "version", "workspace_bytes", "release_cache", "host_alloc", "host_free"] + SHARD_EXPORTS + [
     f"{name}_{sfx}"
     for sfx in ("u32", "u64")
     for name in ("build", "build_device", "verify_device", "sort_suffixes", "sort_segments", "merge", "upper_bound", "lcp")
@@ -110,6 +111,12 @@ class CapsLib:
         f("version").restype = ctypes.c_char_p
         f("workspace_bytes").restype = _ci
         f("workspace_bytes").argtypes = [_u64, _u64, _ci, ctypes.POINTER(_u64)]
+        f("release_cache").restype = None
+        f("release_cache").argtypes = []
+        f("host_alloc").restype = _vp
+        f("host_alloc").argtypes = [_u64]
+        f("host_free").restype = None
+        f("host_free").argtypes = [_vp]
         for sfx in ("u32", "u64"):
             f(f"build_{sfx}").restype = _ci
             f(f"build_{sfx}").argtypes = [_vp, _u64, _u64, _u64, _vp, _vp, _ci, ctypes.POINTER(Stats)]
@@ -176,12 +183,29 @@ class CapsLib:
             T = np.frombuffer(bytes(T), dtype=np.uint8)
         return np.ascontiguousarray(T, dtype=np.uint8)
 
-    def build(self, T, p: int = 0, max_context: int = 0, idx_bits: int = 32, device: int = 0):
-        """construct() on host buffers -> (SA, LCP, stats dict)."""
+    def release_cache(self) -> None:
+        """Frees the device memory the host-buffer entry points keep between calls."""
+        self._f("release_cache")()
+
+    def pinned_empty(self, count: int, dtype) -> np.ndarray:
+        """numpy array over page-locked host memory (caps_sa_hip_host_alloc); freed with the array."""
+        dtype = np.dtype(dtype)
+        nbytes = max(1, count * dtype.itemsize)
+        ptr = self._f("host_alloc")(nbytes)
+        if not ptr:
+            raise CapsSaError(-12, (self._f("last_error")() or b"host_alloc failed").decode())
+        buf = (ctypes.c_char * nbytes).from_address(ptr)
+        arr = np.frombuffer(buf, dtype=dtype, count=count)
+        free = self._f("host_free")
+        weakref.finalize(buf, free, ptr)
+        return arr
+
+    def build(self, T, p: int = 0, max_context: int = 0, idx_bits: int = 32, device: int = 0, pinned: bool = False):
+        """construct() on host buffers -> (SA, LCP, stats dict).  pinned: SA / LCP in page-locked memory."""
         T = self._text(T)
         sfx, dt = _sfx(idx_bits)
-        SA = np.empty(T.size, dtype=dt)
-        LCP = np.empty(T.size, dtype=dt)
+        SA = self.pinned_empty(T.size, dt) if pinned else np.empty(T.size, dtype=dt)
+        LCP = self.pinned_empty(T.size, dt) if pinned else np.empty(T.size, dtype=dt)
         st = Stats()
         self._check(self._f(f"build_{sfx}")(T.ctypes.data, T.size, p, max_context, SA.ctypes.data, LCP.ctypes.data,
                                             device, ctypes.byref(st)))

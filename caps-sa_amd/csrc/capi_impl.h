@@ -6,6 +6,7 @@
 #pragma once
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -101,6 +102,34 @@ int build_device(const void* dT, uint64_t n, uint64_t p_arg, uint64_t max_contex
     });
 }
 
+// Device memory of the host-buffer entry points, kept between calls: hipMalloc + hipFree of the
+// text, the result arrays and the workspace cost far more than the build they serve (n = 1e9:
+// 1.2 s against 28 ms).  One grow-only block per process, re-allocated when a larger build or
+// another device asks; released by caps_sa_hip_release_cache() (or at process exit).  Calls of the
+// host-buffer entry points are serialised on it.
+struct HostPathCache {
+    std::mutex mu;
+    int device = -1;
+    char* base = nullptr;
+    size_t bytes = 0;
+};
+inline HostPathCache& host_cache()
+{
+    static HostPathCache c;
+    return c;
+}
+
+inline void release_host_cache_locked(HostPathCache& c)
+{
+    if (c.base) {
+        Backend be(nullptr);
+        be.free(c.base);
+    }
+    c.base = nullptr;
+    c.bytes = 0;
+    c.device = -1;
+}
+
 template <typename idx_t>
 int build_host(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context, idx_t* SA, idx_t* LCP, int device,
                caps_sa_stats* stats)
@@ -109,17 +138,30 @@ int build_host(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context, 
     if (n && (!SA || !LCP)) return fail(CAPS_SA_EINVAL, "null output");
     if (int rc = set_device(device)) return rc;
     return guarded([&]() -> int {
+        HostPathCache& hc = host_cache();
+        std::lock_guard<std::mutex> lock(hc.mu);
         Backend be(nullptr);
-        DevAllocs da(be);
-        uint8_t* dT = da.get<uint8_t>(n);
-        idx_t* dSA = da.get<idx_t>(n);
-        idx_t* dLCP = da.get<idx_t>(n);
+        auto up = [](size_t b) { return (b + 255) & ~size_t(255); };
+        const Plan<idx_t> need = make_plan<idx_t>(n, p_arg, nullptr);
+        const size_t off_sa = up(n ? n : 1), off_lcp = off_sa + up((n ? n : 1) * sizeof(idx_t));
+        const size_t off_ws = off_lcp + up((n ? n : 1) * sizeof(idx_t));
+        const size_t total = off_ws + need.bytes + 512;
+        if (hc.device != device || hc.bytes < total) {
+            release_host_cache_locked(hc);
+            hc.base = static_cast<char*>(be.alloc(total));
+            hc.bytes = total;
+            hc.device = device;
+        }
+        char* base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(hc.base) + 255) & ~uintptr_t(255));
+        uint8_t* dT = reinterpret_cast<uint8_t*>(base);
+        idx_t* dSA = reinterpret_cast<idx_t*>(base + off_sa);
+        idx_t* dLCP = reinterpret_cast<idx_t*>(base + off_lcp);
         BackendEvent h0 = be.record();
         be.h2d(dT, T, n);
         BackendEvent h1 = be.record();
         be.sync();
         caps_sa_stats local;
-        int rc = build_device<idx_t>(dT, n, p_arg, max_context, dSA, dLCP, nullptr, 0, nullptr, &local);
+        int rc = build_device<idx_t>(dT, n, p_arg, max_context, dSA, dLCP, base + off_ws, hc.bytes - off_ws - 256, nullptr, &local);
         if (rc) return rc;
         BackendEvent d0 = be.record();
         be.d2h(SA, dSA, n * sizeof(idx_t));
@@ -425,6 +467,23 @@ extern "C" {
 
 const char* CAPS_API(last_error)(void) { return caps::last_error_ref().c_str(); }
 const char* CAPS_API(version)(void) { return "caps-sa_amd 0.1 (gfx950)"; }
+
+void CAPS_API(release_cache)(void)
+{
+    caps::HostPathCache& hc = caps::host_cache();
+    std::lock_guard<std::mutex> lock(hc.mu);
+    if (hc.device >= 0 && caps::set_device(hc.device) != CAPS_SA_OK) return;
+    caps::release_host_cache_locked(hc);
+}
+
+void* CAPS_API(host_alloc)(uint64_t bytes)
+{
+    void* p = nullptr;
+    caps::guarded([&]() -> int { p = caps::Backend::host_alloc(bytes); return CAPS_SA_OK; });
+    return p;
+}
+
+void CAPS_API(host_free)(void* p) { caps::Backend::host_free(p); }
 
 int CAPS_API(workspace_bytes)(uint64_t n, uint64_t subproblem_count, int idx_bytes, uint64_t* bytes)
 {

@@ -60,6 +60,14 @@ public:
         return p;
     }
     void free(void* p) { if (p) (void)hipFree(p); }
+    // page-locked host memory (result arrays of the class mirror: D2H at link rate instead of through pageable staging)
+    static void* host_alloc(size_t bytes)
+    {
+        void* p = nullptr;
+        CAPS_HIP(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault));
+        return p;
+    }
+    static void host_free(void* p) { if (p) (void)hipHostFree(p); }
     void memset(void* d, int v, size_t bytes) { CAPS_HIP(hipMemsetAsync(d, v, bytes, stream)); }
     void h2d(void* d, const void* h, size_t bytes) { if (bytes) CAPS_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, stream)); }
     void d2h(void* h, const void* d, size_t bytes) { if (bytes) CAPS_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, stream)); }

@@ -72,6 +72,23 @@ int caps_sa_hip_device_count(void);
 const char* caps_sa_hip_last_error(void);
 const char* caps_sa_hip_version(void);
 
+/*
+ * The host-buffer entry points (caps_sa_hip_build_*) keep their device memory (text, SA, LCP,
+ * workspace) between calls -- allocating and freeing tens of GB costs far more than a build.
+ * One grow-only block per process; this releases it.  (The reference frees everything in
+ * clean_up() / the destructor, src/Suffix_Array.cpp:42-45,455-459; a caller that wants that
+ * behaviour calls this after construct().)
+ */
+void caps_sa_hip_release_cache(void);
+
+/*
+ * Page-locked host memory for SA / LCP buffers (the reference mallocs them in its constructor,
+ * src/Suffix_Array.cpp:20-21).  Results land in such buffers at the PCIe link rate; pageable
+ * buffers work too, slower.  Returns NULL on failure (caps_sa_hip_last_error()).
+ */
+void* caps_sa_hip_host_alloc(uint64_t bytes);
+void caps_sa_hip_host_free(void* p);
+
 /* Device workspace a build of n suffixes needs (bytes). */
 int caps_sa_hip_workspace_bytes(uint64_t n, uint64_t subproblem_count, int idx_bytes, uint64_t* bytes);
 

@@ -44,6 +44,8 @@ public:
         return p;
     }
     void free(void* p) { std::free(p); }
+    static void* host_alloc(size_t bytes) { return std::malloc(bytes ? bytes : 1); }
+    static void host_free(void* p) { std::free(p); }
     void memset(void* d, int v, size_t bytes) { std::memset(d, v, bytes); }
     void h2d(void* d, const void* h, size_t bytes) { std::memcpy(d, h, bytes); }
     void d2h(void* h, const void* d, size_t bytes) { std::memcpy(h, d, bytes); }

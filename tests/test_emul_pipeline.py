@@ -194,3 +194,17 @@ def test_small_tiles_u64_and_segments(oracle):
     seg = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
     idx = rs.permutation(70000)[:int(seg[-1])].astype(np.uint32)
     _check_segments(E, oracle, T, idx, seg)
+
+
+def test_host_entry_point_reuses_and_regrows_its_device_block(oracle):
+    """caps_sa_*_build_* keep one grow-only device block between calls (capi_impl.h: HostPathCache)."""
+    E = emul()
+    rs = np.random.RandomState(12)
+    for n, p, bits in [(50000, 4, 32), (3000, 2, 32), (120000, 9, 64), (70000, 0, 32)]:
+        _same(E, oracle, rs.choice(DNA, size=n), p, bits=bits)
+    E.release_cache()
+    E.release_cache()                                 # idempotent
+    _same(E, oracle, rs.choice(DNA, size=20000), 3)
+    a = E.pinned_empty(1000, np.uint32)               # host_alloc / host_free round trip
+    a[:] = 7
+    assert int(a.sum()) == 7000

@@ -423,3 +423,16 @@ def test_n_block_like_runs_in_256m_dna_device(L):
     assert st["long_runs"] == 1
     assert L.verify_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr()) == 0
     assert int(LCP.max().item()) == 999_999
+
+
+def test_host_entry_point_cache_and_pinned_results(L, oracle):
+    """The host-buffer entry point keeps and re-grows its device block; page-locked result arrays."""
+    rs = np.random.RandomState(31)
+    L.release_cache()
+    for n, p, bits in [(500_000, 40, 32), (3000, 2, 32), (1_200_000, 9, 64), (700_000, 0, 32)]:
+        _same(L, oracle, rs.choice(DNA, size=n), p, bits=bits)
+    L.release_cache()
+    T = rs.choice(DNA, size=300_000)
+    SA, LCP, _ = L.build(T, p=7, pinned=True)
+    SAo, LCPo = oracle.build_sa_lcp(T, p=7)
+    assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo)
