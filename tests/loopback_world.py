@@ -1,0 +1,68 @@
+"""A whole world of shards in ONE process: every rank's Shard lives on the same device and the
+collectives of caps_sa_dist.build_sharded are replaced by tensor copies.  RCCL cannot put two
+ranks on one GPU, and a test box has one GPU: this is how the shard KERNELS are exercised at
+world sizes > 1 on real hardware (the collectives themselves: tests/test_dist_gloo.py on CPU,
+world size 1 over RCCL in test_gpu_parity.py, N = 2, 4, 8 in the driver's scaling run)."""
+import numpy as np
+import torch
+
+
+def build_world(lib, T: torch.Tensor, p: int, world: int, idx_bits: int = 32):
+    """Returns (SA, LCP) of the whole text, concatenated from the ranks' slices."""
+    from caps_sa_dist import ShardBuffers, _idx_dtype
+    n = T.numel()
+    dev, dt = T.device, _idx_dtype(idx_bits)
+    stream = torch.cuda.current_stream().cuda_stream if dev.type == "cuda" else 0
+    shards = [lib.shard(T.data_ptr(), n, p, idx_bits, r, world, stream) for r in range(world)]
+    try:
+        infos = [s.info() for s in shards]
+        P = infos[0]["p"]
+        bufs = [ShardBuffers(i, dev, dt) for i in infos]
+        for s, B in zip(shards, bufs):
+            s.phase1(B.sk.data_ptr(), B.ss.data_ptr())
+        all_k = torch.cat([B.sk[:i["m_local"]] for B, i in zip(bufs, infos)])          # all_gather(samples)
+        all_s = torch.cat([B.ss[:i["m_local"]] for B, i in zip(bufs, infos)])
+        assert all_k.numel() == infos[0]["m_total"]
+        for s, B in zip(shards, bufs):
+            s.pivots(all_k.data_ptr(), all_s.data_ptr(), B.sizes.data_ptr())
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        all_sizes_h = torch.stack([B.sizes for B in bufs]).cpu().numpy().astype(np.uint64).reshape(world, P)
+        sc, rc = [], []
+        for s, B in zip(shards, bufs):
+            a, b = s.collate(all_sizes_h, B.send_k.data_ptr(), B.send_s.data_ptr())
+            sc.append([int(x) for x in a])
+            rc.append([int(x) for x in b])
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        for r in range(world):                                                            # all_to_all_v
+            assert [sc[q][r] for q in range(world)] == rc[r], "send/receive counts disagree"
+            ro = 0
+            for q in range(world):
+                so = sum(sc[q][:r])
+                c = sc[q][r]
+                bufs[r].recv_k[ro:ro + c] = bufs[q].send_k[so:so + c]
+                bufs[r].recv_s[ro:ro + c] = bufs[q].send_s[so:so + c]
+                ro += c
+        for s, B in zip(shards, bufs):
+            s.phase2(B.recv_k.data_ptr(), B.recv_s.data_ptr(), B.SA.data_ptr(), B.LCP.data_ptr())
+        lasts = [s.last_sa() for s in shards]                                             # all_gather(last SA)
+        for r, (s, B) in enumerate(zip(shards, bufs)):
+            prev = 0xFFFFFFFFFFFFFFFF
+            for q in range(r - 1, -1, -1):
+                if lasts[q] != 0xFFFFFFFFFFFFFFFF:
+                    prev = lasts[q]
+                    break
+            s.fix_first_lcp(prev, B.LCP.data_ptr())
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        infos = [s.info() for s in shards]
+        offs = [i["slice_off"] for i in infos]
+        lens = [sum(x) for x in rc]
+        assert offs == [sum(lens[:r]) for r in range(world)] and sum(lens) == n
+        SA = torch.cat([B.SA[:c] for B, c in zip(bufs, lens)])
+        LCP = torch.cat([B.LCP[:c] for B, c in zip(bufs, lens)])
+        return SA, LCP
+    finally:
+        for s in shards:
+            s.close()

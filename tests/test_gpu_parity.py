@@ -436,3 +436,27 @@ def test_host_entry_point_cache_and_pinned_results(L, oracle):
     SA, LCP, _ = L.build(T, p=7, pinned=True)
     SAo, LCPo = oracle.build_sa_lcp(T, p=7)
     assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo)
+
+
+@pytest.mark.parametrize("world,n,p,bits", [(2, 20_000_001, 8000, 32), (3, 6_000_000, 500, 32), (4, 9_000_001, 0, 64),
+                                            (8, 40_000_000, 8000, 32)])
+def test_shard_kernels_at_world_sizes_above_one_loopback(L, world, n, p, bits):
+    """Every rank's shard on the one GPU of the box, collectives replaced by copies
+    (tests/loopback_world.py): result == the single-GPU build, bit for bit."""
+    import torch
+    from loopback_world import build_world
+    g = torch.Generator(device="cuda")
+    g.manual_seed(world * 1000 + 7)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda")
+    T = lut[torch.randint(0, 4, (n,), device="cuda", generator=g, dtype=torch.int64)]
+    if world == 3:
+        T[1_000_000:1_200_000] = ord("G")                     # a long run: run-table comparators in the shard path
+        T[3_000_000:3_050_000] = T[100_000:150_000]           # a long repeat
+    dt = torch.int32 if bits == 32 else torch.int64
+    SA1 = torch.empty(n, dtype=dt, device="cuda")
+    LCP1 = torch.empty(n, dtype=dt, device="cuda")
+    L.build_device(T.data_ptr(), n, SA1.data_ptr(), LCP1.data_ptr(), p=p, idx_bits=bits)
+    assert L.verify_device(T.data_ptr(), n, SA1.data_ptr(), LCP1.data_ptr(), idx_bits=bits) == 0
+    SA, LCP = build_world(L, T, p, world, bits)
+    assert torch.equal(SA, SA1)
+    assert torch.equal(LCP, LCP1)
