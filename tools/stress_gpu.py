@@ -45,17 +45,34 @@ def text(kind, n):
         a = int(rs.randint(0, n // 2)); ln = int(rs.randint(1, n // 3 + 2))
         T[a:a + ln] = T[a]
         return T
+    if kind == "stretches":                      # periodic stretches (run table, csrc/text.h): periods around the table's
+        sym = DNA if rs.rand() < 0.7 else np.frombuffer(b"abcdefg", dtype=np.uint8)        # limit, lengths around RUN_LONG,
+        T = rs.choice(sym, size=n)                                                          # any alignment, text start / end
+        for _ in range(int(rs.randint(1, 7))):
+            per = int(rs.choice([1, 1, 2, 3, 4, 5, 7, 8, 15, 16, 17, 20, 33]))
+            ln = int(rs.choice([rs.randint(40, 200), rs.randint(900, 1200), rs.randint(1200, max(1201, n // 3 + 1202))]))
+            ln = min(ln, n)
+            where = rs.rand()
+            a = 0 if where < 0.15 else (n - ln if where < 0.3 else int(rs.randint(0, n - ln + 1)))
+            T[a:a + ln] = np.tile(rs.choice(sym, size=per), ln // per + 1)[:ln]
+        if rs.rand() < 0.05:
+            T[:] = T[0]
+        return T
     raise ValueError(kind)
 
 
-kinds = ["uniform", "skew", "two", "bytes", "periodic", "planted", "runs"]
-t0 = time.time(); done = 0; oom = 0; stats = {"slot_splits": 0, "slot_splits_redone": 0}
+kinds = ["uniform", "skew", "two", "bytes", "periodic", "planted", "runs", "stretches", "stretches"]
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from sa_check import sa_lcp                 # independent prefix-doubling construction: not quadratic on stretches
+t0 = time.time(); done = 0; oom = 0; stats = {"slot_splits": 0, "slot_splits_redone": 0, "long_runs": 0}
 while time.time() - t0 < budget:
     kind = kinds[rs.randint(len(kinds))]
     big = rs.rand() < 0.25
     n = int(rs.randint(33, int(os.environ.get("STRESS_MAX_N", 3_000_000)) if big else 60_000))
     if kind == "periodic" or kind == "runs":
         n = min(n, 40_000)                       # quadratic in the LCP, for the oracle too
+    if kind == "stretches":
+        n = max(64, min(n, 400_000))             # checked by sa_check (Python Kasai loop)
     p = int(rs.choice([0, 2, 3, 7, 16, 50, 333, 1000, 8000, max(2, n // 16), max(2, n // 40)]))
     p_mem = min(p, 20000)                        # the p x p matrices (like the reference's) must fit
     if os.environ.get("STRESS_CAP_P"): p = p_mem
@@ -68,7 +85,7 @@ while time.time() - t0 < budget:
             raise
         oom += 1
         continue
-    SAo, LCPo = O.build_sa_lcp(T, p=p, idx_bits=bits)[:2]
+    SAo, LCPo = sa_lcp(T, bits) if kind == "stretches" else O.build_sa_lcp(T, p=p, idx_bits=bits)[:2]
     ok = np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo)
     if not ok:
         np.save(os.environ.get("STRESS_DUMP", "/tmp/stress_fail_T.npy"), T)

@@ -1,5 +1,9 @@
-for tag in default norun tie8 enter16; do
-  if [ $tag = default ]; then unset CAPS_SA_LIB; else export CAPS_SA_LIB=$PWD/caps-sa_amd/variants/libcaps_sa_hip_$tag.so; fi
-  echo "== $tag" >> gpurun_out/s2c_genome_variants.log
-  timeout -k 10 150 python tools/genome_like.py 268435456 >> gpurun_out/s2c_genome_variants.log 2>&1 || exit 1
+#!/bin/bash
+# genome-like input (tools/genome_like.py) for the default library and every variant in caps-sa_amd/variants
+out=gpurun_out/${OUT:-var_genome}.log
+rm -f $out
+for so in default caps-sa_amd/variants/libcaps_sa_hip_*.so; do
+  if [ $so = default ]; then unset CAPS_SA_LIB; tag=default; else export CAPS_SA_LIB=$PWD/$so; tag=$(basename $so .so | sed 's/libcaps_sa_hip_//'); fi
+  echo "== $tag" >> $out
+  timeout -k 10 150 python tools/genome_like.py ${N:-268435456} 2>&1 | grep -v amdgpu.ids >> $out || exit 1
 done
