@@ -1602,7 +1602,7 @@ constexpr uint32_t BUCKET_LDS = TILE_BINS_;            // buckets per segment th
 // [pkey[j-1], pkey[j]] (partitions between pivots; a shard owns a slice of the partitions).
 GLOBAL_FN LAUNCH_BOUNDS(256) bucket_plan_kernel(KCTX const uint64_t* __restrict__ seg_start, uint32_t G, uint32_t range_mode,
                                                 const uint64_t* __restrict__ pkey, uint32_t part_off, uint32_t part_total,
-                                                uint32_t enable,
+                                                uint32_t enable, uint32_t fine,
                                                 BucketParams* __restrict__ bp, uint64_t* __restrict__ segB)
 {
     PAR(tid) {
@@ -1617,11 +1617,82 @@ GLOBAL_FN LAUNCH_BOUNDS(256) bucket_plan_kernel(KCTX const uint64_t* __restrict_
             }
             uint32_t B = 1;
             if (enable && len > TILE_E && kmax > kmin) B = (uint32_t)((len + BUCKET_TARGET - 1) / BUCKET_TARGET);
+            // fine > 1: the map of the equalised split's FINE buckets (bucket_group_kernel): `fine` per bucket slot,
+            // as many as the LDS histograms hold; segments with more slots than that keep one fine bucket per slot
+            if (fine > 1 && B > 1 && B <= BUCKET_LDS) B = (uint64_t)B * fine <= BUCKET_LDS ? B * fine : BUCKET_LDS;
             const BucketParams q = make_bucket_params(kmin, kmax, B);
             bp[g] = q;
             segB[g] = B;
         }
     }
+}
+
+// Equalised split (the redo path of a bucket split whose slots overflowed: keys far from uniform in the
+// segment's range).  The count pass has filled fcount[] for the segment's F FINE buckets (linear map with
+// `fine` times the resolution); consecutive fine buckets are grouped greedily into the segment's B bucket
+// slots, each group as close to a tile as it gets without exceeding it.  gfirst[slot] = first fine bucket
+// of the group (F for unused slots), count[slot] = its exact size: no second count pass.  A fine bucket
+// that is larger than a tile by itself is a group of its own (LCP-merge passes finish it, as before); if
+// the slots run out, the rest of the segment goes into the last one.  One thread per segment.
+GLOBAL_FN LAUNCH_BOUNDS(256) bucket_group_kernel(KCTX uint32_t G, const uint64_t* __restrict__ segB, const uint64_t* __restrict__ bstart,
+                                                 const uint64_t* __restrict__ fsegB, const uint64_t* __restrict__ fstart,
+                                                 const uint64_t* __restrict__ fcount, uint64_t* __restrict__ count,
+                                                 uint32_t* __restrict__ gfirst)
+{
+    PAR(tid) {
+        const uint32_t g = K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (g < G) {
+            const uint32_t B = (uint32_t)segB[g], F = (uint32_t)fsegB[g];
+            const uint64_t b0 = bstart[g], f0 = fstart[g];
+            if (B > BUCKET_LDS || F <= B) {               // no finer map (bucket_plan_kernel): every fine bucket is its own slot
+                for (uint32_t i = 0; i < B; ++i) { count[b0 + i] = i < F ? fcount[f0 + i] : 0; gfirst[b0 + i] = i; }
+                continue;
+            }
+            // capacity of a group: a tile if the slots suffice; otherwise the smallest capacity that fits the segment
+            // into its B slots (never worse than the B equal key ranges of the plain split, which is one such grouping)
+            uint64_t cap = TILE_E, total = 0;
+            for (uint32_t f = 0; f < F; ++f) total += fcount[f0 + f];
+            for (uint64_t lo = TILE_E, hi = total > TILE_E ? total : TILE_E;;) {
+                const uint64_t c_try = lo == TILE_E ? lo : (lo + hi) / 2;     // first probe: a tile
+                uint32_t need = 1;
+                uint64_t run = 0;
+                for (uint32_t f = 0; f < F; ++f) {
+                    const uint64_t c = fcount[f0 + f];
+                    if (run > 0 && run + c > c_try) { ++need; run = 0; }
+                    run += c;
+                }
+                if (need <= B) { cap = c_try; hi = c_try; if (c_try == TILE_E) break; }
+                else lo = c_try + 1;
+                if (lo >= hi) { cap = hi; break; }
+            }
+            uint32_t gi = 0;
+            uint64_t sum = 0;
+            gfirst[b0] = 0;
+            for (uint32_t f = 0; f < F; ++f) {
+                const uint64_t c = fcount[f0 + f];
+                if (sum > 0 && sum + c > cap && gi + 1 < B) {
+                    count[b0 + gi] = sum;
+                    ++gi;
+                    gfirst[b0 + gi] = f;
+                    sum = 0;
+                }
+                sum += c;
+            }
+            count[b0 + gi] = sum;
+            for (uint32_t i = gi + 1; i < B; ++i) { count[b0 + i] = 0; gfirst[b0 + i] = F; }
+        }
+    }
+}
+
+// group of fine bucket f: the last slot whose first fine bucket is <= f (tab[0] = 0, unused slots hold F > f)
+DEV_INLINE uint32_t group_of(const uint32_t* tab, uint32_t B, uint32_t f)
+{
+    uint32_t lo = 0, hi = B;                       // tab[lo] <= f < tab[hi] (hi = B: +infinity)
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (tab[mid] <= f) lo = mid; else hi = mid;
+    }
+    return lo;
 }
 
 // Key range of every bucket (inverse of bucket_of, to within rounding: keys just outside are
@@ -1630,8 +1701,10 @@ GLOBAL_FN LAUNCH_BOUNDS(256) bucket_plan_kernel(KCTX const uint64_t* __restrict_
 GLOBAL_FN LAUNCH_BOUNDS(256) bucket_ranges_kernel(KCTX const uint64_t* __restrict__ bstart, uint32_t G,
                                                   const BucketParams* __restrict__ bps, const uint64_t* __restrict__ pkey,
                                                   uint32_t range_mode, uint32_t part_off, uint32_t part_total,
-                                                  BucketParams* __restrict__ tile_map)
+                                                  BucketParams* __restrict__ tile_map,
+                                                  const BucketParams* __restrict__ fbps, const uint32_t* __restrict__ gfirst)
 {
+    // gfirst != null (equalised split): bucket slot i is the group of fine buckets [gfirst[i], gfirst[i + 1]) of fbps[g]
     PAR(tid) {
         const uint64_t i = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
         if (i < bstart[G]) {
@@ -1652,9 +1725,16 @@ GLOBAL_FN LAUNCH_BOUNDS(256) bucket_ranges_kernel(KCTX const uint64_t* __restric
             const double range1 = (double)(kmax - kmin) + 1.0;
             uint64_t l = kmin, h = kmax;
             if (bp.B > 1) {
-                const double dl = (double)bk / (double)bp.B * range1, dh = (double)(bk + 1) / (double)bp.B * range1;
-                if (bk > 0) l = kmin + (uint64_t)dl;
-                if (bk + 1 < bp.B) h = kmin + (uint64_t)dh;
+                uint32_t lo = bk, hi = bk + 1, div = bp.B;
+                if (gfirst) {
+                    div = fbps[g].B;
+                    lo = gfirst[i];
+                    hi = bk + 1 < bp.B ? gfirst[i + 1] : div;
+                    if (hi <= lo) hi = lo + 1;                         // an unused slot: any range will do
+                }
+                const double dl = (double)lo / (double)div * range1, dh = (double)hi / (double)div * range1;
+                if (lo > 0) l = kmin + (uint64_t)dl;
+                if (hi < div) h = kmin + (uint64_t)dh;
                 if (h < l) h = l;
             }
             tile_map[i] = make_bucket_params(l, h, TILE_BINS);      // the tile sort's bin map over the bucket's key range
@@ -1744,8 +1824,11 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
                                                        const BucketParams* __restrict__ bps, const uint64_t* __restrict__ bstart,
                                                        const uint64_t* __restrict__ sub_start, uint32_t slot_cap,
                                                        idx_t* __restrict__ cursor,
-                                                       uint64_t* __restrict__ out_key, idx_t* __restrict__ out_sa)
+                                                       uint64_t* __restrict__ out_key, idx_t* __restrict__ out_sa,
+                                                       const BucketParams* __restrict__ fbps, const uint32_t* __restrict__ gfirst)
 {
+    // gfirst != null: equalised split -- the key's FINE bucket (map fbps[g]) is looked up in the segment's group table
+    // (bucket_group_kernel) to get its bucket slot.
     // slot_cap != 0 ("speculative" split, no count pass): bucket i of the launch owns the fixed slot
     // [i * slot_cap, (i + 1) * slot_cap) of the output; cursor[] ends as the exact bucket sizes, and
     // elements that do not fit their slot are dropped -- the caller sees a size > slot_cap and
@@ -1766,6 +1849,8 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
     const uint32_t cnt = (uint32_t)(t.s1 - start < TILE_E ? t.s1 - start : TILE_E);
     const BucketParams bp = bps[g];
     const uint64_t b0 = bstart[g];
+    const bool grouped = gfirst != nullptr && bp.B > 1 && bp.B <= BUCKET_LDS;
+    const BucketParams fbp = gfirst != nullptr ? fbps[g] : bp;
     SHARED_ARRAY(uint32_t, hist, TILE_BINS + 1);          // counts -> exclusive prefix inside the tile
     SHARED_ARRAY(idx_t, obase, TILE_BINS);                // global slot of the tile's first element of bucket i, minus its prefix
                                                           // (idx_t: 72 KiB of LDS at 32-bit indices -> two workgroups per CU)
@@ -1784,11 +1869,14 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
     uint32_t* twin = reinterpret_cast<uint32_t*>(skey);
     uint64_t* lsrc = skey;
     idx_t* lrow = ssa;
+    uint32_t* gtab = reinterpret_cast<uint32_t*>(sbk);    // group table of the segment (sbk is written after its last use)
+    static_assert(sizeof(uint16_t) * TILE_E >= sizeof(uint32_t) * BUCKET_LDS, "group table fits the bucket-id staging array");
     const uint64_t w0 = text_win_base<BITS>(text_base + start);
     RUNS_TILE_SETUP
     if (lds || FROM_TEXT || FROM_RUNS) {
         PAR(tid) {
             if (lds) for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0;
+            if (grouped) for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM) gtab[i] = gfirst[b0 + i];
             if (FROM_TEXT)
                 for (uint32_t i = tid; i < TEXT_WIN; i += K_BLOCK_DIM) twin[i] = w0 + i < n_words ? P[w0 + i] : 0u;
             if (FROM_RUNS) { RUNS_STAGE(tid) }
@@ -1810,7 +1898,8 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
                 idx_t r;
                 if (bp.B == 1) r = e;                                        // identity: the segment is its own bucket
                 else {
-                    bk = bucket_of(bp, key);
+                    bk = bucket_of(fbp, key);
+                    if (grouped) bk = group_of(gtab, bp.B, bk);
                     r = lds ? FETCH_ADD_U32(&hist[bk], 1u) : caps_fetch_add(&cursor[b0 + bk], (idx_t)1);
                 }
                 TL(rk, tid, k) = key;

@@ -65,6 +65,12 @@ struct SegBufs {
 
 constexpr uint32_t kMaxPasses = 96;
 
+// Fine buckets per bucket slot of the equalised split (bucket_group_kernel), as far as the LDS histograms hold them.
+#ifndef CAPS_EQ_FINE
+#define CAPS_EQ_FINE 16
+#endif
+constexpr uint32_t EQ_FINE = CAPS_EQ_FINE;
+
 // Scratch of the bucketing stage of one sort (kernels.h "Bucketing inside a sort").
 struct BucketBufs {
     BucketParams* params = nullptr;   // [G]
@@ -77,6 +83,12 @@ struct BucketBufs {
     BucketParams* tile_map = nullptr;                     // [nb_cap] bin map of the tile sort over every bucket's key range
     void *first_sa = nullptr, *last_sa = nullptr;         // [nb_cap] idx_t
     SegBufs sub;                      // the buckets as segments (G = nb_cap, trailing ones empty)
+    // equalised split (redo path): fine buckets of every segment and their grouping into the bucket slots
+    BucketParams* fparams = nullptr;  // [G]
+    uint64_t* fsegB = nullptr;        // [G]
+    uint64_t* fstart = nullptr;       // [G+1]
+    uint64_t* fcount = nullptr;       // [EQ_FINE * nb_cap]
+    uint32_t* gfirst = nullptr;       // [nb_cap] first fine bucket of every slot's group
     uint32_t nb_cap = 0;
     uint64_t tile_cap = 0;
     static uint32_t bucket_bound(uint64_t n_elems, uint32_t G) { return (uint32_t)(n_elems / BUCKET_TARGET + G + 1); }
@@ -181,6 +193,11 @@ Plan<idx_t> make_plan(uint64_t n, uint64_t p_arg, char* base)
     pl.bk.first_sa = ar.take<idx_t>(pl.bk.nb_cap);
     pl.bk.last_sa = ar.take<idx_t>(pl.bk.nb_cap);
     segs(pl.bk.sub, pl.bk.nb_cap, pl.bk.tile_cap);
+    pl.bk.fparams = ar.take<BucketParams>(p);
+    pl.bk.fsegB = ar.take<uint64_t>(p);
+    pl.bk.fstart = ar.take<uint64_t>((size_t)p + 1);
+    pl.bk.fcount = ar.take<uint64_t>((size_t)EQ_FINE * pl.bk.nb_cap);
+    pl.bk.gfirst = ar.take<uint32_t>(pl.bk.nb_cap);
     pl.pass_elems = ar.take<uint64_t>(kMaxPasses);
     pl.present = ar.take<uint32_t>(8);
     pl.lut = ar.take<uint8_t>(256);
@@ -333,6 +350,7 @@ struct SortOpts {
     uint64_t text_base = 0;       // element i of the arrays = text position text_base + i
     bool need_lcp = false;        // emit LCPs (by the step that completes each segment)
     bool skip_finished = false;   // finished segments sit out later passes (result spread over both buffers)
+    bool no_equalise = false;     // measurement: plain count split on the redo path (CAPS_SA_NO_EQUALISE=1)
     const BucketBufs* bk = nullptr;   // non-null: split long segments into key-range buckets first
     uint32_t range_mode = 0;      // bucket_plan_kernel: 0 full key range, 1 between pivots
     const uint64_t* pkey = nullptr;
@@ -384,12 +402,12 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         const BucketBufs& bk = *o.bk;
         const SegDesc psd = s.desc();
         CAPS_LAUNCH(bucket_plan_kernel, (s.G + 255) / 256, 256, be, (const uint64_t*)s.seg_start, s.G, o.range_mode, o.pkey, o.part_off,
-                    o.part_total ? o.part_total : s.G, 1u,
+                    o.part_total ? o.part_total : s.G, 1u, 1u,
                     bk.params, bk.segB);
         CAPS_LAUNCH(scan_sizes_kernel, 1, 1024, be, (const uint64_t*)bk.segB, s.G, bk.bstart);
         CAPS_LAUNCH(bucket_ranges_kernel, (bk.nb_cap + 255) / 256, 256, be, (const uint64_t*)bk.bstart, s.G,
                     (const BucketParams*)bk.params, o.pkey, o.range_mode, o.part_off, o.part_total ? o.part_total : s.G,
-                    bk.tile_map);
+                    bk.tile_map, (const BucketParams*)nullptr, (const uint32_t*)nullptr);
         seg_map = bk.tile_map;
         mark("bucket plan");
         const uint32_t pgrid = n_tiles < be.persistent_blocks() ? n_tiles : be.persistent_blocks();
@@ -397,20 +415,22 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         const RunSrc<idx_t> rsrc = runs ? *static_cast<const RunSrc<idx_t>*>(o.runs) : RunSrc<idx_t>();
         const uint64_t n_words = from_text ? packed_words(n, BITS) : 0;
         const uint64_t tbase = from_text ? o.text_base : 0;
-        auto scatter = [&](const uint64_t* sub_start, uint32_t cap, uint64_t* okey, idx_t* osa) {
+        auto scatter = [&](const uint64_t* sub_start, uint32_t cap, uint64_t* okey, idx_t* osa, bool grouped = false) {
+            const BucketParams* fbps = grouped ? bk.fparams : nullptr;
+            const uint32_t* gfirst = grouped ? bk.gfirst : nullptr;
             BackendEvent s0 = be.record();
             if (from_text)
                 CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, SRC_TEXT>), n_tiles, TILE_NT, be, psd, P, n_words, tbase, (const uint64_t*)nullptr,
                             (const idx_t*)nullptr, rsrc, (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, sub_start, cap,
-                            static_cast<idx_t*>(bk.cursor), okey, osa);
+                            static_cast<idx_t*>(bk.cursor), okey, osa, fbps, gfirst);
             else if (runs)
                 CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, SRC_RUNS>), n_tiles, TILE_NT, be, psd, P, n_words, tbase, (const uint64_t*)cur.key,
                             (const idx_t*)cur.sa, rsrc, (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, sub_start, cap,
-                            static_cast<idx_t*>(bk.cursor), okey, osa);
+                            static_cast<idx_t*>(bk.cursor), okey, osa, fbps, gfirst);
             else
                 CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, SRC_ARRAYS>), n_tiles, TILE_NT, be, psd, P, n_words, tbase, (const uint64_t*)cur.key,
                             (const idx_t*)cur.sa, rsrc, (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, sub_start, cap,
-                            static_cast<idx_t*>(bk.cursor), okey, osa);
+                            static_cast<idx_t*>(bk.cursor), okey, osa, fbps, gfirst);
             BackendEvent s1 = be.record();
             if (o.scatter_clock) { o.scatter_clock->spans.push_back({s0, s1}); o.scatter_clock->elems.push_back(n_elems); }
         };
@@ -447,23 +467,46 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
             if (dbg) std::fprintf(stderr, "[sort] slot split: largest bucket %llu -> %s\n", (unsigned long long)out2[1], slots ? "kept" : "redone");
         }
         if (!slots) {
+            // Count split.  Equalised (bk.fcount): the count pass fills EQ_FINE times finer buckets, bucket_group_kernel
+            // packs consecutive fine buckets into the segment's bucket slots (exact sizes, balanced whatever the key
+            // distribution inside the segment), and the scatter looks the slot up from the fine bucket.
+            const bool equalise = bk.fcount != nullptr && !o.no_equalise && !std::getenv("CAPS_SA_NO_EQUALISE");
+            const BucketParams* cparams = bk.params;
+            const uint64_t* cstart = bk.bstart;
+            uint64_t* ccount = bk.count;
+            if (equalise) {
+                CAPS_LAUNCH(bucket_plan_kernel, (s.G + 255) / 256, 256, be, (const uint64_t*)s.seg_start, s.G, o.range_mode, o.pkey, o.part_off,
+                            o.part_total ? o.part_total : s.G, 1u, EQ_FINE, bk.fparams, bk.fsegB);
+                CAPS_LAUNCH(scan_sizes_kernel, 1, 1024, be, (const uint64_t*)bk.fsegB, s.G, bk.fstart);
+                be.memset(bk.fcount, 0, (size_t)EQ_FINE * bk.nb_cap * sizeof(uint64_t));
+                cparams = bk.fparams;
+                cstart = bk.fstart;
+                ccount = bk.fcount;
+            }
             be.memset(bk.count, 0, (size_t)bk.nb_cap * sizeof(uint64_t));
             be.memset(bk.cursor, 0, (size_t)bk.nb_cap * sizeof(idx_t));
             BackendEvent c0 = be.record();
             if (from_text)
                 CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, SRC_TEXT>), pgrid, TILE_NT, be, psd, P, n_words, tbase, (const uint64_t*)nullptr, rsrc,
-                            (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, bk.count);
+                            cparams, cstart, ccount);
             else if (runs)
                 CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, SRC_RUNS>), pgrid, TILE_NT, be, psd, P, n_words, tbase, (const uint64_t*)cur.key, rsrc,
-                            (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, bk.count);
+                            cparams, cstart, ccount);
             else
                 CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, SRC_ARRAYS>), pgrid, TILE_NT, be, psd, P, n_words, tbase, (const uint64_t*)cur.key, rsrc,
-                            (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, bk.count);
+                            cparams, cstart, ccount);
+            if (equalise) {
+                CAPS_LAUNCH(bucket_group_kernel, (s.G + 255) / 256, 256, be, s.G, (const uint64_t*)bk.segB, (const uint64_t*)bk.bstart,
+                            (const uint64_t*)bk.fsegB, (const uint64_t*)bk.fstart, (const uint64_t*)bk.fcount, bk.count, bk.gfirst);
+                CAPS_LAUNCH(bucket_ranges_kernel, (bk.nb_cap + 255) / 256, 256, be, (const uint64_t*)bk.bstart, s.G,
+                            (const BucketParams*)bk.params, o.pkey, o.range_mode, o.part_off, o.part_total ? o.part_total : s.G,
+                            bk.tile_map, (const BucketParams*)bk.fparams, (const uint32_t*)bk.gfirst);
+            }
             BackendEvent c1 = be.record();
             if (o.count_clock) { o.count_clock->spans.push_back({c0, c1}); o.count_clock->elems.push_back(n_elems); }
             adopt_buckets();
             ElemBuf<idx_t> dst = from_text ? cur : oth;
-            scatter((const uint64_t*)bk.sub.seg_start, 0u, dst.key, dst.sa);
+            scatter((const uint64_t*)bk.sub.seg_start, 0u, dst.key, dst.sa, equalise);
             if (!from_text) {
                 std::swap(cur, oth);                     // the scattered copy is the working buffer now
                 r.buf[0] = cur;

@@ -401,6 +401,11 @@ private:
         k.first_sa = get<idx_t>(k.nb_cap);
         k.last_sa = get<idx_t>(k.nb_cap);
         k.sub = segs(k.nb_cap, k.tile_cap);
+        k.fparams = get<BucketParams>(G);
+        k.fsegB = get<uint64_t>(G);
+        k.fstart = get<uint64_t>((size_t)G + 1);
+        k.fcount = get<uint64_t>((size_t)EQ_FINE * k.nb_cap);
+        k.gfirst = get<uint32_t>(k.nb_cap);
         return k;
     }
 };

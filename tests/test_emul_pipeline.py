@@ -208,3 +208,33 @@ def test_host_entry_point_reuses_and_regrows_its_device_block(oracle):
     a = E.pinned_empty(1000, np.uint32)               # host_alloc / host_free round trip
     a[:] = 7
     assert int(a.sum()) == 7000
+
+
+def test_equalised_split_never_needs_more_passes_than_the_plain_one(oracle, monkeypatch):
+    """Redo path of the bucket split (slots overflowed): the count pass fills 16x finer buckets and
+    bucket_group_kernel packs them into the bucket slots.  Same result; never a larger largest bucket
+    (= never more LCP-merge passes) than the plain equal-key-range split."""
+    from emul_util import emul_small
+    rs = np.random.RandomState(13)
+    texts = [rs.choice(DNA, size=150000, p=[0.7, 0.2, 0.08, 0.02]),
+             rs.choice(np.frombuffer(b"abcdefgh", dtype=np.uint8), size=100000, p=[.5, .2, .1, .1, .05, .03, .01, .01])]
+    # order-2 Markov chain with skewed transitions
+    trans = rs.dirichlet([0.3] * 4, size=16)
+    m = np.zeros(120000, dtype=np.int64)
+    u = rs.rand(m.size)
+    for i in range(2, m.size):
+        m[i] = min(3, int(np.searchsorted(np.cumsum(trans[m[i - 2] * 4 + m[i - 1]]), u[i])))
+    texts.append(DNA[m])
+    for E in (emul_small(), emul()):
+        for T in texts:
+            for p in (4, 37):
+                monkeypatch.delenv("CAPS_SA_NO_EQUALISE", raising=False)
+                SA, LCP, st = E.build(T, p=p)
+                monkeypatch.setenv("CAPS_SA_NO_EQUALISE", "1")
+                SA0, LCP0, st0 = E.build(T, p=p)
+                monkeypatch.delenv("CAPS_SA_NO_EQUALISE", raising=False)
+                assert np.array_equal(SA, SA0) and np.array_equal(LCP, LCP0)
+                SAo, LCPo = oracle.build_sa_lcp(T, p=p)
+                assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo)
+                assert st["merge_passes_phase1"] <= st0["merge_passes_phase1"]
+                assert st["merge_passes_phase2"] <= st0["merge_passes_phase2"]

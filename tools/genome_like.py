@@ -34,7 +34,10 @@ def markov_dna(n, order=5, seed=7, device="cuda", skew=0.5, repeats=0.02, repeat
             seg[m] = torch.randint(0, 4, (int(m.sum()),), device=device, generator=g, dtype=torch.uint8)
             seq[d:d + repeat_len] = seg
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
-    return lut[seq.long()]
+    out_t = torch.empty(n, dtype=torch.uint8, device=device)
+    for o in range(0, n, 1 << 28):                # in pieces: seq.long() of 3e9 elements would take 24 GB
+        out_t[o:o + (1 << 28)] = lut[seq[o:o + (1 << 28)].long()]
+    return out_t
 
 
 if __name__ == "__main__":
@@ -45,6 +48,12 @@ if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 64_000_001
     L = caps_sa_amd.lib()
     T = markov_dna(n)
+    if os.environ.get("NBLOCKS"):                 # N-block stand-ins (the CLI maps N to G, src/main.cpp:61-68): long single-letter runs
+        g = torch.Generator(device="cuda")
+        g.manual_seed(99)
+        for ln, cnt in ((2_000_000, 1), (500_000, 5), (50_000, 100)):
+            for a in torch.randint(0, n - ln, (cnt,), device="cuda", generator=g).tolist():
+                T[a:a + ln] = ord("G")
     SA = torch.empty(n, dtype=torch.int32, device="cuda")
     LCP = torch.empty(n, dtype=torch.int32, device="cuda")
     for it in range(2):
@@ -54,7 +63,7 @@ if __name__ == "__main__":
         torch.cuda.synchronize()
         dt = time.time() - t0
     errs = L.verify_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr())
-    keep = ("ms_total", "ms_sort_subarrays", "ms_merge_partitions", "merge_passes_phase1", "merge_passes_phase2",
+    keep = ("long_runs", "slot_splits", "slot_splits_redone", "ms_total", "ms_sort_subarrays", "ms_merge_partitions", "merge_passes_phase1", "merge_passes_phase2",
             "max_partition", "tile_sort_ms", "merge_pass_ms", "bucket_scatter_ms")
     print(json.dumps({"n": n, "wall_ms": 1e3 * dt, "G_suffixes_per_s": n / dt / 1e9, "verify_errors": errs,
                       "max_lcp": int(LCP.max().item()), "mean_lcp": float(LCP.double().mean().item()),
