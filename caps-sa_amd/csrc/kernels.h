@@ -690,6 +690,7 @@ template <typename idx_t> struct FinalOut {
 #ifdef CAPS_EMUL
 extern "C" void caps_emul_count_tile(bool fast, bool known_range);   // test statistics (tests/emul/emul_lib.cpp)
 extern "C" void caps_emul_count_tile2(bool two_level_ok);
+extern "C" void caps_emul_count_tile3(bool equalised_ok);
 #endif
 constexpr uint32_t TILE_BINS = TILE_BINS_;
 #ifndef CAPS_TILE_BIN_LIMIT
@@ -920,6 +921,180 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
         return;
     }
     TILE_SORT_EMIT
+}
+
+// ---- tile_sort_eq_kernel: second chance for the tiles tile_sort_kernel could not finish --------
+// Keys that are far from uniform over the tile's range (skewed k-mer composition: every real genome)
+// crowd a few bins of the linear map.  Here the map is equalised with the tile's own data: a coarse
+// histogram (EQ_COARSE linear bins) gives a piecewise-linear CDF, and an element's bin is its estimated
+// rank: bin = (count before its coarse bin + position inside the coarse bin x count of that bin) *
+// TILE_BINS / cnt -- monotone in the key, so the counting sort + exact in-bin ranking of tile_sort_kernel
+// finish the job unchanged.  Takes the tiles from tile_sort_kernel's queue (redo[0] = length) with a
+// fixed grid; a tile that still has a bin above TILE_BIN_LIMIT (clusters of suffixes that share more
+// chars than the coarse bins resolve), or a deep tie, goes on to tile_sort_general_kernel (redo2).
+// A separate kernel rather than a branch of tile_sort_kernel: that one runs at the register budget.
+constexpr uint32_t EQ_FRAC_BITS = 8;              // position inside a coarse bin, in 1/256
+constexpr uint32_t EQ_COARSE = (TILE_BINS_ * 32u) >> EQ_FRAC_BITS;     // 256 coarse bins for the 2048 bins of a 4096-element tile
+
+// 16-bit position of the key on the tile's linear map: (bin of bucket_of(tb, .)) * 32 + 5 more bits
+DEV_INLINE uint32_t eq_pos16(const BucketParams& bp, uint64_t key)
+{
+    const uint32_t top = bp.B * 32u - 1u;
+    if (key <= bp.kmin) return 0;
+    const uint64_t d = key - bp.kmin;
+    if (d >= bp.range) return top;
+    const uint32_t d32 = (uint32_t)((d << bp.shift) >> 32);
+    const uint64_t prod = (uint64_t)d32 * bp.m;
+    const uint32_t sh = 32u + bp.post;                                   // bucket = prod >> sh
+    const uint32_t p16 = (uint32_t)(sh >= 5 ? prod >> (sh - 5) : prod << (5 - sh));
+    return p16 < top ? p16 : top;
+}
+
+template <typename idx_t, int BITS, bool FROM_TEXT>
+GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_eq_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
+                                                  uint64_t text_base, uint32_t lcp_mode, uint32_t slot_cap, const uint64_t* in_key,
+                                                  const idx_t* in_sa, uint64_t* out_key, idx_t* out_sa, idx_t* out_lcp,
+                                                  FinalOut<idx_t> fin, const BucketParams* __restrict__ seg_map,
+                                                  const uint32_t* __restrict__ redo, uint32_t* __restrict__ redo2)
+{
+    constexpr bool TILE_RUNS = false;
+    SHARED_ARRAY(uint64_t, skey, TILE_E);
+    SHARED_ARRAY(idx_t, ssa, TILE_E);
+    SHARED_ARRAY(uint32_t, hist, TILE_BINS + 1);
+    SHARED_ARRAY(uint32_t, chist, EQ_COARSE + 1);
+    SHARED_ARRAY(uint64_t, kmm, 2);
+    SHARED_ARRAY(uint32_t, flag, 1);
+    TL_DECL(uint64_t, rk, TILE_EPT);
+    TL_DECL(idx_t, rs, TILE_EPT);
+    TL_DECL(uint32_t, rd, TILE_EPT);
+    TL_DECL(uint32_t, rb, TILE_EPT);
+    const uint32_t n_redo = redo[0];
+    for (uint32_t qi = K_BLOCK_IDX; qi < n_redo; qi += K_GRID_DIM) {
+    const uint32_t b = redo[1 + qi];
+    const uint32_t g = sd.tile_rec[b].g;
+    const TileInfo t = tile_info(sd, b);
+    const uint64_t start = t.s0 + (uint64_t)t.tl * TILE_E;
+    const uint32_t cnt = (uint32_t)(t.s1 - start < TILE_E ? t.s1 - start : TILE_E);
+    const bool with_lcp = lcp_mode != 0 && (t.s1 - t.s0) <= TILE_E;
+    const bool direct = with_lcp && fin.sa != nullptr;
+    const uint64_t in0 = slot_cap ? (uint64_t)g * slot_cap : start;
+    TILE_SORT_LOAD
+    PAR(tid) { for (uint32_t i = tid; i <= EQ_COARSE; i += K_BLOCK_DIM) chist[i] = 0; }
+    TILE_SORT_RANGE
+    bool fast = cnt > TILE_BIN_LIMIT && tb.range > 0 && tb.B == TILE_BINS;
+    if (fast) {
+        PAR(tid) {                                             // coarse histogram of the tile
+            UNROLL
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                const uint32_t e = tid + k * TILE_NT;
+                if (e < cnt) {
+                    const uint32_t p16 = eq_pos16(tb, TL(rk, tid, k));
+                    TL(rb, tid, k) = p16;
+                    FETCH_ADD_U32(&chist[p16 >> EQ_FRAC_BITS], 1u);
+                }
+            }
+        }
+        SYNC();
+        PAR(tid) {                                             // exclusive scan of the 256 counters, chist[EQ_COARSE] = cnt
+#ifdef CAPS_EMUL
+            if (tid == 0) { uint32_t run = 0; for (uint32_t i = 0; i <= EQ_COARSE; ++i) { const uint32_t c = i < EQ_COARSE ? chist[i] : 0; chist[i] = run; run += c; } }
+#else
+            if (tid < 64) {                                    // one wave, EQ_COARSE / 64 counters per lane
+                constexpr uint32_t CPL = EQ_COARSE / 64;
+                static_assert(CPL >= 1 && CPL * 64 == EQ_COARSE, "coarse bins per lane");
+                uint32_t v[CPL], sum = 0;
+                UNROLL
+                for (uint32_t i = 0; i < CPL; ++i) { v[i] = chist[tid * CPL + i]; sum += v[i]; }
+                uint32_t x = sum;
+                UNROLL
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t y = __shfl_up(x, d, 64);
+                    if ((int)tid >= d) x += y;
+                }
+                uint32_t run = x - sum;
+                UNROLL
+                for (uint32_t i = 0; i < CPL; ++i) { chist[tid * CPL + i] = run; run += v[i]; }
+                if (tid == 63) chist[EQ_COARSE] = run;
+            }
+#endif
+        }
+        SYNC();
+        const uint64_t K = ((uint64_t)TILE_BINS << (32 - EQ_FRAC_BITS)) / cnt;       // bin = (E * K) >> 32, E = 256 * estimated rank
+        PAR(tid) {
+            UNROLL
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                const uint32_t e = tid + k * TILE_NT;
+                if (e < cnt) {
+                    const uint32_t p16 = TL(rb, tid, k);
+                    const uint32_t c = p16 >> EQ_FRAC_BITS, fr = p16 & ((1u << EQ_FRAC_BITS) - 1u);
+                    const uint32_t before = chist[c], here = chist[c + 1] - before;
+                    const uint64_t E = ((uint64_t)before << EQ_FRAC_BITS) + (uint64_t)here * fr;
+                    uint32_t bin = (uint32_t)((E * K) >> 32);
+                    bin = bin < TILE_BINS ? bin : TILE_BINS - 1;
+                    const uint32_t r = FETCH_ADD_U32(&hist[bin], 1u);
+                    if (r >= TILE_BIN_LIMIT) flag[0] = 1;
+                    TL(rb, tid, k) = bin;
+                    TL(rd, tid, k) = r;
+                }
+            }
+        }
+        SYNC();
+        fast = flag[0] == 0;
+    }
+    if (fast) {                                                // from here on: as in tile_sort_kernel
+        block_exclusive_scan_bins(KCTX_PASS hist);
+        PAR(tid) {
+            UNROLL
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                const uint32_t e = tid + k * TILE_NT;
+                if (e < cnt) {
+                    const uint32_t slot = hist[TL(rb, tid, k)] + TL(rd, tid, k);
+                    skey[slot] = TL(rk, tid, k);
+                    ssa[slot] = TL(rs, tid, k);
+                    TL(rd, tid, k) = slot;
+                }
+            }
+        }
+        SYNC();
+        PAR(tid) {
+            UNROLL
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                const uint32_t e = tid + k * TILE_NT;
+                if (e < cnt) {
+                    const uint32_t bin = TL(rb, tid, k), slot = TL(rd, tid, k);
+                    const uint32_t bs = hist[bin], be = hist[bin + 1];
+                    const uint64_t key = TL(rk, tid, k);
+                    const uint64_t sa = (uint64_t)TL(rs, tid, k);
+                    uint32_t less = 0;
+                    for (uint32_t j = bs; j < be; ++j) {
+                        const uint64_t kj = skey[j];
+                        less += kj < key ? 1u : 0u;
+                        if (kj == key && j != slot) {
+                            const uint32_t c = suffix_less_tie_bounded<BITS>(P, n, (uint64_t)ssa[j], sa);
+                            if (c == 2u) flag[0] = 1;
+                            less += c & 1u;
+                        }
+                    }
+                    TL(rd, tid, k) = bs + less;
+                }
+            }
+        }
+        SYNC();
+        fast = flag[0] == 0;
+        if (fast) {
+            TILE_SORT_PLACE_FINAL
+        }
+    }
+#ifdef CAPS_EMUL
+    caps_emul_count_tile3(fast);
+#endif
+    if (!fast) {
+        PAR(tid) { if (tid == 0) redo2[1 + FETCH_ADD_U32(&redo2[0], 1u)] = b; }
+    } else {
+        TILE_SORT_EMIT
+    }
+    SYNC();                                                    // the staging arrays are free for the next tile
+    }
 }
 
 // ---- tile_sort_general_kernel: the tiles tile_sort_kernel could not finish ------------------

@@ -538,23 +538,33 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         fin.last_sa = static_cast<idx_t*>(o.bnd.last_sa);
     }
     r.fin = fin;
-    // queue of the tiles the bucket sort could not finish ([0] = length): the (idle) tile descriptors' memory
+    // queues of unfinished tiles ([0] = length) in the (idle) tile descriptors' memory: tile_sort_kernel -> redo ->
+    // tile_sort_eq_kernel -> redo2 -> tile_sort_general_kernel
     uint32_t* redo = reinterpret_cast<uint32_t*>(desc);
+    uint32_t* redo2 = redo + ((size_t)n_tiles + 2);
+    static_assert(sizeof(TileDesc) >= 2 * sizeof(uint32_t) + 1, "two queues fit the descriptor array");
     be.memset(redo, 0, sizeof(uint32_t));
+    be.memset(redo2, 0, sizeof(uint32_t));
     const uint32_t ggrid = n_tiles < 4 * be.persistent_blocks() ? n_tiles : 4 * be.persistent_blocks();
+    const bool eq_tiles = !std::getenv("CAPS_SA_NO_EQ_TILES");        // measurement: skip tile_sort_eq_kernel
+    if (!eq_tiles) redo2 = redo;
     BackendEvent t0 = be.record();
     const uint64_t* in_key = slot_cap ? slot_key : cur.key;
     const idx_t* in_sa = slot_cap ? slot_sa : cur.sa;
     if (from_text) {
         CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, sd, P, n, o.text_base, lcp_mode, 0u,
                     (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, seg_map, redo);
+        if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, true>), ggrid, TILE_NT, be, sd, P, n, o.text_base, lcp_mode, 0u,
+                    (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo, redo2);
         CAPS_LAUNCH_RUNS(tile_sort_general_kernel, (idx_t, BITS, true), ggrid, TILE_NT, be, sd, P, n, o.text_base, lcp_mode, 0u,
-                    (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo);
+                    (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo2);
     } else {
         CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
                     in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, redo);
+        if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false>), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
+                    in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo, redo2);
         CAPS_LAUNCH_RUNS(tile_sort_general_kernel, (idx_t, BITS, false), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
-                    in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo);
+                    in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo2);
     }
     BackendEvent t1 = be.record();
     mark("tile sort");

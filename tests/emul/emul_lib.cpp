@@ -6,9 +6,11 @@
 #define CAPS_API(name) caps_sa_emul_##name
 #include <cstdint>
 // statistics of the tile sort paths (read by tests)
-static uint64_t g_tile_stats[6];
+static uint64_t g_tile_stats[8];
 extern "C" void caps_emul_count_tile(bool fast, bool known_range) { ++g_tile_stats[(fast ? 1 : 0) + (known_range ? 2 : 0)]; }
 extern "C" void caps_emul_count_tile2(bool ok) { ++g_tile_stats[4 + (ok ? 1 : 0)]; }
+extern "C" void caps_emul_count_tile3(bool ok) { ++g_tile_stats[6 + (ok ? 1 : 0)]; }     // tile_sort_eq_kernel: gave up / finished
+extern "C" void caps_sa_emul_tile_stats8(uint64_t* out, int reset) { for (int i = 0; i < 8; ++i) { out[i] = g_tile_stats[i]; if (reset) g_tile_stats[i] = 0; } }
 extern "C" void caps_sa_emul_tile_stats6(uint64_t* out, int reset) { for (int i = 0; i < 6; ++i) { out[i] = g_tile_stats[i]; if (reset) g_tile_stats[i] = 0; } }
 extern "C" void caps_sa_emul_tile_stats(uint64_t* out, int reset) { for (int i = 0; i < 4; ++i) { out[i] = g_tile_stats[i]; if (reset) g_tile_stats[i] = 0; } }
 #include "../../caps-sa_amd/csrc/capi_impl.h"

@@ -10,6 +10,7 @@ def markov_dna(n, order=5, seed=7, device="cuda", skew=0.5, repeats=0.02, repeat
     g.manual_seed(seed)
     states = 4 ** order
     # Dirichlet(skew) rows via gamma sampling
+    torch.manual_seed(seed)                       # the transition matrix comes from the CPU generator: same text every run
     gam = torch.distributions.Gamma(torch.full((states, 4), skew), torch.ones(states, 4)).sample().to(device)
     cdf = torch.cumsum(gam / gam.sum(1, keepdim=True), 1)
     # chains run in parallel from random states and are concatenated (stationary enough)
