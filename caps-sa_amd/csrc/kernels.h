@@ -1992,7 +1992,7 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_count_kernel(KCTX SegDesc sd, const uint
 // cursor bump per (tile, non-empty bucket); the tile is then re-ordered by bucket in LDS so
 // that consecutive lanes write consecutive slots (a bucket receives a run of consecutive
 // elements from every tile instead of 64 scattered 8-byte stores per wave instruction).
-template <typename idx_t, int BITS, int SRC>
+template <typename idx_t, int BITS, int SRC, bool GROUPED>
 GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n_words,
                                                        uint64_t text_base, const uint64_t* __restrict__ in_key,
                                                        const idx_t* __restrict__ in_sa, RunSrc<idx_t> rsrc,
@@ -2024,8 +2024,8 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
     const uint32_t cnt = (uint32_t)(t.s1 - start < TILE_E ? t.s1 - start : TILE_E);
     const BucketParams bp = bps[g];
     const uint64_t b0 = bstart[g];
-    const bool grouped = gfirst != nullptr && bp.B > 1 && bp.B <= BUCKET_LDS;
-    const BucketParams fbp = gfirst != nullptr ? fbps[g] : bp;
+    const bool grouped = GROUPED && bp.B > 1 && bp.B <= BUCKET_LDS;      // GROUPED: a build of its own, the plain scatter is hot
+    const BucketParams fbp = GROUPED ? fbps[g] : bp;
     SHARED_ARRAY(uint32_t, hist, TILE_BINS + 1);          // counts -> exclusive prefix inside the tile
     SHARED_ARRAY(idx_t, obase, TILE_BINS);                // global slot of the tile's first element of bucket i, minus its prefix
                                                           // (idx_t: 72 KiB of LDS at 32-bit indices -> two workgroups per CU)

@@ -419,18 +419,18 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
             const BucketParams* fbps = grouped ? bk.fparams : nullptr;
             const uint32_t* gfirst = grouped ? bk.gfirst : nullptr;
             BackendEvent s0 = be.record();
-            if (from_text)
-                CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, SRC_TEXT>), n_tiles, TILE_NT, be, psd, P, n_words, tbase, (const uint64_t*)nullptr,
-                            (const idx_t*)nullptr, rsrc, (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, sub_start, cap,
-                            static_cast<idx_t*>(bk.cursor), okey, osa, fbps, gfirst);
-            else if (runs)
-                CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, SRC_RUNS>), n_tiles, TILE_NT, be, psd, P, n_words, tbase, (const uint64_t*)cur.key,
-                            (const idx_t*)cur.sa, rsrc, (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, sub_start, cap,
-                            static_cast<idx_t*>(bk.cursor), okey, osa, fbps, gfirst);
-            else
-                CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, SRC_ARRAYS>), n_tiles, TILE_NT, be, psd, P, n_words, tbase, (const uint64_t*)cur.key,
-                            (const idx_t*)cur.sa, rsrc, (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, sub_start, cap,
-                            static_cast<idx_t*>(bk.cursor), okey, osa, fbps, gfirst);
+#define CAPS_SCATTER_LAUNCH(SRC_, GRP_, ikey, isa)                                                                          \
+            CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, SRC_, GRP_>), n_tiles, TILE_NT, be, psd, P, n_words, tbase, ikey, isa, rsrc, \
+                        (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, sub_start, cap, static_cast<idx_t*>(bk.cursor),       \
+                        okey, osa, fbps, gfirst)
+            const uint64_t* nokey = nullptr;
+            const idx_t* nosa = nullptr;
+            if (from_text) { if (grouped) CAPS_SCATTER_LAUNCH(SRC_TEXT, true, nokey, nosa); else CAPS_SCATTER_LAUNCH(SRC_TEXT, false, nokey, nosa); }
+            else if (runs) { if (grouped) CAPS_SCATTER_LAUNCH(SRC_RUNS, true, (const uint64_t*)cur.key, (const idx_t*)cur.sa);
+                             else CAPS_SCATTER_LAUNCH(SRC_RUNS, false, (const uint64_t*)cur.key, (const idx_t*)cur.sa); }
+            else { if (grouped) CAPS_SCATTER_LAUNCH(SRC_ARRAYS, true, (const uint64_t*)cur.key, (const idx_t*)cur.sa);
+                   else CAPS_SCATTER_LAUNCH(SRC_ARRAYS, false, (const uint64_t*)cur.key, (const idx_t*)cur.sa); }
+#undef CAPS_SCATTER_LAUNCH
             BackendEvent s1 = be.record();
             if (o.scatter_clock) { o.scatter_clock->spans.push_back({s0, s1}); o.scatter_clock->elems.push_back(n_elems); }
         };
