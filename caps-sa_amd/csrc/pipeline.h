@@ -653,7 +653,9 @@ private:
             o.count_clock = &count_clock_;
             o.pass_counters = pl_.pass_elems + pass_base_;
             o.slot_stats = slot_stats_;
-            o.speculate = std::getenv("CAPS_SA_NO_SLOTS") == nullptr;      // debugging switch: always take the count pass
+            // no speculation once a split of this build had to be redone (phase 2 of a text whose phase 1 overflowed
+            // its slots would overflow them too: the attempt costs a scatter pass).  CAPS_SA_NO_SLOTS: never (debugging)
+            o.speculate = std::getenv("CAPS_SA_NO_SLOTS") == nullptr && slot_stats_[1] == 0;
         }
         SortResult<idx_t> r = segmented_sort<idx_t, BITS>(be_, pl_.P, pl_.n, pl_.desc, s, n_tiles, max_len, cur, oth, n_elems, o);
         if (timed) pass_base_ += r.passes;

@@ -106,6 +106,7 @@ public:
 
     void phase1(void* d_sample_keys, void* d_sample_sa) override
     {
+        slot_stats_[0] = slot_stats_[1] = 0;
         BackendEvent e0 = be_.record();
         bits_ = prepare_text(be_, dT_, n_, P_, present_, lut_);
         if (G_) {
@@ -302,6 +303,7 @@ private:
     uint32_t p_ = 0, ppp_ = 0, g0_ = 0, g1_ = 0, G_ = 0, G2_ = 0, jlo_ = 0, jhi_ = 0, n_tiles1_ = 0, n_tiles2_ = 0, n_desc_ = 0;
     uint64_t s_ = 0, text_base_ = 0, local_n_ = 0, m_local_ = 0, m_total_ = 0, recv_total_ = 0, slice_off_ = 0, max_len2_ = 0;
     int bits_ = 0;
+    uint32_t slot_stats_[2] = {0, 0};    // bucket splits of the current build: kept with slots / redone
     uint32_t* P_ = nullptr;
     uint32_t* present_ = nullptr;
     uint8_t* lut_ = nullptr;
@@ -381,7 +383,8 @@ private:
         o.skip_finished = skip_finished;
         o.bk = bk;
         o.unify = unify;
-        o.speculate = bk != nullptr && std::getenv("CAPS_SA_NO_SLOTS") == nullptr;   // as in Builder::seg_sort
+        o.slot_stats = slot_stats_;
+        o.speculate = bk != nullptr && std::getenv("CAPS_SA_NO_SLOTS") == nullptr && slot_stats_[1] == 0;   // as in Builder::seg_sort
         return segmented_sort<idx_t, BITS>(be_, P_, n_, tdesc_, s, n_tiles, max_len, a, b, n_elems, o);
     }
     BucketBufs buckets(uint64_t n_elems, uint32_t G)
