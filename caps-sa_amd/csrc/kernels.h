@@ -693,10 +693,16 @@ extern "C" void caps_emul_count_tile2(bool two_level_ok);
 extern "C" void caps_emul_count_tile3(bool equalised_ok);
 #endif
 constexpr uint32_t TILE_BINS = TILE_BINS_;
+// Largest bin the exact in-bin ranking (quadratic in the bin) accepts: in tile_sort_kernel, whose linear map either
+// works (uniform keys: bins of 2-3) or is hopeless, and in tile_sort_eq_kernel, the last stop before the comparison sort.
 #ifndef CAPS_TILE_BIN_LIMIT
-#define CAPS_TILE_BIN_LIMIT 128   /* measured: 24 / 64 / 96 / 128 / 256 / 1024 -> 40.4 / 38.0 / 37.5 / 35.6 / 38.2 / 44.9 ms on the genome-like 256 Mi input; no effect on uniform keys */
+#define CAPS_TILE_BIN_LIMIT 48    /* genome-like 3e9: 16 / 24 / 48 / 128 -> 300 / 301 / 299 / 320 ms (the eq kernel sorts crowded tiles cheaper than a quadratic ranking of big bins) */
+#endif
+#ifndef CAPS_EQ_BIN_LIMIT
+#define CAPS_EQ_BIN_LIMIT 128
 #endif
 constexpr uint32_t TILE_BIN_LIMIT = CAPS_TILE_BIN_LIMIT;
+constexpr uint32_t EQ_BIN_LIMIT = CAPS_EQ_BIN_LIMIT;
 
 // ----------------------------------------------------------------------------------
 // a4/a5: tile sort -- one workgroup sorts up to TILE_E suffixes in LDS and emits the
@@ -925,29 +931,34 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
 
 // ---- tile_sort_eq_kernel: second chance for the tiles tile_sort_kernel could not finish --------
 // Keys that are far from uniform over the tile's range (skewed k-mer composition: every real genome)
-// crowd a few bins of the linear map.  Here the map is equalised with the tile's own data: a coarse
-// histogram (EQ_COARSE linear bins) gives a piecewise-linear CDF, and an element's bin is its estimated
-// rank: bin = (count before its coarse bin + position inside the coarse bin x count of that bin) *
-// TILE_BINS / cnt -- monotone in the key, so the counting sort + exact in-bin ranking of tile_sort_kernel
+// crowd a few bins of the linear map.  Here the map is equalised with the tile's own data, iteratively:
+// every element holds a 24-bit POSITION (bin.fraction, first from the linear map); the histogram of the
+// positions' bins is a piecewise-linear CDF, and the new position is the estimated rank it gives:
+// (count before my bin + fraction x count of my bin) * TILE_BINS / cnt.  After EQ_ROUNDS rounds the bin of
+// the position is the counting sort's bin -- monotone in the key, so the exact in-bin ranking of tile_sort_kernel
 // finish the job unchanged.  Takes the tiles from tile_sort_kernel's queue (redo[0] = length) with a
 // fixed grid; a tile that still has a bin above TILE_BIN_LIMIT (clusters of suffixes that share more
 // chars than the coarse bins resolve), or a deep tie, goes on to tile_sort_general_kernel (redo2).
 // A separate kernel rather than a branch of tile_sort_kernel: that one runs at the register budget.
-constexpr uint32_t EQ_FRAC_BITS = 8;              // position inside a coarse bin, in 1/256
-constexpr uint32_t EQ_COARSE = (TILE_BINS_ * 32u) >> EQ_FRAC_BITS;     // 256 coarse bins for the 2048 bins of a 4096-element tile
+#ifndef CAPS_EQ_ROUNDS
+#define CAPS_EQ_ROUNDS 2          /* measured on skewed-Markov tiles (simulation): largest bin, median 243 (linear) -> 50 / 26 / 13 after 1 / 2 / 3 rounds */
+#endif
+constexpr uint32_t EQ_ROUNDS = CAPS_EQ_ROUNDS;
+constexpr uint32_t EQ_FRAC_BITS = 13;             // position inside a bin; a position is bin * 2^13 + fraction < 2^24 at 2048 bins
+static_assert((uint64_t)TILE_BINS_ << EQ_FRAC_BITS <= (1u << 24), "positions fit 24 bits");
 
-// 16-bit position of the key on the tile's linear map: (bin of bucket_of(tb, .)) * 32 + 5 more bits
-DEV_INLINE uint32_t eq_pos16(const BucketParams& bp, uint64_t key)
+// Position of the key on the tile's linear map: (bin of bucket_of(tb, .)) << EQ_FRAC_BITS plus that many more bits
+DEV_INLINE uint32_t eq_pos(const BucketParams& bp, uint64_t key)
 {
-    const uint32_t top = bp.B * 32u - 1u;
+    const uint32_t top = (bp.B << EQ_FRAC_BITS) - 1u;
     if (key <= bp.kmin) return 0;
     const uint64_t d = key - bp.kmin;
     if (d >= bp.range) return top;
     const uint32_t d32 = (uint32_t)((d << bp.shift) >> 32);
     const uint64_t prod = (uint64_t)d32 * bp.m;
     const uint32_t sh = 32u + bp.post;                                   // bucket = prod >> sh
-    const uint32_t p16 = (uint32_t)(sh >= 5 ? prod >> (sh - 5) : prod << (5 - sh));
-    return p16 < top ? p16 : top;
+    const uint32_t x = (uint32_t)(sh >= EQ_FRAC_BITS ? prod >> (sh - EQ_FRAC_BITS) : prod << (EQ_FRAC_BITS - sh));
+    return x < top ? x : top;
 }
 
 template <typename idx_t, int BITS, bool FROM_TEXT>
@@ -961,7 +972,6 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_eq_kernel(KCTX 
     SHARED_ARRAY(uint64_t, skey, TILE_E);
     SHARED_ARRAY(idx_t, ssa, TILE_E);
     SHARED_ARRAY(uint32_t, hist, TILE_BINS + 1);
-    SHARED_ARRAY(uint32_t, chist, EQ_COARSE + 1);
     SHARED_ARRAY(uint64_t, kmm, 2);
     SHARED_ARRAY(uint32_t, flag, 1);
     TL_DECL(uint64_t, rk, TILE_EPT);
@@ -979,60 +989,59 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_eq_kernel(KCTX 
     const bool direct = with_lcp && fin.sa != nullptr;
     const uint64_t in0 = slot_cap ? (uint64_t)g * slot_cap : start;
     TILE_SORT_LOAD
-    PAR(tid) { for (uint32_t i = tid; i <= EQ_COARSE; i += K_BLOCK_DIM) chist[i] = 0; }
     TILE_SORT_RANGE
-    bool fast = cnt > TILE_BIN_LIMIT && tb.range > 0 && tb.B == TILE_BINS;
+    bool fast = cnt > EQ_BIN_LIMIT && tb.range > 0 && tb.B == TILE_BINS;
     if (fast) {
-        PAR(tid) {                                             // coarse histogram of the tile
+        PAR(tid) {
             UNROLL
             for (uint32_t k = 0; k < TILE_EPT; ++k) {
                 const uint32_t e = tid + k * TILE_NT;
-                if (e < cnt) {
-                    const uint32_t p16 = eq_pos16(tb, TL(rk, tid, k));
-                    TL(rb, tid, k) = p16;
-                    FETCH_ADD_U32(&chist[p16 >> EQ_FRAC_BITS], 1u);
-                }
+                if (e < cnt) TL(rb, tid, k) = eq_pos(tb, TL(rk, tid, k));
             }
         }
-        SYNC();
-        PAR(tid) {                                             // exclusive scan of the 256 counters, chist[EQ_COARSE] = cnt
-#ifdef CAPS_EMUL
-            if (tid == 0) { uint32_t run = 0; for (uint32_t i = 0; i <= EQ_COARSE; ++i) { const uint32_t c = i < EQ_COARSE ? chist[i] : 0; chist[i] = run; run += c; } }
-#else
-            if (tid < 64) {                                    // one wave, EQ_COARSE / 64 counters per lane
-                constexpr uint32_t CPL = EQ_COARSE / 64;
-                static_assert(CPL >= 1 && CPL * 64 == EQ_COARSE, "coarse bins per lane");
-                uint32_t v[CPL], sum = 0;
-                UNROLL
-                for (uint32_t i = 0; i < CPL; ++i) { v[i] = chist[tid * CPL + i]; sum += v[i]; }
-                uint32_t x = sum;
-                UNROLL
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint32_t y = __shfl_up(x, d, 64);
-                    if ((int)tid >= d) x += y;
-                }
-                uint32_t run = x - sum;
-                UNROLL
-                for (uint32_t i = 0; i < CPL; ++i) { chist[tid * CPL + i] = run; run += v[i]; }
-                if (tid == 63) chist[EQ_COARSE] = run;
+        // position -> estimated rank, EQ_ROUNDS times: histogram of the positions' bins, its prefix sums are a
+        // piecewise-linear CDF, the new position is the CDF value scaled back to [0, TILE_BINS)
+        const uint64_t K = ((uint64_t)TILE_BINS << 32) / cnt;
+        for (uint32_t round = 0; round < EQ_ROUNDS; ++round) {
+            if (round) {
+                PAR(tid) { for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0; }
+                SYNC();
             }
-#endif
+            PAR(tid) {
+                UNROLL
+                for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                    const uint32_t e = tid + k * TILE_NT;
+                    if (e < cnt) FETCH_ADD_U32(&hist[TL(rb, tid, k) >> EQ_FRAC_BITS], 1u);
+                }
+            }
+            SYNC();
+            block_exclusive_scan_bins(KCTX_PASS hist);
+            PAR(tid) {
+                UNROLL
+                for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                    const uint32_t e = tid + k * TILE_NT;
+                    if (e < cnt) {
+                        const uint32_t x = TL(rb, tid, k);
+                        const uint32_t bn = x >> EQ_FRAC_BITS, fr = x & ((1u << EQ_FRAC_BITS) - 1u);
+                        const uint32_t before = hist[bn], here = hist[bn + 1] - before;
+                        const uint64_t E = ((uint64_t)before << EQ_FRAC_BITS) + (uint64_t)here * fr;     // < cnt * 2^13
+                        const uint32_t y = (uint32_t)((E * K) >> 32);                                     // < TILE_BINS * 2^13
+                        TL(rb, tid, k) = y < (TILE_BINS << EQ_FRAC_BITS) ? y : (TILE_BINS << EQ_FRAC_BITS) - 1u;
+                    }
+                }
+            }
+            SYNC();
         }
+        PAR(tid) { for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0; }
         SYNC();
-        const uint64_t K = ((uint64_t)TILE_BINS << (32 - EQ_FRAC_BITS)) / cnt;       // bin = (E * K) >> 32, E = 256 * estimated rank
         PAR(tid) {
             UNROLL
             for (uint32_t k = 0; k < TILE_EPT; ++k) {
                 const uint32_t e = tid + k * TILE_NT;
                 if (e < cnt) {
-                    const uint32_t p16 = TL(rb, tid, k);
-                    const uint32_t c = p16 >> EQ_FRAC_BITS, fr = p16 & ((1u << EQ_FRAC_BITS) - 1u);
-                    const uint32_t before = chist[c], here = chist[c + 1] - before;
-                    const uint64_t E = ((uint64_t)before << EQ_FRAC_BITS) + (uint64_t)here * fr;
-                    uint32_t bin = (uint32_t)((E * K) >> 32);
-                    bin = bin < TILE_BINS ? bin : TILE_BINS - 1;
+                    const uint32_t bin = TL(rb, tid, k) >> EQ_FRAC_BITS;
                     const uint32_t r = FETCH_ADD_U32(&hist[bin], 1u);
-                    if (r >= TILE_BIN_LIMIT) flag[0] = 1;
+                    if (r >= EQ_BIN_LIMIT) flag[0] = 1;
                     TL(rb, tid, k) = bin;
                     TL(rd, tid, k) = r;
                 }
