@@ -496,7 +496,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
                 CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, SRC_ARRAYS>), pgrid, TILE_NT, be, psd, P, n_words, tbase, (const uint64_t*)cur.key, rsrc,
                             cparams, cstart, ccount);
             if (equalise) {
-                CAPS_LAUNCH(bucket_group_kernel, (s.G + 255) / 256, 256, be, s.G, (const uint64_t*)bk.segB, (const uint64_t*)bk.bstart,
+                CAPS_LAUNCH(bucket_group_kernel, s.G < 16384 ? (s.G ? s.G : 1) : 16384, 256, be, s.G, (const uint64_t*)bk.segB, (const uint64_t*)bk.bstart,
                             (const uint64_t*)bk.fsegB, (const uint64_t*)bk.fstart, (const uint64_t*)bk.fcount, bk.count, bk.gfirst);
                 CAPS_LAUNCH(bucket_ranges_kernel, (bk.nb_cap + 255) / 256, 256, be, (const uint64_t*)bk.bstart, s.G,
                             (const BucketParams*)bk.params, o.pkey, o.range_mode, o.part_off, o.part_total ? o.part_total : s.G,
