@@ -1801,9 +1801,14 @@ GLOBAL_FN LAUNCH_BOUNDS(256) bucket_plan_kernel(KCTX const uint64_t* __restrict_
             }
             uint32_t B = 1;
             if (enable && len > TILE_E && kmax > kmin) B = (uint32_t)((len + BUCKET_TARGET - 1) / BUCKET_TARGET);
-            // fine > 1: the map of the equalised split's FINE buckets (bucket_group_kernel): `fine` per bucket slot,
-            // as many as the LDS histograms hold; segments with more slots than that keep one fine bucket per slot
-            if (fine > 1 && B > 1 && B <= BUCKET_LDS) B = (uint64_t)B * fine <= BUCKET_LDS ? B * fine : BUCKET_LDS;
+            // fine > 1: the map of the equalised split's FINE buckets (bucket_group_kernel): k <= `fine` per bucket slot,
+            // as many as the LDS histograms hold.  A whole number per slot, so that the plain split (k consecutive fine
+            // buckets per slot) is one of the groupings and the chosen one is never worse; segments with more than
+            // BUCKET_LDS / 2 slots keep one fine bucket per slot.
+            if (fine > 1 && B > 1 && B <= BUCKET_LDS) {
+                const uint32_t k = BUCKET_LDS / B < fine ? BUCKET_LDS / B : fine;
+                B *= k;
+            }
             const BucketParams q = make_bucket_params(kmin, kmax, B);
             bp[g] = q;
             segB[g] = B;
@@ -1875,17 +1880,6 @@ GLOBAL_FN LAUNCH_BOUNDS(256) bucket_group_kernel(KCTX uint32_t G, const uint64_t
         }
         SYNC();                                          // fc is free for the next segment
     }
-}
-
-// group of fine bucket f: the last slot whose first fine bucket is <= f (tab[0] = 0, unused slots hold F > f)
-DEV_INLINE uint32_t group_of(const uint32_t* tab, uint32_t B, uint32_t f)
-{
-    uint32_t lo = 0, hi = B;                       // tab[lo] <= f < tab[hi] (hi = B: +infinity)
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (tab[mid] <= f) lo = mid; else hi = mid;
-    }
-    return lo;
 }
 
 // Key range of every bucket (inverse of bucket_of, to within rounding: keys just outside are
@@ -2062,14 +2056,18 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
     uint32_t* twin = reinterpret_cast<uint32_t*>(skey);
     uint64_t* lsrc = skey;
     idx_t* lrow = ssa;
-    uint32_t* gtab = reinterpret_cast<uint32_t*>(sbk);    // group table of the segment (sbk is written after its last use)
-    static_assert(sizeof(uint16_t) * TILE_E >= sizeof(uint32_t) * BUCKET_LDS, "group table fits the bucket-id staging array");
+    uint16_t* gtab = sbk;                                  // fine bucket -> bucket slot of the segment (sbk is written after its last use)
+    static_assert(TILE_E >= BUCKET_LDS && BUCKET_LDS <= 65536, "group table fits the bucket-id staging array");
     const uint64_t w0 = text_win_base<BITS>(text_base + start);
     RUNS_TILE_SETUP
     if (lds || FROM_TEXT || FROM_RUNS) {
         PAR(tid) {
             if (lds) for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0;
-            if (grouped) for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM) gtab[i] = gfirst[b0 + i];
+            if (grouped)                                   // slot i owns the fine buckets [gfirst[i], gfirst[i + 1]) (F for unused slots)
+                for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM) {
+                    const uint32_t f0 = gfirst[b0 + i], f1 = i + 1 < bp.B ? gfirst[b0 + i + 1] : fbp.B;
+                    for (uint32_t f = f0; f < f1 && f < fbp.B; ++f) gtab[f] = (uint16_t)i;
+                }
             if (FROM_TEXT)
                 for (uint32_t i = tid; i < TEXT_WIN; i += K_BLOCK_DIM) twin[i] = w0 + i < n_words ? P[w0 + i] : 0u;
             if (FROM_RUNS) { RUNS_STAGE(tid) }
@@ -2092,7 +2090,7 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
                 if (bp.B == 1) r = e;                                        // identity: the segment is its own bucket
                 else {
                     bk = bucket_of(fbp, key);
-                    if (grouped) bk = group_of(gtab, bp.B, bk);
+                    if (grouped) bk = gtab[bk];
                     r = lds ? FETCH_ADD_U32(&hist[bk], 1u) : caps_fetch_add(&cursor[b0 + bk], (idx_t)1);
                 }
                 TL(rk, tid, k) = key;
