@@ -55,17 +55,19 @@ if __name__ == "__main__":
         for ln, cnt in ((2_000_000, 1), (500_000, 5), (50_000, 100)):
             for a in torch.randint(0, n - ln, (cnt,), device="cuda", generator=g).tolist():
                 T[a:a + ln] = ord("G")
-    SA = torch.empty(n, dtype=torch.int32, device="cuda")
-    LCP = torch.empty(n, dtype=torch.int32, device="cuda")
+    bits = int(os.environ.get("IDX", "32"))          # IDX=64: the u64 kernels
+    dt_idx = torch.int32 if bits == 32 else torch.int64
+    SA = torch.empty(n, dtype=dt_idx, device="cuda")
+    LCP = torch.empty(n, dtype=dt_idx, device="cuda")
     for it in range(2):
         torch.cuda.synchronize()
         t0 = time.time()
-        st = L.build_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr(), p=8000)
+        st = L.build_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr(), p=8000, idx_bits=bits)
         torch.cuda.synchronize()
         dt = time.time() - t0
-    errs = L.verify_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr())
+    errs = L.verify_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr(), idx_bits=bits)
     keep = ("long_runs", "slot_splits", "slot_splits_redone", "ms_total", "ms_sort_subarrays", "ms_merge_partitions", "merge_passes_phase1", "merge_passes_phase2",
             "max_partition", "tile_sort_ms", "merge_pass_ms", "bucket_scatter_ms")
-    print(json.dumps({"n": n, "wall_ms": 1e3 * dt, "G_suffixes_per_s": n / dt / 1e9, "verify_errors": errs,
+    print(json.dumps({"n": n, "idx_bits": bits, "wall_ms": 1e3 * dt, "G_suffixes_per_s": n / dt / 1e9, "verify_errors": errs,
                       "max_lcp": int(LCP.max().item()), "mean_lcp": float(LCP.double().mean().item()),
                       **{k: st[k] for k in keep}}))
