@@ -2242,7 +2242,7 @@ GLOBAL_FN LAUNCH_BOUNDS(256) pick_pivots_kernel(KCTX const uint64_t* __restrict_
 // Pm[g*(np+2) .. ] = {0, ub(pivot_0), ..., ub(pivot_{np-1}), len_g}.
 // One thread per (segment, pivot); exact comparator (no 65,536-char cutoff, cpp:261).
 // ----------------------------------------------------------------------------------
-template <typename idx_t, int BITS>
+template <typename idx_t, int BITS, bool GALLOP = false>
 GLOBAL_FN LAUNCH_BOUNDS(256) locate_kernel(KCTX const uint32_t* __restrict__ P, uint64_t n,
                                            const uint64_t* __restrict__ seg_start, uint32_t G,
                                            const uint64_t* __restrict__ key, const idx_t* __restrict__ sa,
@@ -2261,6 +2261,30 @@ GLOBAL_FN LAUNCH_BOUNDS(256) locate_kernel(KCTX const uint32_t* __restrict__ P, 
         if (j < np) {
             const uint64_t pk = pkey[j], ps = (uint64_t)psa[j];
             uint64_t lo = 0, hi = len;                                    // first element > pivot
+            // The pivots are quantiles of all suffixes, so pivot j sits near rank (j + 1) * len / (np + 1) of any subarray,
+            // whatever the key distribution (binomial spread).  Short subarrays (fewer than 8 elements per pivot: C2 has 4)
+            // gallop from that guess to a bracket and bisect there: C2's locate 1.48 -> 0.87 ms.  Long ones keep the plain
+            // bisection: its upper levels probe the same few cache lines for all 64 pivots of a wave, while every
+            // galloping probe of a wave touches 64 lines (C3, 47 elements per pivot: 4.6 -> 8 ms with the gallop).
+            if (GALLOP && len > 64 && len < 8 * (uint64_t)np) {        // a build of its own: the plain one keeps its registers
+                const uint64_t g0 = ((uint64_t)(j + 1) * len) / ((uint64_t)np + 1);          // < len
+                uint64_t step = 32;
+                if (suffix_less<BITS>(P, n, pk, ps, key[s0 + g0], (uint64_t)sa[s0 + g0])) {   // element g0 > pivot: answer <= g0
+                    hi = g0;
+                    while (hi > 0) {
+                        const uint64_t probe = hi > step ? hi - step : 0;
+                        if (suffix_less<BITS>(P, n, pk, ps, key[s0 + probe], (uint64_t)sa[s0 + probe])) { hi = probe; step *= 2; }
+                        else { lo = probe + 1; break; }
+                    }
+                } else {                                                                      // answer > g0
+                    lo = g0 + 1;
+                    while (lo < len) {
+                        const uint64_t probe = lo + step - 1 < len ? lo + step - 1 : len - 1;
+                        if (!suffix_less<BITS>(P, n, pk, ps, key[s0 + probe], (uint64_t)sa[s0 + probe])) { lo = probe + 1; step *= 2; }
+                        else { hi = probe; break; }
+                    }
+                }
+            }
             while (lo < hi) {
                 const uint64_t mid = (lo + hi) >> 1;
                 if (suffix_less<BITS>(P, n, pk, ps, key[s0 + mid], (uint64_t)sa[s0 + mid])) hi = mid;

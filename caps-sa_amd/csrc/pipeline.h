@@ -731,9 +731,14 @@ private:
             // ---- locate (a7/a8)
             const uint32_t np = p - 1;
             const uint32_t bpr = (np + 255) / 256;
-            CAPS_LAUNCH((locate_kernel<idx_t, BITS>), capped_grid((uint64_t)p * bpr, 256), 256, be_, (const uint32_t*)pl_.P, n,
-                        (const uint64_t*)pl_.seg1.seg_start, p, (const uint64_t*)cur.key, (const idx_t*)cur.sa,
-                        (const uint64_t*)pl_.pkey, (const idx_t*)pl_.psa, np, pl_.Pm);
+            if (n / p < 8ull * np)          // short subarrays: galloping searches (locate_kernel)
+                CAPS_LAUNCH((locate_kernel<idx_t, BITS, true>), capped_grid((uint64_t)p * bpr, 256), 256, be_, (const uint32_t*)pl_.P, n,
+                            (const uint64_t*)pl_.seg1.seg_start, p, (const uint64_t*)cur.key, (const idx_t*)cur.sa,
+                            (const uint64_t*)pl_.pkey, (const idx_t*)pl_.psa, np, pl_.Pm);
+            else
+                CAPS_LAUNCH((locate_kernel<idx_t, BITS, false>), capped_grid((uint64_t)p * bpr, 256), 256, be_, (const uint32_t*)pl_.P, n,
+                            (const uint64_t*)pl_.seg1.seg_start, p, (const uint64_t*)cur.key, (const idx_t*)cur.sa,
+                            (const uint64_t*)pl_.pkey, (const idx_t*)pl_.psa, np, pl_.Pm);
             e4 = be_.record();
 
             // ---- partition sizes, offsets, collate (a9)
