@@ -721,7 +721,10 @@ private:
                         pl_.ppp, (const uint64_t*)cur.key, (const idx_t*)cur.sa, pl_.SA_.key, pl_.SA_.sa);
             CAPS_LAUNCH(uniform_segments_kernel, 1, 256, be_, pl_.segS.seg_start, 1u, m, m);
             prepare_segments(pl_.segS, tiles_of(m));
-            SortResult<idx_t> rs = seg_sort<BITS>(pl_.segS, tiles_of(m), m, pl_.SA_, pl_.SB_, m, SortOpts(), false);
+            SortOpts os;
+            os.bk = &pl_.bk;                    // phase 1's bucket tables are free again: the samples are bucket-sorted too
+            os.unify = true;                    //   (one split + tile sort instead of ~11 merge passes over 5.6 M samples)
+            SortResult<idx_t> rs = seg_sort<BITS>(pl_.segS, tiles_of(m), m, pl_.SA_, pl_.SB_, m, os, false);
             passesS = rs.passes;
             ElemBuf<idx_t> smp = rs.uniform();
             CAPS_LAUNCH((pick_pivots_kernel<idx_t>), (p + 255) / 256, 256, be_, (const uint64_t*)smp.key, (const idx_t*)smp.sa,
