@@ -52,6 +52,11 @@ class Stats(ctypes.Structure):
         ("collate_ms", ctypes.c_double),
         ("slot_splits", ctypes.c_uint32),
         ("slot_splits_redone", ctypes.c_uint32),
+        ("path_direct", ctypes.c_uint32),
+        ("path_fallback", ctypes.c_uint32),
+        ("direct_groups", ctypes.c_uint32),
+        ("direct_reserved_", ctypes.c_uint32),
+        ("direct_max_group", ctypes.c_uint64),
     ]
 
     def as_dict(self) -> dict:

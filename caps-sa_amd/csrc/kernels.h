@@ -75,6 +75,13 @@ struct SegDesc {
     uint32_t G;
 };
 
+// End of segment g: seg_start[g + 1] for contiguous segments; seg_end[g] when the segments sit in
+// fixed-capacity regions with gaps between them (the groups of the direct path, pipeline.h).
+DEV_INLINE uint64_t seg_end_of(const uint64_t* __restrict__ seg_start, const uint64_t* __restrict__ seg_end, uint64_t g)
+{
+    return seg_end ? seg_end[g] : seg_start[g + 1];
+}
+
 DEV_INLINE TileInfo tile_info(const SegDesc& sd, uint32_t b) { return sd.tile_rec[b]; }
 
 // Geometry of the run pair a tile belongs to during a merge pass with run length R
@@ -408,8 +415,8 @@ GLOBAL_FN LAUNCH_BOUNDS(1024) scan_sizes_kernel(KCTX const uint64_t* __restrict_
 // tile_off[G+1] = exclusive scan of ceil(len/TILE_E); out2[0] = #tiles, out2[1] = max segment
 // length (out2 must be zeroed before the launch).  Single workgroup; LDS Hillis-Steele scan
 // per chunk of 1024 segments.
-GLOBAL_FN LAUNCH_BOUNDS(1024) seg_prepare_kernel(KCTX const uint64_t* __restrict__ seg_start, uint32_t G,
-                                                 uint32_t* __restrict__ tile_off, uint64_t* __restrict__ out2)
+GLOBAL_FN LAUNCH_BOUNDS(1024) seg_prepare_kernel(KCTX const uint64_t* __restrict__ seg_start, const uint64_t* __restrict__ seg_end,
+                                                 uint32_t G, uint32_t* __restrict__ tile_off, uint64_t* __restrict__ out2)
 {
     SHARED_ARRAY(uint32_t, buf, 2048);
     uint32_t carry = 0;
@@ -417,7 +424,7 @@ GLOBAL_FN LAUNCH_BOUNDS(1024) seg_prepare_kernel(KCTX const uint64_t* __restrict
         PAR(tid) {
             const uint32_t g = base + tid;
             uint64_t len = 0;
-            if (g < G) len = seg_start[g + 1] - seg_start[g];
+            if (g < G) len = seg_end_of(seg_start, seg_end, g) - seg_start[g];
             buf[tid] = (uint32_t)((len + TILE_E - 1) / TILE_E);
             if (len) ATOMIC_MAX_U64(&out2[1], len);
         }
@@ -433,7 +440,7 @@ GLOBAL_FN LAUNCH_BOUNDS(1024) seg_prepare_kernel(KCTX const uint64_t* __restrict
         PAR(tid) {
             const uint32_t g = base + tid;
             if (g < G) {
-                const uint64_t len = seg_start[g + 1] - seg_start[g];
+                const uint64_t len = seg_end_of(seg_start, seg_end, g) - seg_start[g];
                 tile_off[g] = carry + buf[src * 1024 + tid] - (uint32_t)((len + TILE_E - 1) / TILE_E);
             }
         }
@@ -505,8 +512,8 @@ GLOBAL_FN LAUNCH_BOUNDS(1024) add_offsets_kernel(KCTX OutT* __restrict__ out, ui
 }
 
 // cnt[g] = ceil(len_g / TILE_E); out2[1] = max len (out2 zeroed before the launch).
-GLOBAL_FN LAUNCH_BOUNDS(256) tile_count_kernel(KCTX const uint64_t* __restrict__ seg_start, uint32_t G, uint64_t* __restrict__ cnt,
-                                               uint64_t* __restrict__ out2)
+GLOBAL_FN LAUNCH_BOUNDS(256) tile_count_kernel(KCTX const uint64_t* __restrict__ seg_start, const uint64_t* __restrict__ seg_end,
+                                               uint32_t G, uint64_t* __restrict__ cnt, uint64_t* __restrict__ out2)
 {
     SHARED_ARRAY(uint64_t, mx, 1);
     PAR(tid) { if (tid == 0) mx[0] = 0; }
@@ -514,7 +521,7 @@ GLOBAL_FN LAUNCH_BOUNDS(256) tile_count_kernel(KCTX const uint64_t* __restrict__
     PAR(tid) {
         const uint64_t g = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
         if (g < G) {
-            const uint64_t len = seg_start[g + 1] - seg_start[g];
+            const uint64_t len = seg_end_of(seg_start, seg_end, g) - seg_start[g];
             cnt[g] = (len + TILE_E - 1) / TILE_E;
             if (len) ATOMIC_MAX_LDS_U64(&mx[0], len);
         }
@@ -530,8 +537,8 @@ GLOBAL_FN LAUNCH_BOUNDS(64) tile_total_kernel(KCTX const uint32_t* __restrict__ 
 }
 
 // tile_rec[b] for the segment g with tile_off[g] <= b < tile_off[g+1].
-GLOBAL_FN LAUNCH_BOUNDS(256) tile_map_kernel(KCTX const uint64_t* __restrict__ seg_start, const uint32_t* __restrict__ tile_off, uint32_t G,
-                                             TileInfo* __restrict__ tile_rec)
+GLOBAL_FN LAUNCH_BOUNDS(256) tile_map_kernel(KCTX const uint64_t* __restrict__ seg_start, const uint64_t* __restrict__ seg_end,
+                                             const uint32_t* __restrict__ tile_off, uint32_t G, TileInfo* __restrict__ tile_rec)
 {
     PAR(tid) {
         const uint64_t b = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
@@ -543,7 +550,7 @@ GLOBAL_FN LAUNCH_BOUNDS(256) tile_map_kernel(KCTX const uint64_t* __restrict__ s
             }
             TileInfo t;
             t.s0 = seg_start[lo];
-            t.s1 = seg_start[lo + 1];
+            t.s1 = seg_end_of(seg_start, seg_end, lo);
             t.tl = (uint32_t)b - tile_off[lo];
             t.g = lo;
             t.pad_[0] = t.pad_[1] = 0;
@@ -1784,7 +1791,8 @@ constexpr uint32_t BUCKET_LDS = TILE_BINS_;            // buckets per segment th
 // range_mode 0: keys span the whole 64-bit range (subarrays of text positions);
 // range_mode 1: segment g is partition j = part_off + g of part_total and holds keys in
 // [pkey[j-1], pkey[j]] (partitions between pivots; a shard owns a slice of the partitions).
-GLOBAL_FN LAUNCH_BOUNDS(256) bucket_plan_kernel(KCTX const uint64_t* __restrict__ seg_start, uint32_t G, uint32_t range_mode,
+GLOBAL_FN LAUNCH_BOUNDS(256) bucket_plan_kernel(KCTX const uint64_t* __restrict__ seg_start, const uint64_t* __restrict__ seg_end,
+                                                uint32_t G, uint32_t range_mode,
                                                 const uint64_t* __restrict__ pkey, uint32_t part_off, uint32_t part_total,
                                                 uint32_t enable, uint32_t fine,
                                                 BucketParams* __restrict__ bp, uint64_t* __restrict__ segB)
@@ -1792,7 +1800,7 @@ GLOBAL_FN LAUNCH_BOUNDS(256) bucket_plan_kernel(KCTX const uint64_t* __restrict_
     PAR(tid) {
         const uint32_t g = K_BLOCK_IDX * K_BLOCK_DIM + tid;
         if (g < G) {
-            const uint64_t len = seg_start[g + 1] - seg_start[g];
+            const uint64_t len = seg_end_of(seg_start, seg_end, g) - seg_start[g];
             uint64_t kmin = 0, kmax = ~0ull;
             if (range_mode == 1) {                   // segment g is partition part_off + g of part_total
                 const uint32_t j = part_off + g;
@@ -2004,16 +2012,26 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_count_kernel(KCTX SegDesc sd, const uint
 // cursor bump per (tile, non-empty bucket); the tile is then re-ordered by bucket in LDS so
 // that consecutive lanes write consecutive slots (a bucket receives a run of consecutive
 // elements from every tile instead of 64 scattered 8-byte stores per wave instruction).
-template <typename idx_t, int BITS, int SRC, bool GROUPED>
+// MAP: how a key finds its bucket inside its parent segment --
+//   MAP_LINEAR   linear interpolation over the segment's key range (bps[g]);
+//   MAP_GROUPED  equalised split: fine linear bucket (fbps[g]) -> group table (gfirst) -> bucket slot;
+//   MAP_SPLIT    splitter table (direct path, level A): bucket = #{splitters < key} among the bps[g].B - 1 sorted keys
+//                split[0 .. B-2], staged in LDS and searched branch-free in lockstep for the thread's elements.  Keys only:
+//                all suffixes with one key value land in one bucket, so buckets are consecutive slices of the suffix order.
+constexpr int MAP_LINEAR = 0, MAP_GROUPED = 1, MAP_SPLIT = 2;
+
+template <typename idx_t, int BITS, int SRC, int MAP>
 GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n_words,
                                                        uint64_t text_base, const uint64_t* __restrict__ in_key,
                                                        const idx_t* __restrict__ in_sa, RunSrc<idx_t> rsrc,
                                                        const BucketParams* __restrict__ bps, const uint64_t* __restrict__ bstart,
-                                                       const uint64_t* __restrict__ sub_start, uint32_t slot_cap,
+                                                       const uint64_t* __restrict__ sub_start, uint64_t slot_cap,
                                                        idx_t* __restrict__ cursor,
                                                        uint64_t* __restrict__ out_key, idx_t* __restrict__ out_sa,
-                                                       const BucketParams* __restrict__ fbps, const uint32_t* __restrict__ gfirst)
+                                                       const BucketParams* __restrict__ fbps, const uint32_t* __restrict__ gfirst,
+                                                       const uint64_t* __restrict__ split)
 {
+    constexpr bool GROUPED = MAP == MAP_GROUPED;
     // gfirst != null: equalised split -- the key's FINE bucket (map fbps[g]) is looked up in the segment's group table
     // (bucket_group_kernel) to get its bucket slot.
     // slot_cap != 0 ("speculative" split, no count pass): bucket i of the launch owns the fixed slot
@@ -2059,10 +2077,16 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
     uint16_t* gtab = sbk;                                  // fine bucket -> bucket slot of the segment (sbk is written after its last use)
     static_assert(TILE_E >= BUCKET_LDS && BUCKET_LDS <= 65536, "group table fits the bucket-id staging array");
     const uint64_t w0 = text_win_base<BITS>(text_base + start);
+    // MAP_SPLIT: the splitter table sits in the key staging array too, behind the text window
+    uint64_t* stab = skey + TILE_E / 4;
+    static_assert(TEXT_WIN * sizeof(uint32_t) <= (TILE_E / 4) * sizeof(uint64_t) && TILE_E / 4 + BUCKET_LDS <= TILE_E,
+                  "text window + splitter table fit the key staging array");
+    const uint32_t n_split = MAP == MAP_SPLIT && bp.B > 1 ? bp.B - 1 : 0u;
     RUNS_TILE_SETUP
     if (lds || FROM_TEXT || FROM_RUNS) {
         PAR(tid) {
             if (lds) for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0;
+            if (MAP == MAP_SPLIT && lds) for (uint32_t i = tid; i < n_split; i += K_BLOCK_DIM) stab[i] = split[i];
             if (grouped)                                   // slot i owns the fine buckets [gfirst[i], gfirst[i + 1]) (F for unused slots)
                 for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM) {
                     const uint32_t f0 = gfirst[b0 + i], f1 = i + 1 < bp.B ? gfirst[b0 + i + 1] : fbp.B;
@@ -2074,6 +2098,39 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
         }
         SYNC();
     }
+    if (MAP == MAP_SPLIT && lds) {
+        // keys first, then the TILE_EPT table searches of a thread in lockstep (independent LDS reads in flight together)
+        const uint32_t top = pow2_above(n_split);
+        PAR(tid) {
+            UNROLL
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                const uint32_t e = tid + k * TILE_NT;
+                const uint64_t src = start + e;
+                uint64_t key = 0;
+                idx_t sa = 0;
+                if (e < cnt) {
+                    key = FROM_TEXT ? window64<BITS>(twin, text_base + start + e - w0 * TextTraits<BITS>::CPW) : in_key[src];
+                    sa = FROM_TEXT ? (idx_t)(text_base + start + e) : in_sa[src];
+                }
+                TL(rk, tid, k) = key;
+                TL(rs, tid, k) = sa;
+                TL(rb, tid, k) = 0;
+            }
+            for (uint32_t s = top >> 1; s >= 1; s >>= 1) {
+                UNROLL
+                for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                    const uint32_t idx = TL(rb, tid, k) + s - 1;
+                    const uint64_t mk = stab[idx < n_split ? idx : n_split - 1];
+                    if (idx < n_split && mk < TL(rk, tid, k)) TL(rb, tid, k) += s;
+                }
+            }
+            UNROLL
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                const uint32_t e = tid + k * TILE_NT;
+                if (e < cnt) TL(rr, tid, k) = FETCH_ADD_U32(&hist[TL(rb, tid, k)], 1u);
+            }
+        }
+    } else {
     PAR(tid) {
         UNROLL
         for (uint32_t k = 0; k < TILE_EPT; ++k) {
@@ -2089,8 +2146,14 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
                 idx_t r;
                 if (bp.B == 1) r = e;                                        // identity: the segment is its own bucket
                 else {
-                    bk = bucket_of(fbp, key);
-                    if (grouped) bk = gtab[bk];
+                    if (MAP == MAP_SPLIT) {                                  // too many splitters for the LDS table: search in HBM
+                        uint32_t a = 0, z = bp.B - 1;
+                        while (a < z) { const uint32_t mid = (a + z) >> 1; if (split[mid] < key) a = mid + 1; else z = mid; }
+                        bk = a;
+                    } else {
+                        bk = bucket_of(fbp, key);
+                        if (grouped) bk = gtab[bk];
+                    }
                     r = lds ? FETCH_ADD_U32(&hist[bk], 1u) : caps_fetch_add(&cursor[b0 + bk], (idx_t)1);
                 }
                 TL(rk, tid, k) = key;
@@ -2099,6 +2162,7 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
                 TL(rr, tid, k) = r;
             }
         }
+    }
     }
     if (!lds) {                                            // one bucket, or too many for the LDS histogram
         PAR(tid) {
@@ -2233,6 +2297,69 @@ GLOBAL_FN LAUNCH_BOUNDS(256) pick_pivots_kernel(KCTX const uint64_t* __restrict_
             pkey[j] = skey[at];
             psa[j] = ssa[at];
         }
+    }
+}
+
+// ---- direct path (pipeline.h, Builder::run_direct): pivots straight from the text ----------------
+// The reference samples its SORTED subarrays (cpp:187-195) because phase 1 has sorted them anyway.  The
+// direct path draws the same number of samples (p * ppp) from the text itself: sample t is one position of
+// the t-th of m equal strata of [0, n) (jittered by a hash of t, so that a periodic text does not alias with
+// the stride).  Strata are disjoint, hence the sampled suffixes are distinct.
+DEV_INLINE uint64_t mix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+// pos0 = first text position of the sampled range (a shard samples its own slice), len = its length, m <= len
+template <typename idx_t, int BITS>
+GLOBAL_FN LAUNCH_BOUNDS(256) sample_text_kernel(KCTX const uint32_t* __restrict__ P, uint64_t pos0, uint64_t len, uint64_t m,
+                                                uint64_t* __restrict__ out_key, idx_t* __restrict__ out_sa)
+{
+    PAR(tid) {
+        const uint64_t t = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (t < m) {
+            const uint64_t q = len / m, r = len % m;                    // floor(t * len / m) = t * q + floor(t * r / m)
+            const uint64_t lo = t * q + (t * r) / m, hi = (t + 1) * q + ((t + 1) * r) / m;
+            const uint64_t pos = pos0 + lo + mix64(t) % (hi - lo);      // hi - lo >= q >= 1
+            out_key[t] = window64<BITS>(P, pos);
+            out_sa[t] = (idx_t)pos;
+        }
+    }
+}
+
+// Groups of PG consecutive partitions: gkey[g] = the pivot key that closes group g (g < K1 - 1), i.e. group g holds
+// the keys in (gkey[g-1], gkey[g]].  flag[0] |= 1 when two consecutive pivot KEYS are equal (some key value is so
+// frequent -- a long repeat, an N-block -- that splitting by key alone cannot balance the groups: the caller then
+// takes the samplesort path, whose exact comparator splits such stretches).
+GLOBAL_FN LAUNCH_BOUNDS(256) group_keys_kernel(KCTX const uint64_t* __restrict__ pkey, uint32_t p, uint32_t PG, uint32_t K1,
+                                               uint64_t* __restrict__ gkey, uint32_t* __restrict__ flag)
+{
+    PAR(tid) {
+        const uint32_t j = K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (j + 2 < p && pkey[j] >= pkey[j + 1]) flag[0] = 1;           // benign race: every writer stores 1
+        if (j + 1 < K1) gkey[j] = pkey[(uint64_t)(j + 1) * PG - 1];
+    }
+}
+
+// The groups as segments in fixed-capacity regions: group g = [g * cap, g * cap + size_g) of the level-A output.
+template <typename idx_t>
+GLOBAL_FN LAUNCH_BOUNDS(256) slot_segments_kernel(KCTX const idx_t* __restrict__ sizes, uint32_t G, uint64_t cap,
+                                                  uint64_t* __restrict__ seg_start, uint64_t* __restrict__ seg_end,
+                                                  uint64_t* __restrict__ total)
+{
+    PAR(tid) {
+        const uint32_t g = K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (g < G) {
+            const uint64_t z = (uint64_t)sizes[g];
+            seg_start[g] = (uint64_t)g * cap;
+            seg_end[g] = (uint64_t)g * cap + (z < cap ? z : cap);      // an overflowed group is reported through out2 / total
+            ATOMIC_ADD_U64(total, z);
+            if (z > cap) ATOMIC_MAX_U64(total + 1, z);
+        }
+        if (g == G) seg_start[g] = (uint64_t)G * cap;
     }
 }
 

@@ -56,6 +56,7 @@ struct Arena {
 
 struct SegBufs {
     uint64_t* seg_start = nullptr;   // [G+1]
+    uint64_t* seg_end = nullptr;     // null: segment g ends at seg_start[g+1]; else [G] ends of segments in fixed-capacity regions
     uint32_t* tile_off = nullptr;    // [G+1]
     TileInfo* tile_rec = nullptr;    // [tile capacity]
     uint64_t* out2 = nullptr;        // [2] = {#tiles, max segment length}
@@ -109,6 +110,8 @@ template <typename idx_t> struct Plan {
     idx_t* PmT = nullptr;            // transposes (phase 2 reads partitions through them)
     idx_t* rulerT = nullptr;
     uint64_t* sizes = nullptr;
+    uint64_t* gkey = nullptr;        // [p]   direct path: the pivot keys that close the groups
+    uint64_t* dstat = nullptr;       // [4]   direct path: {elements scattered, largest overflowed group, flag word, -}
     uint64_t* partial = nullptr;     // [PART_CHUNKS * p] partial column sums of Pm
     SegBufs seg1, seg2, segS;
     TileDesc* desc = nullptr;        // [tile_cap] per-pass tile descriptors
@@ -176,8 +179,11 @@ Plan<idx_t> make_plan(uint64_t n, uint64_t p_arg, char* base)
         pl.PmT = ar.take<idx_t>((size_t)p * (p + 1));
         pl.rulerT = ar.take<idx_t>((size_t)p * p);
         pl.sizes = ar.take<uint64_t>(p);
+        pl.gkey = ar.take<uint64_t>(p);
+        pl.dstat = ar.take<uint64_t>(4);
         pl.partial = ar.take<uint64_t>((size_t)PART_CHUNKS * p);
         segs(pl.seg2, p, pl.tile_cap);
+        pl.seg2.seg_end = ar.take<uint64_t>((size_t)p + 1);
         segs(pl.segS, 1, pl.m / TILE_E + 3);
     }
     pl.desc = ar.take<TileDesc>(pl.tile_cap + 1);
@@ -308,19 +314,21 @@ constexpr uint32_t kSmallScan = 48;        // tiny, so that the CPU logic tests 
 constexpr uint32_t kSmallScan = 32768;
 #endif
 
+// use_end: the segments sit in fixed-capacity regions (s.seg_end holds their ends)
 inline void prepare_segments(Backend& be, const SegBufs& s, uint64_t tile_bound, uint64_t* big_tmp = nullptr,
-                             uint64_t* big_cnt = nullptr)
+                             uint64_t* big_cnt = nullptr, bool use_end = false)
 {
     be.memset(s.out2, 0, 2 * sizeof(uint64_t));
+    const uint64_t* send = use_end ? s.seg_end : nullptr;
     if (s.G <= kSmallScan || !big_tmp) {
-        CAPS_LAUNCH(seg_prepare_kernel, 1, 1024, be, (const uint64_t*)s.seg_start, s.G, s.tile_off, s.out2);
+        CAPS_LAUNCH(seg_prepare_kernel, 1, 1024, be, (const uint64_t*)s.seg_start, send, s.G, s.tile_off, s.out2);
     } else {
-        CAPS_LAUNCH(tile_count_kernel, (s.G + 255) / 256, 256, be, (const uint64_t*)s.seg_start, s.G, big_cnt, s.out2);
+        CAPS_LAUNCH(tile_count_kernel, (s.G + 255) / 256, 256, be, (const uint64_t*)s.seg_start, send, s.G, big_cnt, s.out2);
         device_exclusive_scan<uint32_t>(be, big_cnt, s.G, s.tile_off, big_tmp);
         CAPS_LAUNCH(tile_total_kernel, 1, 64, be, (const uint32_t*)s.tile_off, s.G, s.out2);
     }
     const uint32_t grid = (uint32_t)((tile_bound + 255) / 256);
-    CAPS_LAUNCH(tile_map_kernel, grid ? grid : 1, 256, be, (const uint64_t*)s.seg_start, (const uint32_t*)s.tile_off, s.G, s.tile_rec);
+    CAPS_LAUNCH(tile_map_kernel, grid ? grid : 1, 256, be, (const uint64_t*)s.seg_start, send, (const uint32_t*)s.tile_off, s.G, s.tile_rec);
 }
 
 inline uint32_t tiles_of(uint64_t len) { return (uint32_t)((len + TILE_E - 1) / TILE_E); }
@@ -357,6 +365,9 @@ struct SortOpts {
     uint32_t part_off = 0, part_total = 0;    // range_mode 1: segment g = partition part_off + g of part_total
     bool speculate = false;       // try the bucket split without its count pass first (slots carved from `oth`)
     uint32_t* slot_stats = nullptr;   // [2] host counters: splits done with slots / redone with the count pass
+    bool seg_ends = false;        // the segments sit in fixed-capacity regions: their ends are s.seg_end (direct path, level B)
+    const uint64_t* in_key = nullptr;   // non-null: the elements are read from these arrays (indexed like the segments)
+    const void* in_sa = nullptr;        //   instead of `cur`, which then only receives results
     const void* runs = nullptr;   // RunSrc<idx_t>*: the segments are partitions still spread over the sorted subarrays in
                                   //   `cur` (requires the bucket split: bk != null and max_len > TILE_E)
     bool unify = false;           // gather the result into buf[0] (consumers that index whole segments)
@@ -401,7 +412,8 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
     if (o.bk && max_len > TILE_E) {
         const BucketBufs& bk = *o.bk;
         const SegDesc psd = s.desc();
-        CAPS_LAUNCH(bucket_plan_kernel, (s.G + 255) / 256, 256, be, (const uint64_t*)s.seg_start, s.G, o.range_mode, o.pkey, o.part_off,
+        const uint64_t* s_end = o.seg_ends ? (const uint64_t*)s.seg_end : (const uint64_t*)nullptr;
+        CAPS_LAUNCH(bucket_plan_kernel, (s.G + 255) / 256, 256, be, (const uint64_t*)s.seg_start, s_end, s.G, o.range_mode, o.pkey, o.part_off,
                     o.part_total ? o.part_total : s.G, 1u, 1u,
                     bk.params, bk.segB);
         CAPS_LAUNCH(scan_sizes_kernel, 1, 1024, be, (const uint64_t*)bk.segB, s.G, bk.bstart);
@@ -415,21 +427,24 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         const RunSrc<idx_t> rsrc = runs ? *static_cast<const RunSrc<idx_t>*>(o.runs) : RunSrc<idx_t>();
         const uint64_t n_words = from_text ? packed_words(n, BITS) : 0;
         const uint64_t tbase = from_text ? o.text_base : 0;
+        // where the elements are read from (SRC_ARRAYS / SRC_RUNS): `cur`, unless the caller keeps them elsewhere
+        const uint64_t* src_key = o.in_key ? o.in_key : (const uint64_t*)cur.key;
+        const idx_t* src_sa = o.in_key ? static_cast<const idx_t*>(o.in_sa) : (const idx_t*)cur.sa;
         auto scatter = [&](const uint64_t* sub_start, uint32_t cap, uint64_t* okey, idx_t* osa, bool grouped = false) {
             const BucketParams* fbps = grouped ? bk.fparams : nullptr;
             const uint32_t* gfirst = grouped ? bk.gfirst : nullptr;
             BackendEvent s0 = be.record();
-#define CAPS_SCATTER_LAUNCH(SRC_, GRP_, ikey, isa)                                                                          \
-            CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, SRC_, GRP_>), n_tiles, TILE_NT, be, psd, P, n_words, tbase, ikey, isa, rsrc, \
-                        (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, sub_start, cap, static_cast<idx_t*>(bk.cursor),       \
-                        okey, osa, fbps, gfirst)
+#define CAPS_SCATTER_LAUNCH(SRC_, MAP_, ikey, isa)                                                                          \
+            CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, SRC_, MAP_>), n_tiles, TILE_NT, be, psd, P, n_words, tbase, ikey, isa, rsrc, \
+                        (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, sub_start, (uint64_t)cap, static_cast<idx_t*>(bk.cursor),       \
+                        okey, osa, fbps, gfirst, (const uint64_t*)nullptr)
             const uint64_t* nokey = nullptr;
             const idx_t* nosa = nullptr;
-            if (from_text) { if (grouped) CAPS_SCATTER_LAUNCH(SRC_TEXT, true, nokey, nosa); else CAPS_SCATTER_LAUNCH(SRC_TEXT, false, nokey, nosa); }
-            else if (runs) { if (grouped) CAPS_SCATTER_LAUNCH(SRC_RUNS, true, (const uint64_t*)cur.key, (const idx_t*)cur.sa);
-                             else CAPS_SCATTER_LAUNCH(SRC_RUNS, false, (const uint64_t*)cur.key, (const idx_t*)cur.sa); }
-            else { if (grouped) CAPS_SCATTER_LAUNCH(SRC_ARRAYS, true, (const uint64_t*)cur.key, (const idx_t*)cur.sa);
-                   else CAPS_SCATTER_LAUNCH(SRC_ARRAYS, false, (const uint64_t*)cur.key, (const idx_t*)cur.sa); }
+            if (from_text) { if (grouped) CAPS_SCATTER_LAUNCH(SRC_TEXT, MAP_GROUPED, nokey, nosa); else CAPS_SCATTER_LAUNCH(SRC_TEXT, MAP_LINEAR, nokey, nosa); }
+            else if (runs) { if (grouped) CAPS_SCATTER_LAUNCH(SRC_RUNS, MAP_GROUPED, src_key, src_sa);
+                             else CAPS_SCATTER_LAUNCH(SRC_RUNS, MAP_LINEAR, src_key, src_sa); }
+            else { if (grouped) CAPS_SCATTER_LAUNCH(SRC_ARRAYS, MAP_GROUPED, src_key, src_sa);
+                   else CAPS_SCATTER_LAUNCH(SRC_ARRAYS, MAP_LINEAR, src_key, src_sa); }
 #undef CAPS_SCATTER_LAUNCH
             BackendEvent s1 = be.record();
             if (o.scatter_clock) { o.scatter_clock->spans.push_back({s0, s1}); o.scatter_clock->elems.push_back(n_elems); }
@@ -475,7 +490,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
             const uint64_t* cstart = bk.bstart;
             uint64_t* ccount = bk.count;
             if (equalise) {
-                CAPS_LAUNCH(bucket_plan_kernel, (s.G + 255) / 256, 256, be, (const uint64_t*)s.seg_start, s.G, o.range_mode, o.pkey, o.part_off,
+                CAPS_LAUNCH(bucket_plan_kernel, (s.G + 255) / 256, 256, be, (const uint64_t*)s.seg_start, s_end, s.G, o.range_mode, o.pkey, o.part_off,
                             o.part_total ? o.part_total : s.G, 1u, EQ_FINE, bk.fparams, bk.fsegB);
                 CAPS_LAUNCH(scan_sizes_kernel, 1, 1024, be, (const uint64_t*)bk.fsegB, s.G, bk.fstart);
                 be.memset(bk.fcount, 0, (size_t)EQ_FINE * bk.nb_cap * sizeof(uint64_t));
@@ -490,10 +505,10 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
                 CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, SRC_TEXT>), pgrid, TILE_NT, be, psd, P, n_words, tbase, (const uint64_t*)nullptr, rsrc,
                             cparams, cstart, ccount);
             else if (runs)
-                CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, SRC_RUNS>), pgrid, TILE_NT, be, psd, P, n_words, tbase, (const uint64_t*)cur.key, rsrc,
+                CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, SRC_RUNS>), pgrid, TILE_NT, be, psd, P, n_words, tbase, src_key, rsrc,
                             cparams, cstart, ccount);
             else
-                CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, SRC_ARRAYS>), pgrid, TILE_NT, be, psd, P, n_words, tbase, (const uint64_t*)cur.key, rsrc,
+                CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, SRC_ARRAYS>), pgrid, TILE_NT, be, psd, P, n_words, tbase, src_key, rsrc,
                             cparams, cstart, ccount);
             if (equalise) {
                 CAPS_LAUNCH(bucket_group_kernel, s.G < 16384 ? (s.G ? s.G : 1) : 16384, 256, be, s.G, (const uint64_t*)bk.segB, (const uint64_t*)bk.bstart,
@@ -549,8 +564,10 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
     const bool eq_tiles = !std::getenv("CAPS_SA_NO_EQ_TILES");        // measurement: skip tile_sort_eq_kernel
     if (!eq_tiles) redo2 = redo;
     BackendEvent t0 = be.record();
-    const uint64_t* in_key = slot_cap ? slot_key : cur.key;
-    const idx_t* in_sa = slot_cap ? slot_sa : cur.sa;
+    if (o.seg_ends && segs.seg_start == s.seg_start)
+        throw std::invalid_argument("segments in fixed-capacity regions must be bucketed (results are written compactly)");
+    const uint64_t* in_key = slot_cap ? slot_key : (o.in_key && segs.seg_start == s.seg_start) ? o.in_key : cur.key;
+    const idx_t* in_sa = slot_cap ? slot_sa : (o.in_key && segs.seg_start == s.seg_start) ? static_cast<const idx_t*>(o.in_sa) : cur.sa;
     if (from_text) {
         CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, sd, P, n, o.text_base, lcp_mode, 0u,
                     (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, seg_map, redo);
@@ -639,6 +656,12 @@ private:
     KernelClock collate_clock_;
     uint32_t pass_base_ = 0;
     uint32_t slot_stats_[2] = {0, 0};
+    // per-build results of the phase sequences below
+    uint32_t passes1_ = 0, passes2_ = 0, passesS_ = 0;
+    BackendEvent e2_, e3_, e4_, e5_, e6_, e7_;
+    uint64_t max_part_ = 0;
+    uint32_t path_direct_ = 0, path_fallback_ = 0, direct_groups_ = 0;
+    uint64_t direct_max_group_ = 0;
 
     // timed: the full-size sorts (phase 1, phase 2) feed the kernel clocks of caps_sa_stats;
     // their passes count the elements they really move in pl_.pass_elems[pass_base_ ...]
@@ -673,14 +696,248 @@ private:
         o.bnd.last_sa = pl_.bk.last_sa;
     }
 
+    // ---- the samplesort path: the reference's six phases (src/Suffix_Array.cpp:466-494) ----
+    template <int BITS>
+    void run_classic(idx_t* dSA, idx_t* dLCP)
+    {
+        const uint64_t n = pl_.n;
+        const uint32_t p = pl_.p;
+        const uint64_t s = n / p, last = s + n % p;
+        // ---- phase 1 (a5): sort the p subarrays of contiguous text positions (no LCPs needed:
+        //      the collate step moves only keys and indices)
+        CAPS_LAUNCH(uniform_segments_kernel, (p + 256) / 256, 256, be_, pl_.seg1.seg_start, p, s, n);
+        const uint32_t n_tiles1 = (p - 1) * tiles_of(s) + tiles_of(last);
+        prepare_segments(pl_.seg1, n_tiles1);
+        SortOpts o1;
+        o1.from_text = true;
+        o1.bk = &pl_.bk;                    // keys of a subarray span the whole key range
+        o1.unify = true;                    // sample / locate / collate index subarrays as arrays
+        SortResult<idx_t> r1 = seg_sort<BITS>(pl_.seg1, n_tiles1, last, pl_.A, pl_.B, n, o1, true);
+        passes1_ = r1.passes;
+        ElemBuf<idx_t> cur = r1.uniform();
+        ElemBuf<idx_t> oth = cur.key == pl_.A.key ? pl_.B : pl_.A;
+        e2_ = be_.record();
+
+        // ---- pivots (a6)
+        const uint64_t m = pl_.m;
+        CAPS_LAUNCH((sample_kernel<idx_t>), (uint32_t)((m + 255) / 256), 256, be_, (const uint64_t*)pl_.seg1.seg_start, p,
+                    pl_.ppp, (const uint64_t*)cur.key, (const idx_t*)cur.sa, pl_.SA_.key, pl_.SA_.sa);
+        CAPS_LAUNCH(uniform_segments_kernel, 1, 256, be_, pl_.segS.seg_start, 1u, m, m);
+        prepare_segments(pl_.segS, tiles_of(m));
+        SortOpts os;
+        os.bk = &pl_.bk;                    // phase 1's bucket tables are free again: the samples are bucket-sorted too
+        os.unify = true;                    //   (one split + tile sort instead of ~11 merge passes over 5.6 M samples)
+        SortResult<idx_t> rs = seg_sort<BITS>(pl_.segS, tiles_of(m), m, pl_.SA_, pl_.SB_, m, os, false);
+        passesS_ = rs.passes;
+        ElemBuf<idx_t> smp = rs.uniform();
+        CAPS_LAUNCH((pick_pivots_kernel<idx_t>), (p + 255) / 256, 256, be_, (const uint64_t*)smp.key, (const idx_t*)smp.sa,
+                    m, p, pl_.pkey, pl_.psa);
+        e3_ = be_.record();
+
+        // ---- locate (a7/a8)
+        const uint32_t np = p - 1;
+        const uint32_t bpr = (np + 255) / 256;
+        if (n / p < 8ull * np)          // short subarrays: galloping searches (locate_kernel)
+            CAPS_LAUNCH((locate_kernel<idx_t, BITS, true>), capped_grid((uint64_t)p * bpr, 256), 256, be_, (const uint32_t*)pl_.P, n,
+                        (const uint64_t*)pl_.seg1.seg_start, p, (const uint64_t*)cur.key, (const idx_t*)cur.sa,
+                        (const uint64_t*)pl_.pkey, (const idx_t*)pl_.psa, np, pl_.Pm);
+        else
+            CAPS_LAUNCH((locate_kernel<idx_t, BITS, false>), capped_grid((uint64_t)p * bpr, 256), 256, be_, (const uint32_t*)pl_.P, n,
+                        (const uint64_t*)pl_.seg1.seg_start, p, (const uint64_t*)cur.key, (const idx_t*)cur.sa,
+                        (const uint64_t*)pl_.pkey, (const idx_t*)pl_.psa, np, pl_.Pm);
+        e4_ = be_.record();
+
+        // ---- partition sizes, offsets, collate (a9)
+        CAPS_LAUNCH((partition_partial_kernel<idx_t>), ((p + 255) / 256) * PART_CHUNKS, 256, be_, (const idx_t*)pl_.Pm, p, p, pl_.partial);
+        CAPS_LAUNCH((partition_sizes_kernel<idx_t>), ((p + 255) / 256) * PART_CHUNKS, 256, be_, (const idx_t*)pl_.Pm, p, p,
+                    (const uint64_t*)pl_.partial, pl_.ruler, pl_.sizes);
+        CAPS_LAUNCH(scan_sizes_kernel, 1, 1024, be_, (const uint64_t*)pl_.sizes, p, pl_.seg2.seg_start);
+        prepare_segments(pl_.seg2, n / TILE_E + p + 1);
+        uint64_t out2[2];
+        be_.d2h(out2, pl_.seg2.out2, sizeof out2);
+        be_.sync();                                   // out2 = {#tiles, largest partition}
+        const uint32_t n_tiles2 = (uint32_t)out2[0];
+        max_part_ = out2[1];
+        // A partition longer than a tile is bucketed by key range before its tile sort; that
+        // bucket split can read the partition straight from the sorted subarrays (through the
+        // transposed partition matrix): no separate collate pass.  Otherwise (tiny inputs):
+        // collate as the reference does (cpp:343-358), then tile-sort the partitions.
+        const bool fused = max_part_ > TILE_E;
+        uint32_t* tile_plan = reinterpret_cast<uint32_t*>(pl_.desc);      // the tile descriptors are idle here
+        RunSrc<idx_t> rsrc;
+        ElemBuf<idx_t> in2 = cur, out2buf = oth;
+        if (fused) {
+            CAPS_LAUNCH((transpose_kernel<idx_t>), capped_grid((uint64_t)((p + 31) / 32) * ((p + 1 + 31) / 32), 256), 256, be_, (const idx_t*)pl_.Pm, p, p + 1,
+                        pl_.PmT);
+            CAPS_LAUNCH((transpose_kernel<idx_t>), capped_grid((uint64_t)((p + 31) / 32) * ((p + 31) / 32), 256), 256, be_, (const idx_t*)pl_.ruler, p, p,
+                        pl_.rulerT);
+            CAPS_LAUNCH((runs_plan_kernel<idx_t>), (n_tiles2 + 255) / 256, 256, be_, pl_.seg2.desc(), (const idx_t*)pl_.rulerT, p,
+                        tile_plan);
+            rsrc.PmT = pl_.PmT;
+            rsrc.rulerT = pl_.rulerT;
+            rsrc.sub_start = pl_.seg1.seg_start;
+            rsrc.first_run = tile_plan;
+            rsrc.G1 = p;
+        } else {
+            BackendEvent k0 = be_.record();
+            CAPS_LAUNCH((collate_plan_kernel<idx_t>), (n_tiles1 + 255) / 256, 256, be_, pl_.seg1.desc(), p, (const idx_t*)pl_.Pm,
+                        tile_plan);
+            CAPS_LAUNCH((collate_kernel<idx_t>), n_tiles1, TILE_NT, be_, pl_.seg1.desc(), p, (const idx_t*)pl_.Pm,
+                        (const idx_t*)pl_.ruler, (const uint64_t*)pl_.seg2.seg_start, (const uint32_t*)tile_plan,
+                        (const uint64_t*)cur.key, (const idx_t*)cur.sa, oth.key, oth.sa);
+            BackendEvent k1 = be_.record();
+            collate_clock_.spans.push_back({k0, k1});
+            collate_clock_.elems.push_back(n);
+            in2 = oth;
+            out2buf = cur;
+        }
+        e5_ = be_.record();
+
+        // ---- phase 2 (a10): sort every partition; a partition's last step emits its LCPs
+        SortOpts o2;
+        o2.need_lcp = true;
+        o2.skip_finished = true;
+        o2.bk = &pl_.bk;                    // partition j holds keys in [pivot j-1, pivot j]
+        o2.range_mode = 1;
+        o2.pkey = pl_.pkey;
+        if (fused) o2.runs = &rsrc;
+        set_final(o2, dSA, dLCP);
+        SortResult<idx_t> r2 = seg_sort<BITS>(pl_.seg2, n_tiles2, max_part_, in2, out2buf, n, o2, true);
+        passes2_ = r2.passes;
+        e6_ = be_.record();
+
+        // ---- gather SA/LCP + partition-boundary LCPs (a11)
+        finalize<idx_t, BITS>(be_, pl_.P, n, r2, dSA, dLCP);
+        e7_ = be_.record();
+    }
+
+    // Shape of the direct path's two-level distribution: PG consecutive partitions per group, K1 groups.  Level A
+    // (text -> groups) and level B (group -> buckets of one tile) should fan out about equally (the runs a tile
+    // contributes to a destination are then equally long at both levels), a group must fit the LDS histogram of its
+    // bucket split with room for imbalance, and the group table must fit LDS.
+    static int direct_shape(uint64_t n, uint32_t p, uint64_t m, uint32_t* PG, uint32_t* K1)
+    {
+        *PG = *K1 = 0;
+        if (p < 2 || n < 32ull * TILE_E || m < 64 || m > (1ull << 31)) return CAPS_SA_FB_SHAPE;
+        const double group_max = 0.55 * (double)BUCKET_LDS * (double)BUCKET_TARGET;
+        double want = std::sqrt((double)n / (double)BUCKET_TARGET);
+        if ((double)n / group_max > want) want = (double)n / group_max;
+        if (want < 2.0) want = 2.0;
+        if (want > (double)BUCKET_LDS) return CAPS_SA_FB_SHAPE;
+        uint32_t pg = (uint32_t)((double)p / want);
+        if (pg < 1) pg = 1;
+        const uint32_t k1 = (p + pg - 1) / pg;
+        if (k1 < 2 || k1 > BUCKET_LDS || (double)n / k1 > group_max || m / k1 < 16) return CAPS_SA_FB_SHAPE;
+        *PG = pg;
+        *K1 = k1;
+        return CAPS_SA_FB_NONE;
+    }
+
+    // ---- the direct path ------------------------------------------------------------------------------------
+    // Phase 1 of the samplesort (sort_subarrays) and locate_pivots only serve to find out which partition every
+    // suffix belongs to; the order they establish inside the subarrays is discarded when the partitions are sorted.
+    // With 64-bit keys the partition of a suffix can be read off its key: the pivots are sampled from the text
+    // itself, and ONE scatter distributes the text into groups of PG consecutive partitions (level A: splitter table
+    // in LDS, fixed-capacity region per group, no count pass).  Level B is the per-partition sort of the samplesort
+    // path, run on the groups: bucket split by key range between the group's pivots -> tile sort -> SA, LCP.
+    // Returns false (nothing of the result written) when the keys cannot balance the groups: two pivots with one key
+    // or an overflowing group -- long repeats; the samplesort path then does the build.
+    template <int BITS>
+    bool run_direct(idx_t* dSA, idx_t* dLCP, uint32_t PG, uint32_t K1)
+    {
+        const uint64_t n = pl_.n, m = pl_.m;
+        const uint32_t p = pl_.p;
+        // ---- pivots (a6) from samples of the text
+        CAPS_LAUNCH((sample_text_kernel<idx_t, BITS>), (uint32_t)((m + 255) / 256), 256, be_, (const uint32_t*)pl_.P, (uint64_t)0, n, m,
+                    pl_.SA_.key, pl_.SA_.sa);
+        CAPS_LAUNCH(uniform_segments_kernel, 1, 256, be_, pl_.segS.seg_start, 1u, m, m);
+        prepare_segments(pl_.segS, tiles_of(m));
+        SortOpts os;
+        os.bk = &pl_.bk;
+        os.unify = true;
+        SortResult<idx_t> rs = seg_sort<BITS>(pl_.segS, tiles_of(m), m, pl_.SA_, pl_.SB_, m, os, false);
+        passesS_ = rs.passes;
+        ElemBuf<idx_t> smp = rs.uniform();
+        CAPS_LAUNCH((pick_pivots_kernel<idx_t>), (p + 255) / 256, 256, be_, (const uint64_t*)smp.key, (const idx_t*)smp.sa,
+                    m, p, pl_.pkey, pl_.psa);
+        be_.memset(pl_.dstat, 0, 4 * sizeof(uint64_t));
+        uint32_t* dflag = reinterpret_cast<uint32_t*>(pl_.dstat + 2);
+        CAPS_LAUNCH(group_keys_kernel, (p + 255) / 256, 256, be_, (const uint64_t*)pl_.pkey, p, PG, K1, pl_.gkey, dflag);
+        e3_ = be_.record();
+
+        // ---- level A (a9 without a8): the text -> K1 groups, each in its own region of buffer A
+        const ElemBuf<idx_t>& A = pl_.A;
+        uint64_t capA = A.region_bytes / ((sizeof(uint64_t) + sizeof(idx_t)) * (uint64_t)K1);
+        const uint64_t idx_max = (uint64_t)std::numeric_limits<idx_t>::max() - TILE_E;
+        if (capA > idx_max / K1) capA = idx_max / K1;                   // region offsets are idx_t in the scatter
+        uint64_t* a_key = A.key;
+        idx_t* a_sa = reinterpret_cast<idx_t*>(reinterpret_cast<char*>(A.key) + (uint64_t)K1 * capA * sizeof(uint64_t));
+        CAPS_LAUNCH(uniform_segments_kernel, 1, 256, be_, pl_.seg1.seg_start, 1u, n, n);
+        SegBufs whole = pl_.seg1;
+        whole.G = 1;
+        const uint32_t n_tilesA = tiles_of(n);
+        prepare_segments(whole, n_tilesA);
+        BucketParams one = make_bucket_params(0, ~0ull, K1);            // only B is used by MAP_SPLIT
+        const uint64_t b01[2] = {0, K1};
+        be_.h2d(pl_.bk.params, &one, sizeof one);
+        be_.h2d(pl_.bk.bstart, b01, sizeof b01);
+        be_.memset(pl_.bk.cursor, 0, (size_t)K1 * sizeof(idx_t));
+        {
+            BackendEvent s0 = be_.record();
+            CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, SRC_TEXT, MAP_SPLIT>), n_tilesA, TILE_NT, be_, whole.desc(), (const uint32_t*)pl_.P,
+                        packed_words(n, BITS), (uint64_t)0, (const uint64_t*)nullptr, (const idx_t*)nullptr, RunSrc<idx_t>(),
+                        (const BucketParams*)pl_.bk.params, (const uint64_t*)pl_.bk.bstart, (const uint64_t*)nullptr, capA,
+                        static_cast<idx_t*>(pl_.bk.cursor), a_key, a_sa, (const BucketParams*)nullptr, (const uint32_t*)nullptr,
+                        (const uint64_t*)pl_.gkey);
+            BackendEvent s1 = be_.record();
+            scatter_clock_.spans.push_back({s0, s1});
+            scatter_clock_.elems.push_back(n);
+        }
+        SegBufs groups = pl_.seg2;
+        groups.G = K1;
+        CAPS_LAUNCH((slot_segments_kernel<idx_t>), (K1 + 256) / 256, 256, be_, (const idx_t*)static_cast<idx_t*>(pl_.bk.cursor), K1, capA,
+                    groups.seg_start, groups.seg_end, pl_.dstat);
+        ::caps::prepare_segments(be_, groups, n / TILE_E + K1 + 1, nullptr, nullptr, true);
+        uint64_t out2[2], dstat[4];
+        be_.d2h(out2, groups.out2, sizeof out2);
+        be_.d2h(dstat, pl_.dstat, sizeof dstat);
+        be_.sync();                                   // out2 = {#tiles, largest group (clamped to its region)}
+        direct_groups_ = K1;
+        direct_max_group_ = dstat[1] ? dstat[1] : out2[1];
+        if ((uint32_t)dstat[2] != 0) { path_fallback_ = CAPS_SA_FB_PIVOT_TIES; return false; }
+        if (dstat[1] != 0 || dstat[0] != n) { path_fallback_ = CAPS_SA_FB_GROUP_OVERFLOW; return false; }
+        if (out2[1] <= TILE_E) { path_fallback_ = CAPS_SA_FB_SHAPE; return false; }
+        const uint32_t n_tiles2 = (uint32_t)out2[0];
+        max_part_ = out2[1];
+        e2_ = e3_;                                    // no sort_subarrays, no locate_pivots
+        e4_ = e3_;
+        e5_ = be_.record();
+
+        // ---- level B (a10): every group -> buckets between its pivots -> tile sort -> SA, LCP
+        SortOpts o2;
+        o2.need_lcp = true;
+        o2.skip_finished = true;
+        o2.bk = &pl_.bk;
+        o2.range_mode = 1;                            // group g holds the keys in (gkey[g-1], gkey[g]]
+        o2.pkey = pl_.gkey;
+        o2.part_total = K1;
+        o2.seg_ends = true;
+        o2.in_key = a_key;
+        o2.in_sa = a_sa;
+        set_final(o2, dSA, dLCP);
+        SortResult<idx_t> r2 = seg_sort<BITS>(groups, n_tiles2, max_part_, pl_.A, pl_.B, n, o2, true);
+        passes2_ = r2.passes;
+        e6_ = be_.record();
+        finalize<idx_t, BITS>(be_, pl_.P, n, r2, dSA, dLCP);
+        e7_ = be_.record();
+        return true;
+    }
+
     template <int BITS>
     void run(idx_t* dSA, idx_t* dLCP, caps_sa_stats* st, BackendEvent e0, BackendEvent e1)
     {
         const uint64_t n = pl_.n;
         const uint32_t p = pl_.p;
-        uint32_t passes1 = 0, passes2 = 0, passesS = 0;
-        BackendEvent e2, e3, e4, e5, e6, e7;
-        uint64_t max_part = 0;
         be_.memset(pl_.pass_elems, 0, kMaxPasses * sizeof(uint64_t));
 
         if (p < 2) {
@@ -694,118 +951,23 @@ private:
             o.bk = &pl_.bk;                     // one segment: bucket it by key range too
             set_final(o, dSA, dLCP);
             SortResult<idx_t> r = seg_sort<BITS>(pl_.seg1, tiles_of(n), n, pl_.A, pl_.B, n, o, true);
-            passes1 = r.passes;
-            e2 = e3 = e4 = e5 = e6 = be_.record();
+            passes1_ = r.passes;
+            e2_ = e3_ = e4_ = e5_ = e6_ = be_.record();
             finalize<idx_t, BITS>(be_, pl_.P, n, r, dSA, dLCP);
-            e7 = be_.record();
+            e7_ = be_.record();
         } else {
-            const uint64_t s = n / p, last = s + n % p;
-            // ---- phase 1 (a5): sort the p subarrays of contiguous text positions (no LCPs needed:
-            //      the collate step moves only keys and indices)
-            CAPS_LAUNCH(uniform_segments_kernel, (p + 256) / 256, 256, be_, pl_.seg1.seg_start, p, s, n);
-            const uint32_t n_tiles1 = (p - 1) * tiles_of(s) + tiles_of(last);
-            prepare_segments(pl_.seg1, n_tiles1);
-            SortOpts o1;
-            o1.from_text = true;
-            o1.bk = &pl_.bk;                    // keys of a subarray span the whole key range
-            o1.unify = true;                    // sample / locate / collate index subarrays as arrays
-            SortResult<idx_t> r1 = seg_sort<BITS>(pl_.seg1, n_tiles1, last, pl_.A, pl_.B, n, o1, true);
-            passes1 = r1.passes;
-            ElemBuf<idx_t> cur = r1.uniform();
-            ElemBuf<idx_t> oth = cur.key == pl_.A.key ? pl_.B : pl_.A;
-            e2 = be_.record();
-
-            // ---- pivots (a6)
-            const uint64_t m = pl_.m;
-            CAPS_LAUNCH((sample_kernel<idx_t>), (uint32_t)((m + 255) / 256), 256, be_, (const uint64_t*)pl_.seg1.seg_start, p,
-                        pl_.ppp, (const uint64_t*)cur.key, (const idx_t*)cur.sa, pl_.SA_.key, pl_.SA_.sa);
-            CAPS_LAUNCH(uniform_segments_kernel, 1, 256, be_, pl_.segS.seg_start, 1u, m, m);
-            prepare_segments(pl_.segS, tiles_of(m));
-            SortOpts os;
-            os.bk = &pl_.bk;                    // phase 1's bucket tables are free again: the samples are bucket-sorted too
-            os.unify = true;                    //   (one split + tile sort instead of ~11 merge passes over 5.6 M samples)
-            SortResult<idx_t> rs = seg_sort<BITS>(pl_.segS, tiles_of(m), m, pl_.SA_, pl_.SB_, m, os, false);
-            passesS = rs.passes;
-            ElemBuf<idx_t> smp = rs.uniform();
-            CAPS_LAUNCH((pick_pivots_kernel<idx_t>), (p + 255) / 256, 256, be_, (const uint64_t*)smp.key, (const idx_t*)smp.sa,
-                        m, p, pl_.pkey, pl_.psa);
-            e3 = be_.record();
-
-            // ---- locate (a7/a8)
-            const uint32_t np = p - 1;
-            const uint32_t bpr = (np + 255) / 256;
-            if (n / p < 8ull * np)          // short subarrays: galloping searches (locate_kernel)
-                CAPS_LAUNCH((locate_kernel<idx_t, BITS, true>), capped_grid((uint64_t)p * bpr, 256), 256, be_, (const uint32_t*)pl_.P, n,
-                            (const uint64_t*)pl_.seg1.seg_start, p, (const uint64_t*)cur.key, (const idx_t*)cur.sa,
-                            (const uint64_t*)pl_.pkey, (const idx_t*)pl_.psa, np, pl_.Pm);
-            else
-                CAPS_LAUNCH((locate_kernel<idx_t, BITS, false>), capped_grid((uint64_t)p * bpr, 256), 256, be_, (const uint32_t*)pl_.P, n,
-                            (const uint64_t*)pl_.seg1.seg_start, p, (const uint64_t*)cur.key, (const idx_t*)cur.sa,
-                            (const uint64_t*)pl_.pkey, (const idx_t*)pl_.psa, np, pl_.Pm);
-            e4 = be_.record();
-
-            // ---- partition sizes, offsets, collate (a9)
-            CAPS_LAUNCH((partition_partial_kernel<idx_t>), ((p + 255) / 256) * PART_CHUNKS, 256, be_, (const idx_t*)pl_.Pm, p, p, pl_.partial);
-            CAPS_LAUNCH((partition_sizes_kernel<idx_t>), ((p + 255) / 256) * PART_CHUNKS, 256, be_, (const idx_t*)pl_.Pm, p, p,
-                        (const uint64_t*)pl_.partial, pl_.ruler, pl_.sizes);
-            CAPS_LAUNCH(scan_sizes_kernel, 1, 1024, be_, (const uint64_t*)pl_.sizes, p, pl_.seg2.seg_start);
-            prepare_segments(pl_.seg2, n / TILE_E + p + 1);
-            uint64_t out2[2];
-            be_.d2h(out2, pl_.seg2.out2, sizeof out2);
-            be_.sync();                                   // out2 = {#tiles, largest partition}
-            const uint32_t n_tiles2 = (uint32_t)out2[0];
-            max_part = out2[1];
-            // A partition longer than a tile is bucketed by key range before its tile sort; that
-            // bucket split can read the partition straight from the sorted subarrays (through the
-            // transposed partition matrix): no separate collate pass.  Otherwise (tiny inputs):
-            // collate as the reference does (cpp:343-358), then tile-sort the partitions.
-            const bool fused = max_part > TILE_E;
-            uint32_t* tile_plan = reinterpret_cast<uint32_t*>(pl_.desc);      // the tile descriptors are idle here
-            RunSrc<idx_t> rsrc;
-            ElemBuf<idx_t> in2 = cur, out2buf = oth;
-            if (fused) {
-                CAPS_LAUNCH((transpose_kernel<idx_t>), capped_grid((uint64_t)((p + 31) / 32) * ((p + 1 + 31) / 32), 256), 256, be_, (const idx_t*)pl_.Pm, p, p + 1,
-                            pl_.PmT);
-                CAPS_LAUNCH((transpose_kernel<idx_t>), capped_grid((uint64_t)((p + 31) / 32) * ((p + 31) / 32), 256), 256, be_, (const idx_t*)pl_.ruler, p, p,
-                            pl_.rulerT);
-                CAPS_LAUNCH((runs_plan_kernel<idx_t>), (n_tiles2 + 255) / 256, 256, be_, pl_.seg2.desc(), (const idx_t*)pl_.rulerT, p,
-                            tile_plan);
-                rsrc.PmT = pl_.PmT;
-                rsrc.rulerT = pl_.rulerT;
-                rsrc.sub_start = pl_.seg1.seg_start;
-                rsrc.first_run = tile_plan;
-                rsrc.G1 = p;
-            } else {
-                BackendEvent k0 = be_.record();
-                CAPS_LAUNCH((collate_plan_kernel<idx_t>), (n_tiles1 + 255) / 256, 256, be_, pl_.seg1.desc(), p, (const idx_t*)pl_.Pm,
-                            tile_plan);
-                CAPS_LAUNCH((collate_kernel<idx_t>), n_tiles1, TILE_NT, be_, pl_.seg1.desc(), p, (const idx_t*)pl_.Pm,
-                            (const idx_t*)pl_.ruler, (const uint64_t*)pl_.seg2.seg_start, (const uint32_t*)tile_plan,
-                            (const uint64_t*)cur.key, (const idx_t*)cur.sa, oth.key, oth.sa);
-                BackendEvent k1 = be_.record();
-                collate_clock_.spans.push_back({k0, k1});
-                collate_clock_.elems.push_back(n);
-                in2 = oth;
-                out2buf = cur;
+            // direct path unless the text (long periodic stretches: keys alone cannot split them), the shape
+            // (tiny inputs) or CAPS_SA_PATH=classic says otherwise
+            uint32_t PG = 0, K1 = 0;
+            const char* force = std::getenv("CAPS_SA_PATH");
+            if (force && std::string(force) == "classic") path_fallback_ = CAPS_SA_FB_FORCED;
+            else if (be_.long_runs) path_fallback_ = CAPS_SA_FB_LONG_RUNS;
+            else path_fallback_ = (uint32_t)direct_shape(n, p, pl_.m, &PG, &K1);
+            if (path_fallback_ == CAPS_SA_FB_NONE && run_direct<BITS>(dSA, dLCP, PG, K1)) path_direct_ = 1;
+            else {
+                // a direct attempt that gave up has written nothing of the result; its kernel-clock entries stay (it cost them)
+                run_classic<BITS>(dSA, dLCP);
             }
-            e5 = be_.record();
-
-            // ---- phase 2 (a10): sort every partition; a partition's last step emits its LCPs
-            SortOpts o2;
-            o2.need_lcp = true;
-            o2.skip_finished = true;
-            o2.bk = &pl_.bk;                    // partition j holds keys in [pivot j-1, pivot j]
-            o2.range_mode = 1;
-            o2.pkey = pl_.pkey;
-            if (fused) o2.runs = &rsrc;
-            set_final(o2, dSA, dLCP);
-            SortResult<idx_t> r2 = seg_sort<BITS>(pl_.seg2, n_tiles2, max_part, in2, out2buf, n, o2, true);
-            passes2 = r2.passes;
-            e6 = be_.record();
-
-            // ---- gather SA/LCP + partition-boundary LCPs (a11)
-            finalize<idx_t, BITS>(be_, pl_.P, n, r2, dSA, dLCP);
-            e7 = be_.record();
         }
         uint64_t pass_elems[kMaxPasses];
         be_.d2h(pass_elems, pl_.pass_elems, sizeof pass_elems);
@@ -816,19 +978,19 @@ private:
             st->bits_per_char = BITS;
             st->long_runs = be_.long_runs ? 1u : 0u;
             st->ppp = pl_.ppp;
-            st->max_partition = max_part;
-            st->merge_passes_phase1 = passes1;
-            st->merge_passes_phase2 = passes2;
-            st->merge_passes_samples = passesS;
+            st->max_partition = max_part_;
+            st->merge_passes_phase1 = passes1_;
+            st->merge_passes_phase2 = passes2_;
+            st->merge_passes_samples = passesS_;
             st->workspace_bytes = pl_.bytes;
             st->ms_pack = be_.elapsed_ms(e0, e1);
-            st->ms_sort_subarrays = be_.elapsed_ms(e1, e2);
-            st->ms_select_pivots = be_.elapsed_ms(e2, e3);
-            st->ms_locate_pivots = be_.elapsed_ms(e3, e4);
-            st->ms_partition = be_.elapsed_ms(e4, e5);
-            st->ms_merge_partitions = be_.elapsed_ms(e5, e6);
-            st->ms_boundary_lcp = be_.elapsed_ms(e6, e7);
-            st->ms_output = be_.elapsed_ms(e7, e8);
+            st->ms_sort_subarrays = be_.elapsed_ms(e1, e2_);
+            st->ms_select_pivots = be_.elapsed_ms(e2_, e3_);
+            st->ms_locate_pivots = be_.elapsed_ms(e3_, e4_);
+            st->ms_partition = be_.elapsed_ms(e4_, e5_);
+            st->ms_merge_partitions = be_.elapsed_ms(e5_, e6_);
+            st->ms_boundary_lcp = be_.elapsed_ms(e6_, e7_);
+            st->ms_output = be_.elapsed_ms(e7_, e8);
             st->ms_total = be_.elapsed_ms(e0, e8);
             auto sum = [&](KernelClock& c, double* ms, uint64_t* launches, uint64_t* elems) {
                 for (size_t i = 0; i < c.spans.size(); ++i) {
@@ -843,6 +1005,10 @@ private:
             sum(scatter_clock_, &st->bucket_scatter_ms, &st->bucket_scatter_launches, &st->bucket_scatter_elems);
             sum(count_clock_, &st->bucket_count_ms, &dummy_l, &dummy_e);
             sum(collate_clock_, &st->collate_ms, &dummy_l, &dummy_e);
+            st->path_direct = path_direct_;
+            st->path_fallback = path_fallback_;
+            st->direct_groups = direct_groups_;
+            st->direct_max_group = direct_max_group_;
             st->slot_splits = slot_stats_[0];
             st->slot_splits_redone = slot_stats_[1];
             st->merge_pass_elems = 0;                      // elements the timed passes really merged

@@ -66,7 +66,22 @@ typedef struct caps_sa_stats {
     double collate_ms;
     /* bucket splits done without a count pass (fixed-capacity slots) / splits that had to be redone with one */
     uint32_t slot_splits, slot_splits_redone;
+    /* Which construction ran.  1 = direct path: pivots sampled from the text, ONE scatter of the text into groups of
+     * partitions, then the per-partition sort (select_pivots -> partition -> merge_partitions; sort_subarrays and
+     * locate_pivots are skipped: their order would be discarded).  0 = samplesort path, all six phases of construct().
+     * path_fallback: why a build that tried the direct path took the samplesort path after all (CAPS_SA_FB_*). */
+    uint32_t path_direct, path_fallback;
+    uint32_t direct_groups;        /* groups of consecutive partitions the text was scattered into */
+    uint32_t direct_reserved_;
+    uint64_t direct_max_group;     /* largest group (elements) */
 } caps_sa_stats;
+
+#define CAPS_SA_FB_NONE 0
+#define CAPS_SA_FB_FORCED 1        /* CAPS_SA_PATH=classic */
+#define CAPS_SA_FB_SHAPE 2         /* too small / too few subproblems for a two-level distribution */
+#define CAPS_SA_FB_LONG_RUNS 3     /* the text holds a long periodic stretch: keys alone cannot split it */
+#define CAPS_SA_FB_PIVOT_TIES 4    /* two sampled pivots share their key */
+#define CAPS_SA_FB_GROUP_OVERFLOW 5 /* a group outgrew its region (a very frequent key) */
 
 int caps_sa_hip_device_count(void);
 const char* caps_sa_hip_last_error(void);

@@ -31,3 +31,11 @@ def golden_cases():
 
 def text_bytes(s: str) -> np.ndarray:
     return np.frombuffer(s.encode("latin-1"), dtype=np.uint8)
+
+
+@pytest.fixture(params=["classic", "auto"])
+def sa_path(request, monkeypatch):
+    """Which construction a build takes (csrc/pipeline.h Builder::run): the samplesort path forced, or the default
+    (direct path whenever the input's shape allows it).  The library reads CAPS_SA_PATH at every build."""
+    monkeypatch.setenv("CAPS_SA_PATH", request.param)
+    return request.param

@@ -30,7 +30,7 @@ def test_golden_cases(oracle, golden_cases):
 
 @pytest.mark.parametrize("n,p", [(200000, 7), (200001, 0), (300007, 16), (100000, 1), (4096, 2), (4097, 2),
                                  (8191, 3), (8193, 0), (65536 + 17, 4)])
-def test_random_dna(oracle, n, p):
+def test_random_dna(oracle, sa_path, n, p):
     rs = np.random.RandomState(n % 1000 + p)
     st = _same(emul(), oracle, rs.choice(DNA, size=n), p)
     assert st["bits_per_char"] == 2
@@ -127,9 +127,10 @@ def test_segmented_sort_mixed_lengths(oracle):
     _check_segments(emul(), oracle, T, idx, seg)
 
 
-def test_uniform_keys_take_the_bucket_sort_fast_path(oracle):
-    """Regression guard for the bucket maps: on random DNA every tile of the two big sorts must be
-    sorted by the in-LDS bucket sort (known key range, no bin overflow), with no merge pass."""
+def test_uniform_keys_take_the_bucket_sort_fast_path(oracle, sa_path):
+    """Regression guard for the bucket maps: on random DNA every tile of the big sorts (two on the samplesort
+    path, one on the direct path) must be sorted by the in-LDS bucket sort (known key range, no bin overflow),
+    with no merge pass."""
     import ctypes
     E = emul()
     f = E.dll.caps_sa_emul_tile_stats
@@ -141,7 +142,10 @@ def test_uniform_keys_take_the_bucket_sort_fast_path(oracle):
     f(a, 1)
     slow_unknown, fast_unknown, slow_known, fast_known = list(a)
     assert slow_known == 0 and slow_unknown == 0, list(a)
-    assert fast_known > 700
+    assert st["path_direct"] == (0 if sa_path == "classic" else 1), st
+    assert fast_known > (700 if sa_path == "classic" else 350)
+    if sa_path != "classic":
+        assert st["slot_splits"] >= 1 and st["slot_splits_redone"] == 0 and st["direct_groups"] >= 2
     assert st["merge_passes_phase1"] == 0 and st["merge_passes_phase2"] == 0
     SAo, LCPo = oracle.build_sa_lcp(T, p=20)
     assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo)
@@ -160,7 +164,7 @@ def _skewed(rs, n):
 
 @pytest.mark.parametrize("n,p", [(5000, 3), (40000, 300), (60000, 7), (200000, 400), (400000, 1000), (30011, 0), (257, 2),
                                  (256 * 9 + 1, 9)])
-def test_small_tiles_random_dna(oracle, n, p):
+def test_small_tiles_random_dna(oracle, sa_path, n, p):
     from emul_util import emul_small
     rs = np.random.RandomState(n % 97 + p)
     T = rs.choice(DNA, size=n)
@@ -170,7 +174,7 @@ def test_small_tiles_random_dna(oracle, n, p):
 
 
 @pytest.mark.parametrize("n,p", [(20000, 5), (50000, 64), (120000, 300), (90000, 1200)])
-def test_small_tiles_skewed_and_repetitive(oracle, n, p):
+def test_small_tiles_skewed_and_repetitive(oracle, sa_path, n, p):
     from emul_util import emul_small
     rs = np.random.RandomState(n % 89 + p)
     E = emul_small()
@@ -182,7 +186,7 @@ def test_small_tiles_skewed_and_repetitive(oracle, n, p):
         assert np.array_equal(LCP, LCPo), (n, p)
 
 
-def test_small_tiles_u64_and_segments(oracle):
+def test_small_tiles_u64_and_segments(oracle, sa_path):
     from emul_util import emul_small
     rs = np.random.RandomState(77)
     E = emul_small()
@@ -225,6 +229,7 @@ def test_equalised_split_never_needs_more_passes_than_the_plain_one(oracle, monk
     for i in range(2, m.size):
         m[i] = min(3, int(np.searchsorted(np.cumsum(trans[m[i - 2] * 4 + m[i - 1]]), u[i])))
     texts.append(DNA[m])
+    monkeypatch.setenv("CAPS_SA_PATH", "classic")        # the pass counts below are those of the samplesort path's two sorts
     for E in (emul_small(), emul()):
         for T in texts:
             for p in (4, 37):

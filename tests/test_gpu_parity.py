@@ -54,7 +54,7 @@ def test_reference_dump_digest_pins(L, oracle):
 
 @pytest.mark.parametrize("n,p", [(200000, 7), (200001, 0), (300007, 16), (100000, 1), (4096, 2), (4097, 2),
                                  (8191, 3), (8193, 0), (65536 + 17, 4), (1, 0), (5, 0), (31, 0), (32, 0), (33, 3)])
-def test_random_dna_vs_naive(L, oracle, n, p):
+def test_random_dna_vs_naive(L, oracle, sa_path, n, p):
     rs = np.random.RandomState(n % 1000 + p)
     st = _same(L, oracle, rs.choice(DNA, size=n), p, ref="naive")
     assert st["bits_per_char"] == 2
@@ -177,16 +177,21 @@ def _device_build_and_verify(L, n, p, seed):
     return st
 
 
-def test_c2_256mib_device_resident(L):
-    """BASELINE config 1: 256 MiB random DNA, u32, p = 8000."""
+def test_c2_256mib_device_resident(L, sa_path):
+    """BASELINE config 1: 256 MiB random DNA, u32, p = 8000 (both constructions)."""
     st = _device_build_and_verify(L, 268_435_457, 8000, 42)
     assert st["p_eff"] == 8000 and st["bits_per_char"] == 2
+    assert st["path_direct"] == (0 if sa_path == "classic" else 1), st
 
 
-def test_c3_3g_device_resident(L):
-    """BASELINE headline size: 3e9 bases (+1), u32, p = 8000.  Property check on the device."""
+def test_c3_3g_device_resident(L, sa_path):
+    """BASELINE headline size: 3e9 bases (+1), u32, p = 8000.  Property check on the device (both constructions;
+    the default must be the direct path with its splits kept in slots)."""
     st = _device_build_and_verify(L, 3_000_000_001, 8000, 42)
     assert st["p_eff"] == 8000
+    assert st["path_direct"] == (0 if sa_path == "classic" else 1), st
+    if sa_path != "classic":
+        assert st["path_fallback"] == 0 and st["slot_splits_redone"] == 0 and st["direct_groups"] == 1000, st
 
 
 def test_sharded_driver_single_rank_rccl(L):
@@ -284,18 +289,19 @@ def test_u64_device_resident_50m(L):
     assert L.verify_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr(), idx_bits=64) == 0
 
 
-def test_skewed_and_texty_inputs_device(L, oracle):
+def test_skewed_and_texty_inputs_device(L, oracle, sa_path):
     """Keys far from uniform in their range: buckets overflow their tile and are finished by the
     LCP-merge passes (skip_finished / unify / finalize-with-records paths)."""
     rs = np.random.RandomState(21)
     T = rs.choice(DNA, size=3_000_000, p=[0.7, 0.1, 0.1, 0.1])
     st = _same(L, oracle, T, 50)
-    assert st["merge_passes_phase1"] + st["merge_passes_phase2"] > 0
+    if sa_path == "classic":
+        assert st["merge_passes_phase1"] + st["merge_passes_phase2"] > 0
     letters = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz ", dtype=np.uint8)
     _same(L, oracle, rs.choice(letters, size=2_000_000, p=np.r_[np.full(26, 0.03), 0.22]), 40)
 
 
-def test_genome_like_markov_with_repeats_device(L):
+def test_genome_like_markov_with_repeats_device(L, sa_path):
     """Order-5 Markov chain with skewed transitions + planted mutated repeats (tools/genome_like.py):
     most tiles leave the bucket-sort fast path (samplesort / rank-merge levels), buckets overflow into
     LCP-merge passes.  Checked with the exact device verifier."""
@@ -314,12 +320,13 @@ def test_genome_like_markov_with_repeats_device(L):
     assert int(LCP.max().item()) > 200          # the planted repeats are there
 
 
-def test_slot_splits_kept_on_uniform_keys_and_redone_on_skew(L, oracle):
+def test_slot_splits_kept_on_uniform_keys_and_redone_on_skew(L, oracle, sa_path):
     """The bucket splits of phase 1 and phase 2 first scatter into fixed-capacity slots (no count pass).
     Uniform keys: both are kept (and C2 / C3 rely on that for their speed).  Skewed keys: a bucket
     overflows its slot, the split is redone with the count pass; both ways the result is exact."""
     st = _device_build_and_verify(L, 60_000_001, 200, 5)
-    assert st["slot_splits"] == 2 and st["slot_splits_redone"] == 0, st
+    assert st["slot_splits"] == (2 if sa_path == "classic" else 1) and st["slot_splits_redone"] == 0, st
+    assert st["path_direct"] == (0 if sa_path == "classic" else 1), st
     assert st["merge_passes_phase1"] == 0 and st["merge_passes_phase2"] == 0
     rs = np.random.RandomState(22)
     T = rs.choice(DNA, size=4_000_000, p=[0.6, 0.2, 0.1, 0.1])
@@ -327,15 +334,16 @@ def test_slot_splits_kept_on_uniform_keys_and_redone_on_skew(L, oracle):
     assert st["slot_splits_redone"] >= 1, st
 
 
-def test_partitions_spanning_more_runs_than_a_tile_stages(L):
+def test_partitions_spanning_more_runs_than_a_tile_stages(L, monkeypatch):
     """p = 8000 on 40 M bases: a 4096-element tile of a 5000-element partition spans more than 4096
     of the p sorted subarrays' runs, so the phase-2 scatter resolves runs by binary search in global
     memory instead of in its LDS stage (bucket_scatter_kernel<SRC_RUNS>, !runs_staged)."""
+    monkeypatch.setenv("CAPS_SA_PATH", "classic")          # the samplesort path's phase 2 is what this is about
     st = _device_build_and_verify(L, 40_000_001, 8000, 6)
-    assert st["p_eff"] == 8000 and st["max_partition"] > 4096
+    assert st["p_eff"] == 8000 and st["max_partition"] > 4096 and st["path_direct"] == 0
 
 
-def test_more_subproblems_than_a_dispatch_has_threads(L, oracle):
+def test_more_subproblems_than_a_dispatch_has_threads(L, oracle, sa_path):
     """p = 72,845 (found by tools/stress_gpu.py): locate_kernel's natural grid of p^2 threads exceeds the
     2^32 work-items of one dispatch, which HIP truncates silently; the kernel loops over its blocks."""
     rs = np.random.RandomState(172)
