@@ -1794,21 +1794,29 @@ constexpr uint32_t BUCKET_LDS = TILE_BINS_;            // buckets per segment th
 GLOBAL_FN LAUNCH_BOUNDS(256) bucket_plan_kernel(KCTX const uint64_t* __restrict__ seg_start, const uint64_t* __restrict__ seg_end,
                                                 uint32_t G, uint32_t range_mode,
                                                 const uint64_t* __restrict__ pkey, uint32_t part_off, uint32_t part_total,
-                                                uint32_t enable, uint32_t fine,
+                                                uint32_t enable, uint32_t fine, uint32_t sub,
                                                 BucketParams* __restrict__ bp, uint64_t* __restrict__ segB)
 {
+    // sub > 1: every `sub` consecutive segments are the sub-streams of ONE parent (a group of the direct path, written
+    // by level A as one stream per XCD): they share the parent's key range and its buckets.  All of them get the parent's
+    // map; the bucket count is credited to the LAST sub-stream only, so that the exclusive scan of segB gives every
+    // sub-stream the same first bucket.
     PAR(tid) {
         const uint32_t g = K_BLOCK_IDX * K_BLOCK_DIM + tid;
         if (g < G) {
-            const uint64_t len = seg_end_of(seg_start, seg_end, g) - seg_start[g];
+            const uint32_t parent = g / sub, first = parent * sub;
+            uint64_t len = 0;
+            for (uint32_t x = 0; x < sub && first + x < G; ++x) len += seg_end_of(seg_start, seg_end, first + x) - seg_start[first + x];
             uint64_t kmin = 0, kmax = ~0ull;
-            if (range_mode == 1) {                   // segment g is partition part_off + g of part_total
-                const uint32_t j = part_off + g;
+            if (range_mode == 1) {                   // the parent is partition part_off + parent of part_total
+                const uint32_t j = part_off + parent;
                 if (j > 0) kmin = pkey[j - 1];
                 if (j + 1 < part_total) kmax = pkey[j];
             }
             uint32_t B = 1;
             if (enable && len > TILE_E && kmax > kmin) B = (uint32_t)((len + BUCKET_TARGET - 1) / BUCKET_TARGET);
+            // sub-streams never take the scatter's one-bucket shortcut (an identity copy of ONE segment): at least two buckets
+            if (sub > 1 && B < 2) B = 2;
             // fine > 1: the map of the equalised split's FINE buckets (bucket_group_kernel): k <= `fine` per bucket slot,
             // as many as the LDS histograms hold.  A whole number per slot, so that the plain split (k consecutive fine
             // buckets per slot) is one of the groupings and the chosen one is never worse; segments with more than
@@ -1819,7 +1827,7 @@ GLOBAL_FN LAUNCH_BOUNDS(256) bucket_plan_kernel(KCTX const uint64_t* __restrict_
             }
             const BucketParams q = make_bucket_params(kmin, kmax, B);
             bp[g] = q;
-            segB[g] = B;
+            segB[g] = (g % sub == sub - 1 || g == G - 1) ? B : 0;
         }
     }
 }
@@ -1895,7 +1903,7 @@ GLOBAL_FN LAUNCH_BOUNDS(256) bucket_group_kernel(KCTX uint32_t G, const uint64_t
 // bin map over that range.  One thread per bucket.
 GLOBAL_FN LAUNCH_BOUNDS(256) bucket_ranges_kernel(KCTX const uint64_t* __restrict__ bstart, uint32_t G,
                                                   const BucketParams* __restrict__ bps, const uint64_t* __restrict__ pkey,
-                                                  uint32_t range_mode, uint32_t part_off, uint32_t part_total,
+                                                  uint32_t range_mode, uint32_t part_off, uint32_t part_total, uint32_t sub,
                                                   BucketParams* __restrict__ tile_map,
                                                   const BucketParams* __restrict__ fbps, const uint32_t* __restrict__ gfirst)
 {
@@ -1912,7 +1920,7 @@ GLOBAL_FN LAUNCH_BOUNDS(256) bucket_ranges_kernel(KCTX const uint64_t* __restric
             const BucketParams bp = bps[g];
             uint64_t kmin = 0, kmax = ~0ull;
             if (range_mode == 1) {
-                const uint32_t j = part_off + g;
+                const uint32_t j = part_off + g / sub;            // sub-streams of one parent share its buckets (bucket_plan_kernel)
                 if (j > 0) kmin = pkey[j - 1];
                 if (j + 1 < part_total) kmax = pkey[j];
             }
@@ -1941,6 +1949,9 @@ GLOBAL_FN LAUNCH_BOUNDS(256) bucket_ranges_kernel(KCTX const uint64_t* __restric
 // packed text in LDS (one coalesced read of ~1 KiB) instead of three dependent global loads
 // per suffix.  TEXT_WIN words cover TILE_E positions + one key + alignment slack for BITS = 8.
 constexpr uint32_t TEXT_WIN = TILE_E / 4 + 24;
+// cells of the splitter LUT of bucket_scatter_kernel<MAP_SPLIT> (split_lut_kernel)
+constexpr uint32_t SPLIT_LUT_BITS = TILE_E >= 4096 ? 12 : TILE_E >= 256 ? 8 : 4;
+constexpr uint32_t SPLIT_LUT_CELLS = 1u << SPLIT_LUT_BITS;
 
 // word index (in P) of the first staged word for a tile whose first text position is pos0
 template <int BITS> HD uint64_t text_win_base(uint64_t pos0) { return pos0 / TextTraits<BITS>::CPW; }
@@ -2029,8 +2040,13 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
                                                        idx_t* __restrict__ cursor,
                                                        uint64_t* __restrict__ out_key, idx_t* __restrict__ out_sa,
                                                        const BucketParams* __restrict__ fbps, const uint32_t* __restrict__ gfirst,
-                                                       const uint64_t* __restrict__ split)
+                                                       const uint64_t* __restrict__ split, const uint16_t* __restrict__ split_lut,
+                                                       const uint32_t* __restrict__ split_span, uint32_t sub)
 {
+    // sub > 1 (slots only; level A of the direct path): bucket i owns `sub` slots, one per sub-stream; the tiles of a
+    // launch are dealt to the sub-streams round-robin by block index, i.e. (observed dispatch order, MI355X_MICROARCH
+    // "Workgroup dispatch") one sub-stream per XCD: the short runs that consecutive tiles append to a stream then
+    // complete each other's cache lines in ONE L2 instead of leaving partial lines in eight.  Any placement is correct.
     constexpr bool GROUPED = MAP == MAP_GROUPED;
     // gfirst != null: equalised split -- the key's FINE bucket (map fbps[g]) is looked up in the segment's group table
     // (bucket_group_kernel) to get its bucket slot.
@@ -2041,11 +2057,13 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
     const bool spec = slot_cap != 0;
     const idx_t NO_SLOT = (idx_t)~(idx_t)0;
 #if CAPS_SCATTER_SWZ
-    const uint32_t v = (uint32_t)xcd_swizzle(K_BLOCK_IDX, K_GRID_DIM);   // tiles of one segment on one XCD: the partial
+    const uint32_t v = sub > 1 ? K_BLOCK_IDX                             // sub-streams: tile -> stream by block index
+                               : (uint32_t)xcd_swizzle(K_BLOCK_IDX, K_GRID_DIM);   // tiles of one segment on one XCD: the partial
                                                                          // lines of neighbouring runs meet in its L2
 #else
     const uint32_t v = K_BLOCK_IDX;
 #endif
+    const uint32_t sx = sub > 1 ? K_BLOCK_IDX % sub : 0u;
     if (v >= sd.tile_off[sd.G]) return;
     const uint32_t b = v;
     const uint32_t g = sd.tile_rec[b].g;
@@ -2079,14 +2097,19 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
     const uint64_t w0 = text_win_base<BITS>(text_base + start);
     // MAP_SPLIT: the splitter table sits in the key staging array too, behind the text window
     uint64_t* stab = skey + TILE_E / 4;
+    uint16_t* slut = reinterpret_cast<uint16_t*>(ssa);    // ... and its LUT in the index staging array
     static_assert(TEXT_WIN * sizeof(uint32_t) <= (TILE_E / 4) * sizeof(uint64_t) && TILE_E / 4 + BUCKET_LDS <= TILE_E,
                   "text window + splitter table fit the key staging array");
+    static_assert((SPLIT_LUT_CELLS + 1) * sizeof(uint16_t) <= TILE_E * sizeof(idx_t), "splitter LUT fits the index staging array");
     const uint32_t n_split = MAP == MAP_SPLIT && bp.B > 1 ? bp.B - 1 : 0u;
     RUNS_TILE_SETUP
     if (lds || FROM_TEXT || FROM_RUNS) {
         PAR(tid) {
             if (lds) for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0;
-            if (MAP == MAP_SPLIT && lds) for (uint32_t i = tid; i < n_split; i += K_BLOCK_DIM) stab[i] = split[i];
+            if (MAP == MAP_SPLIT && lds) {
+                for (uint32_t i = tid; i < n_split; i += K_BLOCK_DIM) stab[i] = split[i];
+                for (uint32_t i = tid; i <= SPLIT_LUT_CELLS; i += K_BLOCK_DIM) slut[i] = split_lut[i];
+            }
             if (grouped)                                   // slot i owns the fine buckets [gfirst[i], gfirst[i + 1]) (F for unused slots)
                 for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM) {
                     const uint32_t f0 = gfirst[b0 + i], f1 = i + 1 < bp.B ? gfirst[b0 + i + 1] : fbp.B;
@@ -2100,7 +2123,8 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
     }
     if (MAP == MAP_SPLIT && lds) {
         // keys first, then the TILE_EPT table searches of a thread in lockstep (independent LDS reads in flight together)
-        const uint32_t top = pow2_above(n_split);
+        const uint32_t top = pow2_above(split_span[0]);      // candidates per LUT cell (block-uniform): depth of the search
+        TL_DECL(uint32_t, rh, TILE_EPT);
         PAR(tid) {
             UNROLL
             for (uint32_t k = 0; k < TILE_EPT; ++k) {
@@ -2112,16 +2136,18 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
                     key = FROM_TEXT ? window64<BITS>(twin, text_base + start + e - w0 * TextTraits<BITS>::CPW) : in_key[src];
                     sa = FROM_TEXT ? (idx_t)(text_base + start + e) : in_sa[src];
                 }
+                const uint32_t cell = (uint32_t)(key >> (64 - SPLIT_LUT_BITS));
                 TL(rk, tid, k) = key;
                 TL(rs, tid, k) = sa;
-                TL(rb, tid, k) = 0;
+                TL(rb, tid, k) = slut[cell];
+                TL(rh, tid, k) = slut[cell + 1];
             }
             for (uint32_t s = top >> 1; s >= 1; s >>= 1) {
                 UNROLL
                 for (uint32_t k = 0; k < TILE_EPT; ++k) {
                     const uint32_t idx = TL(rb, tid, k) + s - 1;
                     const uint64_t mk = stab[idx < n_split ? idx : n_split - 1];
-                    if (idx < n_split && mk < TL(rk, tid, k)) TL(rb, tid, k) += s;
+                    if (idx < TL(rh, tid, k) && mk < TL(rk, tid, k)) TL(rb, tid, k) += s;
                 }
             }
             UNROLL
@@ -2154,7 +2180,7 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
                         bk = bucket_of(fbp, key);
                         if (grouped) bk = gtab[bk];
                     }
-                    r = lds ? FETCH_ADD_U32(&hist[bk], 1u) : caps_fetch_add(&cursor[b0 + bk], (idx_t)1);
+                    r = lds ? FETCH_ADD_U32(&hist[bk], 1u) : caps_fetch_add(&cursor[(b0 + bk) * (spec ? sub : 1u) + sx], (idx_t)1);
                 }
                 TL(rk, tid, k) = key;
                 TL(rs, tid, k) = sa;
@@ -2172,7 +2198,7 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
                 if (e < cnt) {
                     // one bucket: slot = same offset inside the segment (64-bit: such a segment can be long)
                     const uint64_t off = (bp.B == 1 ? (start - t.s0) : 0) + TL(rr, tid, k);
-                    const uint64_t bi = b0 + TL(rb, tid, k);
+                    const uint64_t bi = (b0 + TL(rb, tid, k)) * (spec ? sub : 1u) + sx;
                     if (!spec || off < slot_cap) {
                         const uint64_t dst = (spec ? bi * slot_cap : sub_start[bi]) + off;
                         out_key[dst] = TL(rk, tid, k);
@@ -2180,7 +2206,7 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
                     }
                 }
             }
-            if (spec && bp.B == 1 && tid == 0) caps_fetch_add(&cursor[b0], (idx_t)cnt);    // the size of a one-bucket segment
+            if (spec && bp.B == 1 && tid == 0) caps_fetch_add(&cursor[b0 * sub + sx], (idx_t)cnt);    // the size of a one-bucket segment
         }
         return;
     }
@@ -2190,9 +2216,10 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
             const uint32_t c = hist[i];
             idx_t ob = 0;
             if (c) {
-                const idx_t old = caps_fetch_add(&cursor[b0 + i], (idx_t)c);
+                const uint64_t ci = spec ? (b0 + i) * sub + sx : b0 + i;
+                const idx_t old = caps_fetch_add(&cursor[ci], (idx_t)c);
                 if (!spec) ob = (idx_t)(sub_start[b0 + i] + old);
-                else ob = (uint64_t)old + c <= slot_cap ? (idx_t)((b0 + i) * slot_cap + old) : NO_SLOT;
+                else ob = (uint64_t)old + c <= slot_cap ? (idx_t)(ci * slot_cap + old) : NO_SLOT;
             }
             obase[i] = ob;
         }
@@ -2227,6 +2254,138 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
                 }
             }
         }
+    }
+}
+
+// ---- level A of the direct path: the text -> groups, in tiles of GA_E consecutive positions -------------------------
+// A dedicated kernel rather than bucket_scatter_kernel<SRC_TEXT, MAP_SPLIT> (kept: it is the same computation on
+// TILE_E positions and serves as its cross-check): with ~1000 groups, a 4096-element tile spends as much on its groups
+// (histogram, one cursor bump each, scan) as on its elements, and appends runs of 4 elements.  Here a workgroup takes
+// GA_E = 4 x TILE_E positions.  Nothing but the tile's slice of the packed text is staged: a key is cut from it when the
+// element is classified and again when it is written, so the per-element state between the two is ONE register
+// (group << 14 | position in the re-ordered tile), and the re-ordered tile goes out in TILE_E-element chunks through a
+// 16 KB permutation buffer -- 60 KB of LDS at 2-bit codes, two workgroups per CU.
+//   cursor[sx * K1 + g]  elements of group g appended so far to sub-stream sx (= block index % sub, see
+//                        bucket_scatter_kernel); ends as the stream's size -- larger than slot_cap = the stream overflowed,
+//                        its surplus was dropped and the caller must not use the result
+//   stream (g, sx) owns [(g * sub + sx) * slot_cap, +slot_cap) of out_key / out_sa
+constexpr uint32_t GA_TILES = 4;
+constexpr uint32_t GA_E = GA_TILES * TILE_E;
+constexpr uint32_t GA_EPT = GA_E / TILE_NT;
+static_assert(GA_E <= (1u << 14) && BUCKET_LDS <= (1u << 11), "group << 14 | position fits a register");
+
+template <typename idx_t, int BITS>
+GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) group_scatter_kernel(KCTX const uint32_t* __restrict__ P, uint64_t n_words,
+                                                      uint64_t text_base, uint64_t len, const uint64_t* __restrict__ split, uint32_t K1,
+                                                      const uint16_t* __restrict__ split_lut, const uint32_t* __restrict__ split_span,
+                                                      uint32_t sub, uint64_t slot_cap, idx_t* __restrict__ cursor,
+                                                      uint64_t* __restrict__ out_key, idx_t* __restrict__ out_sa)
+{
+    constexpr uint32_t CPW = TextTraits<BITS>::CPW;
+    constexpr uint32_t WIN = GA_E / CPW + 8;                   // words covering GA_E positions + one key
+    const idx_t NO_SLOT = (idx_t)~(idx_t)0;
+    SHARED_ARRAY(uint32_t, twin, WIN);
+    SHARED_ARRAY(uint64_t, stab, BUCKET_LDS);
+    SHARED_ARRAY(uint16_t, slut, SPLIT_LUT_CELLS + 2);
+    SHARED_ARRAY(uint32_t, hist, TILE_BINS + 1);
+    SHARED_ARRAY(idx_t, obase, TILE_BINS);
+    SHARED_ARRAY(uint32_t, perm, TILE_E);
+    TL_DECL(uint32_t, pk, GA_EPT);
+    const uint64_t start = (uint64_t)K_BLOCK_IDX * GA_E;
+    if (start >= len) return;
+    const uint32_t cnt = (uint32_t)(len - start < GA_E ? len - start : GA_E);
+    const uint32_t sx = sub > 1 ? K_BLOCK_IDX % sub : 0u;
+    const uint32_t n_split = K1 - 1;
+    const uint64_t pos0 = text_base + start;
+    const uint64_t w0 = pos0 / CPW;
+    const uint32_t top = pow2_above(split_span[0]);
+    PAR(tid) {
+        for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0;
+        for (uint32_t i = tid; i < WIN; i += K_BLOCK_DIM) twin[i] = w0 + i < n_words ? P[w0 + i] : 0u;
+        for (uint32_t i = tid; i < n_split; i += K_BLOCK_DIM) stab[i] = split[i];
+        for (uint32_t i = tid; i <= SPLIT_LUT_CELLS; i += K_BLOCK_DIM) slut[i] = split_lut[i];
+    }
+    SYNC();
+    // ---- classify: group = #{splitters < key} (LUT cell -> a few candidates -> branch-free search), rank inside (tile, group)
+    PAR(tid) {
+        UNROLL
+        for (uint32_t kk = 0; kk < GA_EPT; kk += 4) {
+            uint64_t key[4];
+            uint32_t lo[4], hi[4];
+            UNROLL
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t e = tid + (kk + j) * TILE_NT;
+                key[j] = e < cnt ? window64<BITS>(twin, pos0 + e - w0 * CPW) : 0;
+                const uint32_t cell = (uint32_t)(key[j] >> (64 - SPLIT_LUT_BITS));
+                lo[j] = slut[cell];
+                hi[j] = slut[cell + 1];
+            }
+            for (uint32_t st = top >> 1; st >= 1; st >>= 1) {
+                UNROLL
+                for (uint32_t j = 0; j < 4; ++j) {
+                    const uint32_t idx = lo[j] + st - 1;
+                    const uint64_t mk = stab[idx < n_split ? idx : (n_split ? n_split - 1 : 0)];
+                    if (idx < hi[j] && mk < key[j]) lo[j] += st;
+                }
+            }
+            UNROLL
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t e = tid + (kk + j) * TILE_NT;
+                uint32_t v = 0;
+                if (e < cnt) v = (lo[j] << 14) | FETCH_ADD_U32(&hist[lo[j]], 1u);
+                TL(pk, tid, kk + j) = v;
+            }
+        }
+    }
+    SYNC();
+    // ---- one cursor bump per (tile, non-empty group); then hist -> first position of every group in the re-ordered tile
+    PAR(tid) {
+        for (uint32_t i = tid; i < K1; i += K_BLOCK_DIM) {
+            const uint32_t c = hist[i];
+            idx_t ob = 0;
+            if (c) {
+                const idx_t old = caps_fetch_add(&cursor[(uint64_t)sx * K1 + i], (idx_t)c);
+                ob = (uint64_t)old + c <= slot_cap ? (idx_t)(((uint64_t)i * sub + sx) * slot_cap + old) : NO_SLOT;
+            }
+            obase[i] = ob;
+        }
+    }
+    SYNC();
+    block_exclusive_scan_bins(KCTX_PASS hist);
+    PAR(tid) {
+        UNROLL
+        for (uint32_t k = 0; k < GA_EPT; ++k) {
+            const uint32_t v = TL(pk, tid, k), g = v >> 14;
+            TL(pk, tid, k) = (g << 14) | (hist[g] + (v & 0x3FFFu));       // group << 14 | position q in the re-ordered tile
+        }
+    }
+    // ---- write the re-ordered tile, TILE_E positions at a time: perm[q] = group << 14 | element
+    for (uint32_t c0 = 0; c0 < cnt; c0 += TILE_E) {
+        PAR(tid) {
+            UNROLL
+            for (uint32_t k = 0; k < GA_EPT; ++k) {
+                const uint32_t e = tid + k * TILE_NT;
+                const uint32_t v = TL(pk, tid, k), q = v & 0x3FFFu;
+                if (e < cnt && q - c0 < TILE_E) perm[q - c0] = (v & ~0x3FFFu) | e;
+            }
+        }
+        SYNC();
+        PAR(tid) {
+            UNROLL
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                const uint32_t q = c0 + tid + k * TILE_NT;
+                if (q < cnt) {
+                    const uint32_t v = perm[q - c0], g = v >> 14, e = v & 0x3FFFu;
+                    const idx_t ob = obase[g];
+                    if (ob != NO_SLOT) {
+                        const uint64_t dst = (uint64_t)ob + (q - hist[g]);
+                        out_key[dst] = window64<BITS>(twin, pos0 + e - w0 * CPW);
+                        out_sa[dst] = (idx_t)(pos0 + e);
+                    }
+                }
+            }
+        }
+        SYNC();
     }
 }
 
@@ -2344,22 +2503,59 @@ GLOBAL_FN LAUNCH_BOUNDS(256) group_keys_kernel(KCTX const uint64_t* __restrict__
     }
 }
 
-// The groups as segments in fixed-capacity regions: group g = [g * cap, g * cap + size_g) of the level-A output.
-template <typename idx_t>
-GLOBAL_FN LAUNCH_BOUNDS(256) slot_segments_kernel(KCTX const idx_t* __restrict__ sizes, uint32_t G, uint64_t cap,
-                                                  uint64_t* __restrict__ seg_start, uint64_t* __restrict__ seg_end,
-                                                  uint64_t* __restrict__ total)
+// Splitter search accelerator of level A (bucket_scatter_kernel<MAP_SPLIT>): the top SPLIT_LUT_BITS bits of a key select a
+// cell; lut[c] = #{splitters < smallest key of cell c} (lut[cells] = n_split), so a key of cell c belongs to group
+// lut[c] + #{splitters in [lut[c], lut[c+1]) that are < key}: a search over lut[c+1] - lut[c] candidates instead of all of
+// them -- 0 to 2 on pivots that are roughly uniform in the key range, whatever it takes on skewed ones: span[0] = the largest
+// such count, the (block-uniform) depth of the branch-free search.
+
+GLOBAL_FN LAUNCH_BOUNDS(256) split_lut_kernel(KCTX const uint64_t* __restrict__ split, uint32_t n_split, uint16_t* __restrict__ lut,
+                                              uint32_t* __restrict__ span)
 {
     PAR(tid) {
-        const uint32_t g = K_BLOCK_IDX * K_BLOCK_DIM + tid;
-        if (g < G) {
-            const uint64_t z = (uint64_t)sizes[g];
-            seg_start[g] = (uint64_t)g * cap;
-            seg_end[g] = (uint64_t)g * cap + (z < cap ? z : cap);      // an overflowed group is reported through out2 / total
+        const uint32_t c = K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (c <= SPLIT_LUT_CELLS) {
+            uint32_t lo = 0, hi = n_split;                               // #{splitters < cell_lo(c)}; cell_lo(cells) = 2^64
+            if (c < SPLIT_LUT_CELLS) {
+                const uint64_t cell_lo = (uint64_t)c << (64 - SPLIT_LUT_BITS);
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (split[mid] < cell_lo) lo = mid + 1; else hi = mid; }
+            } else lo = n_split;
+            lut[c] = (uint16_t)lo;
+            if (c < SPLIT_LUT_CELLS) {
+                uint32_t a = lo, z = n_split;                            // lut[c + 1], recomputed (no dependence on another thread)
+                if (c + 1 < SPLIT_LUT_CELLS) {
+                    const uint64_t next_lo = (uint64_t)(c + 1) << (64 - SPLIT_LUT_BITS);
+                    while (a < z) { const uint32_t mid = (a + z) >> 1; if (split[mid] < next_lo) a = mid + 1; else z = mid; }
+                } else a = n_split;
+#ifdef CAPS_EMUL
+                if (a - lo > span[0]) span[0] = a - lo;
+#else
+                if (a > lo) atomicMax(&span[0], a - lo);
+#endif
+            }
+        }
+    }
+}
+
+// The groups as segments in fixed-capacity regions: group g = [g * cap, g * cap + size_g) of the level-A output.
+template <typename idx_t>
+GLOBAL_FN LAUNCH_BOUNDS(256) slot_segments_kernel(KCTX const idx_t* __restrict__ sizes, uint32_t K1, uint32_t sub, uint32_t stream_major,
+                                                  uint64_t cap, uint64_t* __restrict__ seg_start, uint64_t* __restrict__ seg_end,
+                                                  uint64_t* __restrict__ total)
+{
+    // segment s = g * sub + x is sub-stream x of group g; its size is sizes[x * K1 + g] (stream_major: group_scatter_kernel's
+    // cursors) or sizes[s] (bucket_scatter_kernel's)
+    PAR(tid) {
+        const uint32_t G = K1 * sub;
+        const uint32_t s = K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (s < G) {
+            const uint64_t z = (uint64_t)sizes[stream_major ? (uint64_t)(s % sub) * K1 + s / sub : s];
+            seg_start[s] = (uint64_t)s * cap;
+            seg_end[s] = (uint64_t)s * cap + (z < cap ? z : cap);      // an overflowed stream is reported through total[1]
             ATOMIC_ADD_U64(total, z);
             if (z > cap) ATOMIC_MAX_U64(total + 1, z);
         }
-        if (g == G) seg_start[g] = (uint64_t)G * cap;
+        if (s == G) seg_start[s] = (uint64_t)G * cap;
     }
 }
 

@@ -66,6 +66,12 @@ struct SegBufs {
 
 constexpr uint32_t kMaxPasses = 96;
 
+// Sub-streams per group of the direct path's level A (one per XCD of the MI355X, see bucket_scatter_kernel).
+#ifndef CAPS_DIRECT_SUB
+#define CAPS_DIRECT_SUB 8
+#endif
+constexpr uint32_t DIRECT_SUB = CAPS_DIRECT_SUB;
+
 // Fine buckets per bucket slot of the equalised split (bucket_group_kernel), as far as the LDS histograms hold them.
 #ifndef CAPS_EQ_FINE
 #define CAPS_EQ_FINE 16
@@ -92,7 +98,7 @@ struct BucketBufs {
     uint32_t* gfirst = nullptr;       // [nb_cap] first fine bucket of every slot's group
     uint32_t nb_cap = 0;
     uint64_t tile_cap = 0;
-    static uint32_t bucket_bound(uint64_t n_elems, uint32_t G) { return (uint32_t)(n_elems / BUCKET_TARGET + G + 1); }
+    static uint32_t bucket_bound(uint64_t n_elems, uint32_t G) { return (uint32_t)(n_elems / BUCKET_TARGET + 2 * (uint64_t)G + 2); }
 };
 
 template <typename idx_t> struct Plan {
@@ -111,7 +117,9 @@ template <typename idx_t> struct Plan {
     idx_t* rulerT = nullptr;
     uint64_t* sizes = nullptr;
     uint64_t* gkey = nullptr;        // [p]   direct path: the pivot keys that close the groups
-    uint64_t* dstat = nullptr;       // [4]   direct path: {elements scattered, largest overflowed group, flag word, -}
+    uint64_t* dstat = nullptr;       // [4]   direct path: {elements scattered, largest overflowed group, (u32 pivot-tie flag, u32 LUT span), -}
+    idx_t* dcur = nullptr;           // [gseg] direct path: level A's cursors = sizes of the groups' sub-streams
+    uint16_t* glut = nullptr;        // [SPLIT_LUT_CELLS + 1] direct path: LUT over the group keys (split_lut_kernel)
     uint64_t* partial = nullptr;     // [PART_CHUNKS * p] partial column sums of Pm
     SegBufs seg1, seg2, segS;
     TileDesc* desc = nullptr;        // [tile_cap] per-pass tile descriptors
@@ -146,6 +154,8 @@ Plan<idx_t> make_plan(uint64_t n, uint64_t p_arg, char* base)
     const uint64_t nn = n ? n : 1;
     const bool split = pl.p >= 2;
     const uint32_t p = split ? pl.p : 1;
+    // per-segment tables also serve the direct path's level B: up to DIRECT_SUB sub-streams for each of <= BUCKET_LDS groups
+    const uint32_t gseg = std::max<uint32_t>(p, DIRECT_SUB * std::min<uint32_t>(p, BUCKET_LDS));
     pl.m = split ? (uint64_t)p * pl.ppp : 0;
     pl.bk.nb_cap = BucketBufs::bucket_bound(nn, p);
     pl.bk.tile_cap = nn / TILE_E + pl.bk.nb_cap + 2;
@@ -181,15 +191,18 @@ Plan<idx_t> make_plan(uint64_t n, uint64_t p_arg, char* base)
         pl.sizes = ar.take<uint64_t>(p);
         pl.gkey = ar.take<uint64_t>(p);
         pl.dstat = ar.take<uint64_t>(4);
+        pl.dcur = ar.take<idx_t>(gseg);
+        pl.glut = ar.take<uint16_t>(SPLIT_LUT_CELLS + 2);
         pl.partial = ar.take<uint64_t>((size_t)PART_CHUNKS * p);
-        segs(pl.seg2, p, pl.tile_cap);
-        pl.seg2.seg_end = ar.take<uint64_t>((size_t)p + 1);
+        segs(pl.seg2, gseg, pl.tile_cap);
+        pl.seg2.G = p;
+        pl.seg2.seg_end = ar.take<uint64_t>((size_t)gseg + 1);
         segs(pl.segS, 1, pl.m / TILE_E + 3);
     }
     pl.desc = ar.take<TileDesc>(pl.tile_cap + 1);
-    pl.bk.params = ar.take<BucketParams>(p);
-    pl.bk.segB = ar.take<uint64_t>(p);
-    pl.bk.bstart = ar.take<uint64_t>((size_t)p + 1);
+    pl.bk.params = ar.take<BucketParams>(gseg);
+    pl.bk.segB = ar.take<uint64_t>(gseg);
+    pl.bk.bstart = ar.take<uint64_t>((size_t)gseg + 1);
     pl.bk.count = ar.take<uint64_t>(pl.bk.nb_cap);
     pl.bk.cursor = ar.take<idx_t>(pl.bk.nb_cap);
     pl.bk.scan_tmp = ar.take<uint64_t>(2 * ((size_t)pl.bk.nb_cap / SCAN_CHUNK + 2));
@@ -199,9 +212,9 @@ Plan<idx_t> make_plan(uint64_t n, uint64_t p_arg, char* base)
     pl.bk.first_sa = ar.take<idx_t>(pl.bk.nb_cap);
     pl.bk.last_sa = ar.take<idx_t>(pl.bk.nb_cap);
     segs(pl.bk.sub, pl.bk.nb_cap, pl.bk.tile_cap);
-    pl.bk.fparams = ar.take<BucketParams>(p);
-    pl.bk.fsegB = ar.take<uint64_t>(p);
-    pl.bk.fstart = ar.take<uint64_t>((size_t)p + 1);
+    pl.bk.fparams = ar.take<BucketParams>(gseg);
+    pl.bk.fsegB = ar.take<uint64_t>(gseg);
+    pl.bk.fstart = ar.take<uint64_t>((size_t)gseg + 1);
     pl.bk.fcount = ar.take<uint64_t>((size_t)EQ_FINE * pl.bk.nb_cap);
     pl.bk.gfirst = ar.take<uint32_t>(pl.bk.nb_cap);
     pl.pass_elems = ar.take<uint64_t>(kMaxPasses);
@@ -366,6 +379,7 @@ struct SortOpts {
     bool speculate = false;       // try the bucket split without its count pass first (slots carved from `oth`)
     uint32_t* slot_stats = nullptr;   // [2] host counters: splits done with slots / redone with the count pass
     bool seg_ends = false;        // the segments sit in fixed-capacity regions: their ends are s.seg_end (direct path, level B)
+    uint32_t sub = 1;             // > 1: every `sub` consecutive segments are sub-streams of one parent and share its buckets
     const uint64_t* in_key = nullptr;   // non-null: the elements are read from these arrays (indexed like the segments)
     const void* in_sa = nullptr;        //   instead of `cur`, which then only receives results
     const void* runs = nullptr;   // RunSrc<idx_t>*: the segments are partitions still spread over the sorted subarrays in
@@ -409,16 +423,16 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
     uint32_t slot_cap = 0;                           // != 0: the tile sort's input sits in fixed-capacity slots
     uint64_t* slot_key = nullptr;
     idx_t* slot_sa = nullptr;
-    if (o.bk && max_len > TILE_E) {
+    if (o.bk && (max_len > TILE_E || o.seg_ends)) {      // segments in regions are always bucketed: results are written compactly
         const BucketBufs& bk = *o.bk;
         const SegDesc psd = s.desc();
         const uint64_t* s_end = o.seg_ends ? (const uint64_t*)s.seg_end : (const uint64_t*)nullptr;
         CAPS_LAUNCH(bucket_plan_kernel, (s.G + 255) / 256, 256, be, (const uint64_t*)s.seg_start, s_end, s.G, o.range_mode, o.pkey, o.part_off,
-                    o.part_total ? o.part_total : s.G, 1u, 1u,
+                    o.part_total ? o.part_total : s.G, 1u, 1u, o.sub,
                     bk.params, bk.segB);
         CAPS_LAUNCH(scan_sizes_kernel, 1, 1024, be, (const uint64_t*)bk.segB, s.G, bk.bstart);
         CAPS_LAUNCH(bucket_ranges_kernel, (bk.nb_cap + 255) / 256, 256, be, (const uint64_t*)bk.bstart, s.G,
-                    (const BucketParams*)bk.params, o.pkey, o.range_mode, o.part_off, o.part_total ? o.part_total : s.G,
+                    (const BucketParams*)bk.params, o.pkey, o.range_mode, o.part_off, o.part_total ? o.part_total : s.G, o.sub,
                     bk.tile_map, (const BucketParams*)nullptr, (const uint32_t*)nullptr);
         seg_map = bk.tile_map;
         mark("bucket plan");
@@ -437,7 +451,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
 #define CAPS_SCATTER_LAUNCH(SRC_, MAP_, ikey, isa)                                                                          \
             CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, SRC_, MAP_>), n_tiles, TILE_NT, be, psd, P, n_words, tbase, ikey, isa, rsrc, \
                         (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, sub_start, (uint64_t)cap, static_cast<idx_t*>(bk.cursor),       \
-                        okey, osa, fbps, gfirst, (const uint64_t*)nullptr)
+                        okey, osa, fbps, gfirst, (const uint64_t*)nullptr, (const uint16_t*)nullptr, (const uint32_t*)nullptr, 1u)
             const uint64_t* nokey = nullptr;
             const idx_t* nosa = nullptr;
             if (from_text) { if (grouped) CAPS_SCATTER_LAUNCH(SRC_TEXT, MAP_GROUPED, nokey, nosa); else CAPS_SCATTER_LAUNCH(SRC_TEXT, MAP_LINEAR, nokey, nosa); }
@@ -491,7 +505,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
             uint64_t* ccount = bk.count;
             if (equalise) {
                 CAPS_LAUNCH(bucket_plan_kernel, (s.G + 255) / 256, 256, be, (const uint64_t*)s.seg_start, s_end, s.G, o.range_mode, o.pkey, o.part_off,
-                            o.part_total ? o.part_total : s.G, 1u, EQ_FINE, bk.fparams, bk.fsegB);
+                            o.part_total ? o.part_total : s.G, 1u, EQ_FINE, o.sub, bk.fparams, bk.fsegB);
                 CAPS_LAUNCH(scan_sizes_kernel, 1, 1024, be, (const uint64_t*)bk.fsegB, s.G, bk.fstart);
                 be.memset(bk.fcount, 0, (size_t)EQ_FINE * bk.nb_cap * sizeof(uint64_t));
                 cparams = bk.fparams;
@@ -514,7 +528,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
                 CAPS_LAUNCH(bucket_group_kernel, s.G < 16384 ? (s.G ? s.G : 1) : 16384, 256, be, s.G, (const uint64_t*)bk.segB, (const uint64_t*)bk.bstart,
                             (const uint64_t*)bk.fsegB, (const uint64_t*)bk.fstart, (const uint64_t*)bk.fcount, bk.count, bk.gfirst);
                 CAPS_LAUNCH(bucket_ranges_kernel, (bk.nb_cap + 255) / 256, 256, be, (const uint64_t*)bk.bstart, s.G,
-                            (const BucketParams*)bk.params, o.pkey, o.range_mode, o.part_off, o.part_total ? o.part_total : s.G,
+                            (const BucketParams*)bk.params, o.pkey, o.range_mode, o.part_off, o.part_total ? o.part_total : s.G, o.sub,
                             bk.tile_map, (const BucketParams*)bk.fparams, (const uint32_t*)bk.gfirst);
             }
             BackendEvent c1 = be.record();
@@ -820,7 +834,10 @@ private:
         *PG = *K1 = 0;
         if (p < 2 || n < 32ull * TILE_E || m < 64 || m > (1ull << 31)) return CAPS_SA_FB_SHAPE;
         const double group_max = 0.55 * (double)BUCKET_LDS * (double)BUCKET_TARGET;
+        // (measured at C3, K1 = 500 / 1000 / 1400 / 2000: 50.0 / 49.4 / 49.7 / 50.3 ms per build -- flat; the square root it is)
         double want = std::sqrt((double)n / (double)BUCKET_TARGET);
+        if (const char* k1 = std::getenv("CAPS_SA_DIRECT_K1")) { if (std::atof(k1) >= 2.0) want = std::atof(k1); }   // measurement
+        if (want > (double)BUCKET_LDS) want = (double)BUCKET_LDS;
         if ((double)n / group_max > want) want = (double)n / group_max;
         if (want < 2.0) want = 2.0;
         if (want > (double)BUCKET_LDS) return CAPS_SA_FB_SHAPE;
@@ -843,7 +860,7 @@ private:
     // Returns false (nothing of the result written) when the keys cannot balance the groups: two pivots with one key
     // or an overflowing group -- long repeats; the samplesort path then does the build.
     template <int BITS>
-    bool run_direct(idx_t* dSA, idx_t* dLCP, uint32_t PG, uint32_t K1)
+    bool run_direct(idx_t* dSA, idx_t* dLCP, uint32_t PG, uint32_t K1, BackendEvent e1)
     {
         const uint64_t n = pl_.n, m = pl_.m;
         const uint32_t p = pl_.p;
@@ -863,53 +880,66 @@ private:
         be_.memset(pl_.dstat, 0, 4 * sizeof(uint64_t));
         uint32_t* dflag = reinterpret_cast<uint32_t*>(pl_.dstat + 2);
         CAPS_LAUNCH(group_keys_kernel, (p + 255) / 256, 256, be_, (const uint64_t*)pl_.pkey, p, PG, K1, pl_.gkey, dflag);
+        CAPS_LAUNCH(split_lut_kernel, (SPLIT_LUT_CELLS + 256) / 256, 256, be_, (const uint64_t*)pl_.gkey, K1 - 1, pl_.glut, dflag + 1);
         e3_ = be_.record();
 
-        // ---- level A (a9 without a8): the text -> K1 groups, each in its own region of buffer A
+        // ---- level A (a9 without a8): the text -> K1 groups, each as SUB sub-streams in their own regions of buffer A
         const ElemBuf<idx_t>& A = pl_.A;
-        uint64_t capA = A.region_bytes / ((sizeof(uint64_t) + sizeof(idx_t)) * (uint64_t)K1);
+        const uint32_t n_tilesA = tiles_of(n);
+        const char* sub_env = std::getenv("CAPS_SA_DIRECT_SUB");          // measurement: 1 = one stream per group
+        // sub-streams only when each gets enough tiles to be of even size (a stream that outgrows its region voids the attempt)
+        uint32_t SUB = (n + GA_E - 1) / GA_E >= 32ull * DIRECT_SUB ? DIRECT_SUB : 1u;
+        if (sub_env && std::atoi(sub_env) >= 1 && (uint32_t)std::atoi(sub_env) <= DIRECT_SUB) SUB = (uint32_t)std::atoi(sub_env);
+        const uint32_t n_streams = K1 * SUB;
+        uint64_t capA = A.region_bytes / ((sizeof(uint64_t) + sizeof(idx_t)) * (uint64_t)n_streams);
         const uint64_t idx_max = (uint64_t)std::numeric_limits<idx_t>::max() - TILE_E;
-        if (capA > idx_max / K1) capA = idx_max / K1;                   // region offsets are idx_t in the scatter
+        if (capA > idx_max / n_streams) capA = idx_max / n_streams;     // region offsets are idx_t in the scatter
         uint64_t* a_key = A.key;
-        idx_t* a_sa = reinterpret_cast<idx_t*>(reinterpret_cast<char*>(A.key) + (uint64_t)K1 * capA * sizeof(uint64_t));
+        idx_t* a_sa = reinterpret_cast<idx_t*>(reinterpret_cast<char*>(A.key) + (uint64_t)n_streams * capA * sizeof(uint64_t));
         CAPS_LAUNCH(uniform_segments_kernel, 1, 256, be_, pl_.seg1.seg_start, 1u, n, n);
         SegBufs whole = pl_.seg1;
         whole.G = 1;
-        const uint32_t n_tilesA = tiles_of(n);
         prepare_segments(whole, n_tilesA);
         BucketParams one = make_bucket_params(0, ~0ull, K1);            // only B is used by MAP_SPLIT
         const uint64_t b01[2] = {0, K1};
         be_.h2d(pl_.bk.params, &one, sizeof one);
         be_.h2d(pl_.bk.bstart, b01, sizeof b01);
-        be_.memset(pl_.bk.cursor, 0, (size_t)K1 * sizeof(idx_t));
+        be_.memset(pl_.dcur, 0, (size_t)n_streams * sizeof(idx_t));
+        // CAPS_SA_LEVEL_A=tile: the same distribution by bucket_scatter_kernel<SRC_TEXT, MAP_SPLIT> on TILE_E positions (cross-check)
+        const char* la = std::getenv("CAPS_SA_LEVEL_A");
+        const bool big_tiles = !(la && std::string(la) == "tile");
         {
             BackendEvent s0 = be_.record();
-            CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, SRC_TEXT, MAP_SPLIT>), n_tilesA, TILE_NT, be_, whole.desc(), (const uint32_t*)pl_.P,
-                        packed_words(n, BITS), (uint64_t)0, (const uint64_t*)nullptr, (const idx_t*)nullptr, RunSrc<idx_t>(),
-                        (const BucketParams*)pl_.bk.params, (const uint64_t*)pl_.bk.bstart, (const uint64_t*)nullptr, capA,
-                        static_cast<idx_t*>(pl_.bk.cursor), a_key, a_sa, (const BucketParams*)nullptr, (const uint32_t*)nullptr,
-                        (const uint64_t*)pl_.gkey);
+            if (big_tiles)
+                CAPS_LAUNCH((group_scatter_kernel<idx_t, BITS>), (uint32_t)((n + GA_E - 1) / GA_E), TILE_NT, be_, (const uint32_t*)pl_.P,
+                            packed_words(n, BITS), (uint64_t)0, n, (const uint64_t*)pl_.gkey, K1, (const uint16_t*)pl_.glut,
+                            (const uint32_t*)(dflag + 1), SUB, capA, pl_.dcur, a_key, a_sa);
+            else
+                CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, SRC_TEXT, MAP_SPLIT>), n_tilesA, TILE_NT, be_, whole.desc(), (const uint32_t*)pl_.P,
+                            packed_words(n, BITS), (uint64_t)0, (const uint64_t*)nullptr, (const idx_t*)nullptr, RunSrc<idx_t>(),
+                            (const BucketParams*)pl_.bk.params, (const uint64_t*)pl_.bk.bstart, (const uint64_t*)nullptr, capA,
+                            pl_.dcur, a_key, a_sa, (const BucketParams*)nullptr, (const uint32_t*)nullptr,
+                            (const uint64_t*)pl_.gkey, (const uint16_t*)pl_.glut, (const uint32_t*)(dflag + 1), SUB);
             BackendEvent s1 = be_.record();
             scatter_clock_.spans.push_back({s0, s1});
             scatter_clock_.elems.push_back(n);
         }
         SegBufs groups = pl_.seg2;
-        groups.G = K1;
-        CAPS_LAUNCH((slot_segments_kernel<idx_t>), (K1 + 256) / 256, 256, be_, (const idx_t*)static_cast<idx_t*>(pl_.bk.cursor), K1, capA,
+        groups.G = n_streams;
+        CAPS_LAUNCH((slot_segments_kernel<idx_t>), (n_streams + 256) / 256, 256, be_, (const idx_t*)pl_.dcur, K1, SUB, big_tiles ? 1u : 0u, capA,
                     groups.seg_start, groups.seg_end, pl_.dstat);
-        ::caps::prepare_segments(be_, groups, n / TILE_E + K1 + 1, nullptr, nullptr, true);
+        ::caps::prepare_segments(be_, groups, n / TILE_E + n_streams + 1, nullptr, nullptr, true);
         uint64_t out2[2], dstat[4];
         be_.d2h(out2, groups.out2, sizeof out2);
         be_.d2h(dstat, pl_.dstat, sizeof dstat);
-        be_.sync();                                   // out2 = {#tiles, largest group (clamped to its region)}
+        be_.sync();                                   // out2 = {#tiles, largest sub-stream (clamped to its region)}
         direct_groups_ = K1;
         direct_max_group_ = dstat[1] ? dstat[1] : out2[1];
         if ((uint32_t)dstat[2] != 0) { path_fallback_ = CAPS_SA_FB_PIVOT_TIES; return false; }
         if (dstat[1] != 0 || dstat[0] != n) { path_fallback_ = CAPS_SA_FB_GROUP_OVERFLOW; return false; }
-        if (out2[1] <= TILE_E) { path_fallback_ = CAPS_SA_FB_SHAPE; return false; }
         const uint32_t n_tiles2 = (uint32_t)out2[0];
         max_part_ = out2[1];
-        e2_ = e3_;                                    // no sort_subarrays, no locate_pivots
+        e2_ = e1;                                     // no sort_subarrays, no locate_pivots
         e4_ = e3_;
         e5_ = be_.record();
 
@@ -921,6 +951,7 @@ private:
         o2.range_mode = 1;                            // group g holds the keys in (gkey[g-1], gkey[g]]
         o2.pkey = pl_.gkey;
         o2.part_total = K1;
+        o2.sub = SUB;
         o2.seg_ends = true;
         o2.in_key = a_key;
         o2.in_sa = a_sa;
@@ -963,7 +994,7 @@ private:
             if (force && std::string(force) == "classic") path_fallback_ = CAPS_SA_FB_FORCED;
             else if (be_.long_runs) path_fallback_ = CAPS_SA_FB_LONG_RUNS;
             else path_fallback_ = (uint32_t)direct_shape(n, p, pl_.m, &PG, &K1);
-            if (path_fallback_ == CAPS_SA_FB_NONE && run_direct<BITS>(dSA, dLCP, PG, K1)) path_direct_ = 1;
+            if (path_fallback_ == CAPS_SA_FB_NONE && run_direct<BITS>(dSA, dLCP, PG, K1, e1)) path_direct_ = 1;
             else {
                 // a direct attempt that gave up has written nothing of the result; its kernel-clock entries stay (it cost them)
                 run_classic<BITS>(dSA, dLCP);
