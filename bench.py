@@ -9,6 +9,9 @@ in HBM): the interval the reference prints as "Constructed the suffix array"
 (src/Suffix_Array.cpp:469,492-493).  Default workload = the configuration the metric is
 quoted on, C3: 3,000,000,000 random bases + the trailing newline the CLI remaps to 'C'
 (src/main.cpp:61-70), 32-bit indices, 8000 subproblems.  Prints ONE JSON line (rank 0).
+
+The result of the LAST timed step is always checked by the exact device verifier
+(permutation + adjacent order + exact LCP on the raw bytes): `verify_errors` in the line.
 """
 import argparse
 import json
@@ -17,24 +20,42 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for _p in (ROOT, os.path.join(ROOT, "oracle")):
+for _p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 WORKLOADS = {
-    # name: (bases, description)
-    "c3": (3_000_000_000, "C3: 3e9 random DNA bases + remapped trailing newline, u32 indices, p=8000"),
-    "c2": (268_435_456, "C2: 256 Mi random DNA bases + remapped trailing newline, u32 indices, p=8000"),
+    # name: (bases, kind, description)
+    "c3": (3_000_000_000, "uniform", "C3: 3e9 random DNA bases + remapped trailing newline, u32 indices, p=8000"),
+    "c2": (268_435_456, "uniform", "C2: 256 Mi random DNA bases + remapped trailing newline, u32 indices, p=8000"),
+    # GRCh38 is not available offline: order-5 Markov chain with Dirichlet(0.5) transitions + 2 % planted mutated
+    # repeats (tools/genome_like.py, seeded), and the same with N-block stand-ins (the CLI maps N to G: src/main.cpp:61-68)
+    "g3": (3_000_000_000, "genome", "genome-like (tools/genome_like.py seed 7): 3e9 bases, u32 indices, p=8000"),
+    "g2": (268_435_456, "genome", "genome-like (tools/genome_like.py seed 7): 256 Mi bases, u32 indices, p=8000"),
+    "g3n": (3_000_000_000, "genome+n", "genome-like + single-letter blocks (1 x 2e6, 5 x 5e5, 100 x 5e4): 3e9 bases, u32, p=8000"),
 }
 
 
-def make_text(torch, n_bases, seed, device):
-    """i.i.d. uniform ACGT on the device, plus the CLI's remapped trailing newline ('C')."""
+def make_text(torch, n_bases, seed, device, kind="uniform"):
+    """The workload's text on the device, plus the CLI's remapped trailing newline ('C')."""
+    n = n_bases + 1
+    if kind.startswith("genome"):
+        from genome_like import markov_dna
+        T = torch.empty(n, dtype=torch.uint8, device=device)
+        T[:n_bases] = markov_dna(n_bases, seed=7, device=device)
+        if kind == "genome+n":
+            g = torch.Generator(device=device)
+            g.manual_seed(99)
+            for ln, cnt in ((2_000_000, 1), (500_000, 5), (50_000, 100)):
+                if ln * 4 < n_bases:
+                    for a in torch.randint(0, n_bases - ln, (cnt,), device=device, generator=g).tolist():
+                        T[a:a + ln] = ord("G")
+        T[n - 1] = ord("C")
+        return T
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
-    n = n_bases + 1
     T = torch.empty(n, dtype=torch.uint8, device=device)
     step = 1 << 28
     for o in range(0, n_bases, step):
@@ -44,7 +65,7 @@ def make_text(torch, n_bases, seed, device):
     return T
 
 
-def cpu_baseline(T_dev, n_sample, p):
+def cpu_baseline(T_dev, n_sample, p, n_full):
     """The oracle (C restatement of the reference algorithm: kind 'port') timed on this host's
     cores on a bounded sample of the same text."""
     import oracle as O
@@ -53,17 +74,61 @@ def cpu_baseline(T_dev, n_sample, p):
     t0 = time.time()
     O.build_sa_lcp(T, p=p, timings=tm)
     wall = time.time() - t0
+    rate = n_sample / tm["total"]
     return {
-        "value": n_sample / tm["total"],
+        "value": rate,
         "unit": "suffixes/s",
         "cores": int(tm["threads"]),
         "kind": "port",
-        "sample": f"first {n_sample} chars of the same text, p={p}, oracle construct() interval "
-                  f"{tm['total']:.2f} s (wall {wall:.2f} s), host cpus={os.cpu_count()}",
+        "seconds": tm["total"],
+        "sample": f"first {n_sample} chars of the same text, p={p}: oracle construct() interval {tm['total']:.2f} s "
+                  f"(wall {wall:.2f} s) on {int(tm['threads'])} threads of this host (cpus={os.cpu_count()}); at that rate "
+                  f"the full {n_full}-char text would take {n_full / rate:.0f} s (an underestimate: merge depth grows with n)",
     }
 
 
-def main():
+def roofline(kernels, w, traffic_key):
+    """kernels: {family: (ms summed over its launches, launches, elements summed)} over the timed steps.
+    Every family is one streaming pass over the suffixes; algorithmic bytes = 4w per suffix (read + write of an SA- and
+    an LCP-sized payload: SURVEY 8d's per-pass figure).  The dominant (largest summed time) family is the headline;
+    all of them are listed."""
+    moved = {                               # what a pass really moves per suffix (64-bit keys travel with the indices)
+        "level_a_scatter": 0.25 + (8 + w),                       # packed text in, (key, sa) out
+        "level_b_scatter": 2 * (8 + w),                          # (key, sa) in and out
+        "bucket_scatter_kernel": 2 * (8 + w),
+        "tile_sort_kernel": (8 + w) + 2 * w,                     # (key, sa) in, SA + LCP out
+        "merge_pass_kernel": 2 * (8 + w),
+    }
+    traffic = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            traffic = json.load(f).get(traffic_key, {})
+    except OSError:
+        pass
+    rows = {}
+    for name, (ms, launches, elems) in kernels.items():
+        if not launches or ms <= 0:
+            continue
+        avg_ms = ms / launches
+        alg = 4 * w * (elems / launches)
+        ach = alg / (avg_ms * 1e-3) / 1e9
+        rows[name] = {"avg_launch_ms": avg_ms, "launches": launches, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
+                      "algorithmic_bytes_per_launch": alg,
+                      "moved_bytes_per_launch_incl_keys": moved.get(name, 0) * (elems / launches),
+                      "traffic": (traffic.get(name) or {}).get("traffic_bytes_per_launch")}
+    if not rows:
+        return None
+    dom = max(rows, key=lambda k: rows[k]["avg_launch_ms"] * rows[k]["launches"])
+    d = rows[dom]
+    return {"bound": "hbm", "kernel": dom, "achieved": d["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac"],
+            "traffic": d["traffic"], "avg_launch_ms": d["avg_launch_ms"],
+            "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
+            "moved_bytes_per_launch_incl_keys": d["moved_bytes_per_launch_incl_keys"],
+            "traffic_source": "profiles/traffic.json (rocprofv3 PMC passes of this workload, FETCH_SIZE x2 + WRITE_SIZE)",
+            "kernels": rows}
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -72,10 +137,16 @@ def main():
     ap.add_argument("--bases", type=int, default=0, help="override the number of bases (debugging)")
     ap.add_argument("--p", type=int, default=8000)
     ap.add_argument("--seed", type=int, default=42)
-    ap.add_argument("--cpu-sample", type=int, default=16 * 1024 * 1024 + 1)
+    ap.add_argument("--cpu-sample", type=int, default=256 * 1024 * 1024 + 1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--verify", action="store_true", help="run the device verifier on the last result")
-    args = ap.parse_args()
+    ap.add_argument("--no-verify", action="store_true", help="skip the device verifier after the timed steps")
+    ap.add_argument("--verify", action="store_true", help="(default; kept for old command lines)")
+    ap.add_argument("--host-path", action="store_true", help="also time the host-buffer entry point (PCIe inclusive)")
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
 
     import torch  # first: the HIP runtime of this process is torch's
     import caps_sa_amd
@@ -98,12 +169,12 @@ def main():
     dev = torch.device("cuda", local_rank)
     L = caps_sa_amd.lib()
 
-    n_bases, desc = WORKLOADS[args.workload]
+    n_bases, kind, desc = WORKLOADS[args.workload]
     if args.bases:
-        n_bases, desc = args.bases, f"custom: {args.bases} random DNA bases + remapped newline, u32, p={args.p}"
+        n_bases, desc = args.bases, f"custom: {args.bases} bases of kind {kind} + remapped newline, p={args.p}"
     n = n_bases + 1
     idx_bits = 32 if n <= 0xFFFFFFFF else 64
-    T = make_text(torch, n_bases, args.seed, dev)
+    T = make_text(torch, n_bases, args.seed, dev, kind)
     dt = torch.int32 if idx_bits == 32 else torch.int64
     SA = torch.empty(n, dtype=dt, device=dev)
     LCP = torch.empty(n, dtype=dt, device=dev)
@@ -126,43 +197,25 @@ def main():
     elapsed = time.perf_counter() - t0
     ms_per_step = 1e3 * elapsed / args.steps
     value = n / (elapsed / args.steps)
+    verify_errors = None if args.no_verify else L.verify_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr(), idx_bits=idx_bits)
 
-    # Roofline of the DOMINANT kernel family of the timed steps (HIP events on the build's stream
-    # around every launch, summed in caps_sa_stats).  Every candidate is one streaming pass over
-    # the suffixes; its algorithmic bytes are 4w per suffix (read + write of SA and LCP-sized
-    # payload: SURVEY 8d's per-pass figure).  What the kernel really moves (64-bit keys travel
-    # with the indices) is reported next to it.
+    # kernel families of the timed steps (HIP events on the build's stream around every launch, summed in caps_sa_stats)
     w = idx_bits // 8
-    fams = {
-        "tile_sort_kernel": ("tile_sort_ms", "tile_sort_launches", "tile_sort_elems", 2 * (8 + w) + w / 2),
-        "merge_pass_kernel": ("merge_pass_ms", "merge_pass_launches", "merge_pass_elems", 2 * (8 + w)),
-        "bucket_scatter_kernel": ("bucket_scatter_ms", "bucket_scatter_launches", "bucket_scatter_elems", 1.5 * (8 + w)),
-    }
-    tot = {k: sum(s[v[0]] for s in stats) for k, v in fams.items()}
-    dom = max(tot, key=tot.get)
-    f_ms, f_l, f_e, moved_per_elem = fams[dom]
-    launches = sum(s[f_l] for s in stats)
-    ms = sum(s[f_ms] for s in stats)
-    elems = sum(s[f_e] for s in stats)
-    roof = None
-    if launches and ms > 0:
-        avg_ms = ms / launches
-        alg_bytes = 4 * w * (elems / launches)
-        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-        # HBM bytes per launch measured with rocprofv3 PMC passes (cannot be collected inside this
-        # process): taken from the committed profile of the same workload, if there is one
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-                traffic = json.load(f).get(args.workload if not args.bases else "", {}).get(dom, {}).get("traffic_bytes_per_launch")
-        except OSError:
-            pass
-        roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "avg_launch_ms": avg_ms, "launches_per_step": launches / args.steps,
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "moved_bytes_per_launch_incl_keys": moved_per_elem * (elems / launches),
-                "kernel_ms_per_step": {k: v / args.steps for k, v in tot.items()}}
+    direct = all(s["path_direct"] for s in stats)
+    fams = {}
+    if direct:      # the first scatter launch of a direct build is level A (text -> groups), the second level B
+        la = sum(s["level_a_ms"] for s in stats)
+        fams["level_a_scatter"] = (la, len(stats), n * len(stats))
+        lb = sum(s["bucket_scatter_ms"] - s["level_a_ms"] for s in stats)
+        fams["level_b_scatter"] = (lb, sum(s["bucket_scatter_launches"] - 1 for s in stats), n * len(stats))
+    else:
+        fams["bucket_scatter_kernel"] = (sum(s["bucket_scatter_ms"] for s in stats), sum(s["bucket_scatter_launches"] for s in stats),
+                                         sum(s["bucket_scatter_elems"] for s in stats))
+    fams["tile_sort_kernel"] = (sum(s["tile_sort_ms"] for s in stats), sum(s["tile_sort_launches"] for s in stats),
+                                sum(s["tile_sort_elems"] for s in stats))
+    fams["merge_pass_kernel"] = (sum(s["merge_pass_ms"] for s in stats), sum(s["merge_pass_launches"] for s in stats),
+                                 sum(s["merge_pass_elems"] for s in stats))
+    roof = roofline(fams, w, args.workload if not args.bases else "")
     last = stats[-1]
     phases = {k: last[k] for k in ("ms_total", "ms_pack", "ms_sort_subarrays", "ms_select_pivots", "ms_locate_pivots",
                                    "ms_partition", "ms_merge_partitions", "ms_boundary_lcp", "ms_output",
@@ -172,18 +225,44 @@ def main():
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": f"u{idx_bits}", "data": "synthetic",
         "config": {"workload": desc, "n": n, "subproblems": last["p_eff"], "bits_per_char": last["bits_per_char"],
+                   "construction": "direct (pivots from the text, one scatter into groups, per-group sort)" if direct
+                                   else f"samplesort (fallback reason {last['path_fallback']})",
+                   "groups": last["direct_groups"], "slot_splits": [last["slot_splits"], last["slot_splits_redone"]],
                    "merge_passes": [last["merge_passes_phase1"], last["merge_passes_phase2"]],
                    "max_partition": last["max_partition"], "workspace": "preallocated",
                    "workspace_gb": ws_bytes / 1e9, "parallelism": "1 GPU"},
         "phases_ms": phases,
+        "bytes_per_suffix": {"compulsory_floor": 1 + 2 * w,
+                             "moved_by_the_big_kernels": (sum(r["moved_bytes_per_launch_incl_keys"] * r["launches"]
+                                                              for r in roof["kernels"].values()) / (n * len(stats))) if roof else None},
         "roofline": roof,
+        "verify_errors": verify_errors,
     }
-    if args.verify:
-        out["verify_errors"] = L.verify_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr(), idx_bits=idx_bits)
+    if args.host_path:
+        out["pcie_inclusive"] = host_path(L, T, n, args.p, idx_bits)
     if not args.no_cpu_baseline:
         del ws
-        out["cpu_baseline"] = cpu_baseline(T, min(args.cpu_sample, n), args.p)
+        out["cpu_baseline"] = cpu_baseline(T, min(args.cpu_sample, n), args.p, n)
     print(json.dumps(out))
+
+
+def host_path(L, T_dev, n, p, idx_bits):
+    """What construct() callers see: caps_sa_hip_build_* on host buffers (H2D of T, build, D2H of SA and LCP).
+    Never `value`."""
+    import numpy as np
+    T = T_dev.cpu().numpy()
+    res = {}
+    for label, pinned in (("pageable", False), ("pinned", True)):
+        times = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            SA, LCP, st = L.build(T, p=p, idx_bits=idx_bits, pinned=pinned)
+            times.append(1e3 * (time.perf_counter() - t0))
+            del SA, LCP
+        res[label] = {"first_call_ms": times[0], "steady_ms": min(times[1:]), "ms_h2d": st["ms_h2d"], "ms_d2h": st["ms_d2h"],
+                      "ms_build": st["ms_total"]}
+    L.release_cache()
+    return res
 
 
 if __name__ == "__main__":

@@ -57,6 +57,7 @@ class Stats(ctypes.Structure):
         ("direct_groups", ctypes.c_uint32),
         ("direct_reserved_", ctypes.c_uint32),
         ("direct_max_group", ctypes.c_uint64),
+        ("level_a_ms", ctypes.c_double),
     ]
 
     def as_dict(self) -> dict:
@@ -78,6 +79,14 @@ class ShardInfo(ctypes.Structure):
         ("capacity", ctypes.c_uint64),
         ("ms_phase1", ctypes.c_double), ("ms_pivots", ctypes.c_double), ("ms_collate", ctypes.c_double),
         ("ms_phase2", ctypes.c_double),
+        ("direct_fallback", ctypes.c_uint32), ("direct_groups", ctypes.c_uint32), ("direct_sub", ctypes.c_uint32),
+        ("n_streams", ctypes.c_uint32),
+        ("stream_cap", ctypes.c_uint64), ("send_capacity", ctypes.c_uint64),
+        ("ms_scatter", ctypes.c_double), ("ms_sort", ctypes.c_double),
+        ("ms_level_a", ctypes.c_double), ("ms_level_b", ctypes.c_double), ("ms_tile_sort", ctypes.c_double),
+        ("ms_merge_passes", ctypes.c_double),
+        ("level_a_elems", ctypes.c_uint64),
+        ("slot_splits", ctypes.c_uint32), ("slot_splits_redone", ctypes.c_uint32),
     ]
 
     def as_dict(self) -> dict:
@@ -85,7 +94,7 @@ class ShardInfo(ctypes.Structure):
 
 
 SHARD_EXPORTS = ["shard_create", "shard_destroy", "shard_info", "shard_phase1", "shard_pivots", "shard_collate",
-                 "shard_phase2", "shard_last_sa", "shard_fix_first_lcp"]
+                 "shard_phase2", "shard_last_sa", "shard_fix_first_lcp", "shard_scatter", "shard_plan", "shard_sort"]
 
 EXPORTS = ["device_count", "last_error", "version", "workspace_bytes", "release_cache", "host_alloc", "host_free"] + SHARD_EXPORTS + [
     f"{name}_{sfx}"
@@ -154,6 +163,12 @@ class CapsLib:
         f("shard_collate").argtypes = [_vp, _vp, _vp, _vp, _vp, _vp]
         f("shard_phase2").restype = _ci
         f("shard_phase2").argtypes = [_vp, _vp, _vp, _vp, _vp]
+        f("shard_scatter").restype = _ci
+        f("shard_scatter").argtypes = [_vp, _vp, _vp, _vp]
+        f("shard_plan").restype = _ci
+        f("shard_plan").argtypes = [_vp, _vp, _vp, _vp]
+        f("shard_sort").restype = _ci
+        f("shard_sort").argtypes = [_vp, _vp, _vp, _vp, _vp]
         f("shard_last_sa").restype = _ci
         f("shard_last_sa").argtypes = [_vp, ctypes.POINTER(_u64)]
         f("shard_fix_first_lcp").restype = _ci
@@ -326,6 +341,23 @@ class Shard:
 
     def phase2(self, d_recv_keys: int, d_recv_sa: int, dSA: int, dLCP: int):
         self.lib._check(self.lib._f("shard_phase2")(self.h, d_recv_keys or None, d_recv_sa or None, dSA or None, dLCP or None))
+
+    def scatter(self, d_send_keys: int, d_send_sa: int, d_report: int):
+        self.lib._check(self.lib._f("shard_scatter")(self.h, d_send_keys, d_send_sa, d_report))
+
+    def plan(self, all_reports: np.ndarray):
+        """-> (fallback code, send_counts, recv_counts); code 0: go on with the direct path."""
+        all_reports = np.ascontiguousarray(all_reports, dtype=np.uint64)
+        world = all_reports.shape[0]
+        sc = np.zeros(world, dtype=np.uint64)
+        rc = np.zeros(world, dtype=np.uint64)
+        code = self.lib._f("shard_plan")(self.h, all_reports.ctypes.data, sc.ctypes.data, rc.ctypes.data)
+        if code < 0:
+            self.lib._check(code)
+        return code, sc, rc
+
+    def sort_owned(self, d_recv_keys: int, d_recv_sa: int, dSA: int, dLCP: int):
+        self.lib._check(self.lib._f("shard_sort")(self.h, d_recv_keys or None, d_recv_sa or None, dSA or None, dLCP or None))
 
     def last_sa(self) -> int:
         v = _u64(0)

@@ -569,6 +569,21 @@ int CAPS_API(shard_phase2)(caps_sa_shard* s, const void* k, const void* a, void*
     if (!s) return caps::fail(CAPS_SA_EINVAL, "null shard");
     return caps::guarded([&]() -> int { s->impl->phase2(k, a, dSA, dLCP); return CAPS_SA_OK; });
 }
+int CAPS_API(shard_scatter)(caps_sa_shard* s, void* k, void* a, void* report)
+{
+    if (!s || !k || !a || !report) return caps::fail(CAPS_SA_EINVAL, "null pointer");
+    return caps::guarded([&]() -> int { s->impl->scatter(k, a, report); return CAPS_SA_OK; });
+}
+int CAPS_API(shard_plan)(caps_sa_shard* s, const uint64_t* all_reports, uint64_t* sc, uint64_t* rc)
+{
+    if (!s || !all_reports || !sc || !rc) return caps::fail(CAPS_SA_EINVAL, "null pointer");
+    return caps::guarded([&]() -> int { return s->impl->plan(all_reports, sc, rc); });
+}
+int CAPS_API(shard_sort)(caps_sa_shard* s, const void* k, const void* a, void* dSA, void* dLCP)
+{
+    if (!s) return caps::fail(CAPS_SA_EINVAL, "null shard");
+    return caps::guarded([&]() -> int { s->impl->sort_owned(k, a, dSA, dLCP); return CAPS_SA_OK; });
+}
 int CAPS_API(shard_last_sa)(caps_sa_shard* s, uint64_t* last_sa)
 {
     if (!s || !last_sa) return caps::fail(CAPS_SA_EINVAL, "null pointer");

@@ -2279,8 +2279,12 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) group_scatter_kernel(KCTX
                                                       uint64_t text_base, uint64_t len, const uint64_t* __restrict__ split, uint32_t K1,
                                                       const uint16_t* __restrict__ split_lut, const uint32_t* __restrict__ split_span,
                                                       uint32_t sub, uint64_t slot_cap, idx_t* __restrict__ cursor,
-                                                      uint64_t* __restrict__ out_key, idx_t* __restrict__ out_sa)
+                                                      uint64_t* __restrict__ out_key, idx_t* __restrict__ out_sa,
+                                                      uint32_t tile_first, uint32_t tile_stride)
 {
+    // Workgroup b takes tile tile_first + b * tile_stride of [text_base, text_base + len): a rank of a sharded build takes
+    // every world-th tile (its share of the text is then a fine-grained interleave, balanced whatever the text's composition
+    // does along its length); one GPU: tile_first = 0, tile_stride = 1.
     constexpr uint32_t CPW = TextTraits<BITS>::CPW;
     constexpr uint32_t WIN = GA_E / CPW + 8;                   // words covering GA_E positions + one key
     const idx_t NO_SLOT = (idx_t)~(idx_t)0;
@@ -2291,7 +2295,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) group_scatter_kernel(KCTX
     SHARED_ARRAY(idx_t, obase, TILE_BINS);
     SHARED_ARRAY(uint32_t, perm, TILE_E);
     TL_DECL(uint32_t, pk, GA_EPT);
-    const uint64_t start = (uint64_t)K_BLOCK_IDX * GA_E;
+    const uint64_t start = ((uint64_t)tile_first + (uint64_t)K_BLOCK_IDX * tile_stride) * GA_E;
     if (start >= len) return;
     const uint32_t cnt = (uint32_t)(len - start < GA_E ? len - start : GA_E);
     const uint32_t sx = sub > 1 ? K_BLOCK_IDX % sub : 0u;
@@ -2386,6 +2390,23 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) group_scatter_kernel(KCTX
             }
         }
         SYNC();
+    }
+}
+
+// Report of a rank's level A for the other ranks (sharded direct path): out[0 .. n_streams) = stream sizes,
+// out[n_streams] = flag word (pivot-key ties), out[n_streams + 1] = size of the largest stream that outgrew its region (0: none).
+template <typename idx_t>
+GLOBAL_FN LAUNCH_BOUNDS(256) stream_report_kernel(KCTX const idx_t* __restrict__ cursor, uint32_t n_streams, uint64_t cap,
+                                                  const uint32_t* __restrict__ flag, uint64_t* __restrict__ out)
+{
+    PAR(tid) {
+        const uint32_t s = K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (s < n_streams) {
+            const uint64_t z = (uint64_t)cursor[s];
+            out[s] = z;
+            if (z > cap) ATOMIC_MAX_U64(&out[n_streams + 1], z);
+        }
+        if (s == n_streams) out[n_streams] = flag[0];
     }
 }
 

@@ -640,6 +640,32 @@ void finalize(Backend& be, const uint32_t* P, uint64_t n, const SortResult<idx_t
                     r.fin);
 }
 
+// Shape of the direct path's two-level distribution: PG consecutive partitions per group, K1 groups.  Level A
+// (text -> groups) and level B (group -> buckets of one tile) should fan out about equally (the runs a tile
+// contributes to a destination are then equally long at both levels), a group must fit the LDS histogram of its
+// bucket split with room for imbalance, and the group table must fit LDS.
+inline int direct_shape(uint64_t n, uint32_t p, uint64_t m, uint32_t* PG, uint32_t* K1)
+{
+    *PG = *K1 = 0;
+    if (p < 2 || n < 32ull * TILE_E || m < 64 || m > (1ull << 31)) return CAPS_SA_FB_SHAPE;
+    const double group_max = 0.9 * (double)BUCKET_LDS * (double)BUCKET_TARGET;   // groups are sample quantiles: +-1.3 % at C3
+    // (measured at C3, K1 = 500 / 1000 / 1400 / 2000: 50.0 / 49.4 / 49.7 / 50.3 ms per build -- flat; the square root it is)
+    double want = std::sqrt((double)n / (double)BUCKET_TARGET);
+    if (const char* k1 = std::getenv("CAPS_SA_DIRECT_K1")) { if (std::atof(k1) >= 2.0) want = std::atof(k1); }   // measurement
+    if (want > (double)BUCKET_LDS) want = (double)BUCKET_LDS;
+    if ((double)n / group_max > want) want = (double)n / group_max;
+    if (want < 2.0) want = 2.0;
+    if (want > (double)BUCKET_LDS) return CAPS_SA_FB_SHAPE;
+    uint32_t pg = (uint32_t)((double)p / want);
+    if (pg < 1) pg = 1;
+    const uint32_t k1 = (p + pg - 1) / pg;
+    if (k1 < 2 || k1 > BUCKET_LDS || (double)n / k1 > group_max || m / k1 < 16) return CAPS_SA_FB_SHAPE;
+    *PG = pg;
+    *K1 = k1;
+    return CAPS_SA_FB_NONE;
+}
+
+
 template <typename idx_t> class Builder {
 public:
     Builder(Backend& be, const Plan<idx_t>& pl) : be_(be), pl_(pl) {}
@@ -672,7 +698,7 @@ private:
     uint32_t slot_stats_[2] = {0, 0};
     // per-build results of the phase sequences below
     uint32_t passes1_ = 0, passes2_ = 0, passesS_ = 0;
-    BackendEvent e2_, e3_, e4_, e5_, e6_, e7_;
+    BackendEvent e2_, e3_, e4_, e5_, e6_, e7_, la0_, la1_;
     uint64_t max_part_ = 0;
     uint32_t path_direct_ = 0, path_fallback_ = 0, direct_groups_ = 0;
     uint64_t direct_max_group_ = 0;
@@ -825,31 +851,6 @@ private:
         e7_ = be_.record();
     }
 
-    // Shape of the direct path's two-level distribution: PG consecutive partitions per group, K1 groups.  Level A
-    // (text -> groups) and level B (group -> buckets of one tile) should fan out about equally (the runs a tile
-    // contributes to a destination are then equally long at both levels), a group must fit the LDS histogram of its
-    // bucket split with room for imbalance, and the group table must fit LDS.
-    static int direct_shape(uint64_t n, uint32_t p, uint64_t m, uint32_t* PG, uint32_t* K1)
-    {
-        *PG = *K1 = 0;
-        if (p < 2 || n < 32ull * TILE_E || m < 64 || m > (1ull << 31)) return CAPS_SA_FB_SHAPE;
-        const double group_max = 0.55 * (double)BUCKET_LDS * (double)BUCKET_TARGET;
-        // (measured at C3, K1 = 500 / 1000 / 1400 / 2000: 50.0 / 49.4 / 49.7 / 50.3 ms per build -- flat; the square root it is)
-        double want = std::sqrt((double)n / (double)BUCKET_TARGET);
-        if (const char* k1 = std::getenv("CAPS_SA_DIRECT_K1")) { if (std::atof(k1) >= 2.0) want = std::atof(k1); }   // measurement
-        if (want > (double)BUCKET_LDS) want = (double)BUCKET_LDS;
-        if ((double)n / group_max > want) want = (double)n / group_max;
-        if (want < 2.0) want = 2.0;
-        if (want > (double)BUCKET_LDS) return CAPS_SA_FB_SHAPE;
-        uint32_t pg = (uint32_t)((double)p / want);
-        if (pg < 1) pg = 1;
-        const uint32_t k1 = (p + pg - 1) / pg;
-        if (k1 < 2 || k1 > BUCKET_LDS || (double)n / k1 > group_max || m / k1 < 16) return CAPS_SA_FB_SHAPE;
-        *PG = pg;
-        *K1 = k1;
-        return CAPS_SA_FB_NONE;
-    }
-
     // ---- the direct path ------------------------------------------------------------------------------------
     // Phase 1 of the samplesort (sort_subarrays) and locate_pivots only serve to find out which partition every
     // suffix belongs to; the order they establish inside the subarrays is discarded when the partitions are sorted.
@@ -913,7 +914,7 @@ private:
             if (big_tiles)
                 CAPS_LAUNCH((group_scatter_kernel<idx_t, BITS>), (uint32_t)((n + GA_E - 1) / GA_E), TILE_NT, be_, (const uint32_t*)pl_.P,
                             packed_words(n, BITS), (uint64_t)0, n, (const uint64_t*)pl_.gkey, K1, (const uint16_t*)pl_.glut,
-                            (const uint32_t*)(dflag + 1), SUB, capA, pl_.dcur, a_key, a_sa);
+                            (const uint32_t*)(dflag + 1), SUB, capA, pl_.dcur, a_key, a_sa, 0u, 1u);
             else
                 CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, SRC_TEXT, MAP_SPLIT>), n_tilesA, TILE_NT, be_, whole.desc(), (const uint32_t*)pl_.P,
                             packed_words(n, BITS), (uint64_t)0, (const uint64_t*)nullptr, (const idx_t*)nullptr, RunSrc<idx_t>(),
@@ -923,6 +924,8 @@ private:
             BackendEvent s1 = be_.record();
             scatter_clock_.spans.push_back({s0, s1});
             scatter_clock_.elems.push_back(n);
+            la0_ = s0;
+            la1_ = s1;
         }
         SegBufs groups = pl_.seg2;
         groups.G = n_streams;
@@ -1040,6 +1043,7 @@ private:
             st->path_fallback = path_fallback_;
             st->direct_groups = direct_groups_;
             st->direct_max_group = direct_max_group_;
+            st->level_a_ms = direct_groups_ ? be_.elapsed_ms(la0_, la1_) : 0.0;
             st->slot_splits = slot_stats_[0];
             st->slot_splits_redone = slot_stats_[1];
             st->merge_pass_elems = 0;                      // elements the timed passes really merged

@@ -17,6 +17,17 @@
 //            contiguous slice [slice_off, slice_off + slice_len) of the global SA / LCP
 //   fix      LCP of the slice's first suffix against the previous rank's last one    [1 idx]
 //
+// That is the samplesort path.  The DIRECT path (pipeline.h, Builder::run_direct) shards more simply, and is what a
+// build takes unless the text forbids it (long repeats: keys alone cannot balance the groups):
+//
+//   scatter  every rank packs the text, draws the SAME samples from it and derives the SAME pivots (nothing to
+//            exchange), then runs level A on every world-th tile of the text: its suffixes go, group by group, into
+//            stream regions of the send buffers; groups are owned by ranks in contiguous ranges (equal counts: groups
+//            are sample quantiles, hence of equal size), so a destination's streams are one contiguous block    [local]
+//   -------- all_gather of the stream sizes (+ flags); all-to-all of the blocks of (key, sa) --------          [exchange]
+//   plan     from all ranks' reports: agree on going on (or falling back), lay out the received streams           [host]
+//   sort_owned  level B + tile sort over the owned groups -> the rank's contiguous slice of SA / LCP            [local]
+//
 // The collectives themselves are issued by the host driver (caps_sa_dist.py) with
 // torch.distributed; this class only runs kernels on the rank's stream.
 #pragma once
@@ -41,6 +52,10 @@ struct ShardBase {
     virtual void phase2(const void* d_recv_keys, const void* d_recv_sa, void* dSA, void* dLCP) = 0;
     virtual uint64_t last_sa() = 0;
     virtual void fix_first_lcp(uint64_t prev_sa, void* dLCP) = 0;
+    // direct path (see Shard)
+    virtual void scatter(void* d_send_keys, void* d_send_sa, void* d_report) = 0;
+    virtual int plan(const uint64_t* all_reports, uint64_t* send_counts, uint64_t* recv_counts) = 0;
+    virtual void sort_owned(const void* d_recv_keys, const void* d_recv_sa, void* dSA, void* dLCP) = 0;
 };
 
 template <typename idx_t> class Shard : public ShardBase {
@@ -59,12 +74,32 @@ public:
         local_n_ = G_ ? (g1_ == p_ ? n : (uint64_t)g1_ * s_) - text_base_ : 0;
         m_local_ = (uint64_t)G_ * ppp_;
         m_total_ = (uint64_t)p_ * ppp_;
+        // direct path: groups, sub-streams, capacity of a stream region (sample quantiles: +-1.3 % at C3, Poisson on top)
+        direct_fb_ = direct_shape(n, p_, m_total_, &PG_, &K1_);
+        if (const char* force = std::getenv("CAPS_SA_PATH")) if (std::string(force) == "classic") direct_fb_ = CAPS_SA_FB_FORCED;
+        const uint64_t ga_tiles = (n + GA_E - 1) / GA_E;
+        my_tiles_ = (uint32_t)(ga_tiles > (uint64_t)rank ? (ga_tiles - rank + world - 1) / world : 0);
+        if (direct_fb_ == CAPS_SA_FB_NONE) {
+            SUB_ = ga_tiles / world >= 32ull * DIRECT_SUB ? DIRECT_SUB : 1u;
+            if (const char* e = std::getenv("CAPS_SA_DIRECT_SUB")) if (std::atoi(e) >= 1 && (uint32_t)std::atoi(e) <= DIRECT_SUB) SUB_ = (uint32_t)std::atoi(e);
+            n_streams_ = K1_ * SUB_;
+            const double mean = (double)n / ((double)n_streams_ * world);
+            capA_ = (uint64_t)(mean * 1.10 + 6.0 * std::sqrt(mean) + 2.0 * GA_E / K1_ + 64.0);
+            capA_ += capA_ & 1;
+            if (n_streams_ * capA_ + TILE_E >= (uint64_t)std::numeric_limits<idx_t>::max()) direct_fb_ = CAPS_SA_FB_SHAPE;
+        }
+        const uint32_t gseg = std::max<uint32_t>(p_, DIRECT_SUB * std::min<uint32_t>(p_, BUCKET_LDS));
         try {
             // Everything is allocated ONCE here (hipMalloc / hipFree of tens of GB cost seconds): the
             // element arrays serve phase 1 (this rank's subarrays) and phase 2 (its partitions), sized
             // for the larger of the two with 25 % slack for the imbalance of the partition ownership.
             const uint64_t share = n / (uint64_t)world + 1;
             cap_ = std::max<uint64_t>(local_n_, share + share / 4 + 16 * TILE_E);
+            if (world == 1) cap_ = local_n_;               // a single rank owns everything: no ownership imbalance to provide for
+            if (direct_fb_ == CAPS_SA_FB_NONE) {           // received streams of the owned groups, gaps included
+                const uint64_t own_max = ((uint64_t)K1_ + world - 1) / world * SUB_ * world * capA_;
+                cap_ = std::max<uint64_t>(cap_, own_max + TILE_E);
+            }
             P_ = get<uint32_t>(text_alloc_words(n));
             present_ = get<uint32_t>(8);
             lut_ = get<uint8_t>(256);
@@ -72,7 +107,13 @@ public:
             B_ = elems(cap_);
             seg1_ = segs(G_ ? G_ : 1, cap_ / TILE_E + p_ + 2);
             seg1_.G = G_;
-            seg2_ = segs(p_, cap_ / TILE_E + p_ + 2);
+            seg2_ = segs(gseg, cap_ / TILE_E + gseg + 2);
+            seg2_.G = p_;
+            seg2_.seg_end = get<uint64_t>((size_t)gseg + 1);
+            gkey_ = get<uint64_t>(p_);
+            glut_ = get<uint16_t>(SPLIT_LUT_CELLS + 2);
+            dcur_ = get<idx_t>(gseg);
+            dstat_ = get<uint64_t>(4);
             SA_ = elems(m_total_);
             SB_ = elems(m_total_);
             segS_ = segs(1, m_total_ / TILE_E + 3);
@@ -83,7 +124,7 @@ public:
             sizes_ = get<uint64_t>(p_);
             partial_ = get<uint64_t>((size_t)PART_CHUNKS * p_);
             lstart_ = get<uint64_t>((size_t)p_ + 1);
-            bk_ = buckets(cap_, p_);
+            bk_ = buckets(cap_, gseg);
             const uint64_t a = bk_.tile_cap + 3, b = m_total_ / TILE_E + 3;
             tdesc_ = get<TileDesc>(a > b ? a : b);
             desc_ = get<uint64_t>((size_t)3 * world * p_ + 3);
@@ -102,6 +143,13 @@ public:
         o->recv_total = recv_total_; o->slice_off = slice_off_; o->capacity = cap_;
         o->part_lo = jlo_; o->part_hi = jhi_;
         o->ms_phase1 = ms_phase1_; o->ms_pivots = ms_pivots_; o->ms_collate = ms_collate_; o->ms_phase2 = ms_phase2_;
+        o->direct_fallback = (uint32_t)direct_fb_; o->direct_groups = K1_; o->direct_sub = SUB_;
+        o->n_streams = n_streams_; o->stream_cap = capA_;
+        o->send_capacity = std::max<uint64_t>(local_n_, direct_fb_ == CAPS_SA_FB_NONE ? (uint64_t)n_streams_ * capA_ : 0);
+        o->ms_scatter = ms_scatter_; o->ms_sort = ms_sort_;
+        o->ms_level_a = ms_level_a_; o->ms_level_b = ms_level_b_ + ms_count_; o->ms_tile_sort = ms_tile_sort_; o->ms_merge_passes = ms_merge_;
+        o->level_a_elems = (uint64_t)my_tiles_ * GA_E < n_ ? (uint64_t)my_tiles_ * GA_E : n_;
+        o->slot_splits = slot_stats_[0]; o->slot_splits_redone = slot_stats_[1];
     }
 
     void phase1(void* d_sample_keys, void* d_sample_sa) override
@@ -208,9 +256,21 @@ public:
                         static_cast<uint64_t*>(d_send_keys), static_cast<idx_t*>(d_send_sa));
         }
 
-        // phase 2 re-uses the phase-1 arrays (dead once the send buffers are filled)
-        if (recv_total_ > cap_)
-            throw std::runtime_error("partition ownership is more imbalanced than the shard's capacity allows");
+        // phase 2 re-uses the phase-1 arrays (dead once the send buffers are filled).  Ownership is by partition midpoint,
+        // so a rank can own up to n / world plus one whole partition: with few partitions per rank that can exceed the
+        // buffers.  Every rank sees the same sizes: all of them fail together (a rank failing alone would leave the
+        // others waiting in the exchange).
+        {
+            const uint64_t share = n_ / (uint64_t)world_ + 1, common_cap = share + share / 4 + 16 * TILE_E;
+            for (int r = 0; r < world_; ++r) {
+                uint64_t own = 0;
+                for (uint32_t j = lo[r]; j < lo[r + 1]; ++j) own += gs[j];
+                if (own > common_cap)
+                    throw std::runtime_error("partition ownership is more imbalanced than the shards' capacity allows (rank " +
+                                             std::to_string(r) + " would own " + std::to_string(own) + " of " + std::to_string(n_) +
+                                             " suffixes): use more subproblems per GPU");
+            }
+        }
         seg2_.G = G2_;
         std::vector<uint64_t> st((size_t)G2_ + 1, 0);
         max_len2_ = 0;
@@ -273,6 +333,111 @@ public:
         be_.release_events();
     }
 
+    // ---- direct path ---------------------------------------------------------------------------------------
+    // d_send_keys: u64[send_capacity], d_send_sa: idx[send_capacity]; d_report: u64[n_streams + 2] (stream_report_kernel)
+    void scatter(void* d_send_keys, void* d_send_sa, void* d_report) override
+    {
+        if (direct_fb_ != CAPS_SA_FB_NONE) throw std::invalid_argument("this shard's shape does not allow the direct path");
+        slot_stats_[0] = slot_stats_[1] = 0;
+        BackendEvent e0 = be_.record();
+        bits_ = prepare_text(be_, dT_, n_, P_, present_, lut_);
+        uint64_t* report = static_cast<uint64_t*>(d_report);
+        be_.memset(report, 0, ((size_t)n_streams_ + 2) * sizeof(uint64_t));
+        be_.memset(dstat_, 0, 4 * sizeof(uint64_t));
+        uint32_t* dflag = reinterpret_cast<uint32_t*>(dstat_ + 2);
+        if (be_.long_runs) {
+            const uint32_t code = CAPS_SA_FB_LONG_RUNS;        // every rank sees the same text: all report the same
+            be_.h2d(dflag, &code, sizeof code);
+        } else if (bits_ == 2) scatter_bits<2>(d_send_keys, d_send_sa, dflag);
+        else scatter_bits<8>(d_send_keys, d_send_sa, dflag);
+        CAPS_LAUNCH((stream_report_kernel<idx_t>), (n_streams_ + 256) / 256, 256, be_, (const idx_t*)dcur_, n_streams_, capA_,
+                    (const uint32_t*)dflag, report);
+        BackendEvent e1 = be_.record();
+        be_.sync();
+        ms_scatter_ = be_.elapsed_ms(e0, e1);
+        ms_level_a_ = be_.long_runs ? 0.0 : be_.elapsed_ms(a0_, a1_);
+        be_.release_events();
+    }
+
+    // all_reports: HOST u64[world][n_streams + 2] (every rank's report).  Returns CAPS_SA_FB_NONE and the exchange's counts
+    // (elements per peer, gaps included), or the reason why every rank must take the samplesort path instead.
+    int plan(const uint64_t* all_reports, uint64_t* send_counts, uint64_t* recv_counts) override
+    {
+        if (direct_fb_ != CAPS_SA_FB_NONE) return direct_fb_;
+        const size_t W = (size_t)n_streams_ + 2;
+        for (int r = 0; r < world_; ++r) {
+            const uint64_t flag = all_reports[r * W + n_streams_], over = all_reports[r * W + n_streams_ + 1];
+            if (flag == CAPS_SA_FB_LONG_RUNS) return CAPS_SA_FB_LONG_RUNS;
+            if (flag != 0) return CAPS_SA_FB_PIVOT_TIES;
+            if (over != 0) return CAPS_SA_FB_GROUP_OVERFLOW;
+        }
+        auto bound = [&](int d) { return (uint32_t)((uint64_t)d * K1_ / world_); };          // rank d owns groups [bound(d), bound(d+1))
+        jlo_ = bound(rank_);
+        jhi_ = bound(rank_ + 1);
+        G2_ = jhi_ - jlo_;
+        for (int d = 0; d < world_; ++d) {
+            send_counts[d] = (uint64_t)(bound(d + 1) - bound(d)) * SUB_ * capA_;
+            recv_counts[d] = (uint64_t)G2_ * SUB_ * capA_;
+        }
+        if ((uint64_t)G2_ * SUB_ * capA_ * world_ > cap_) throw std::runtime_error("receive buffer too small for the owned streams");
+        // size of stream x of group g at rank r: the cursors are stream-major (group_scatter_kernel)
+        auto sz = [&](int r, uint32_t g, uint32_t x) { return all_reports[r * W + (size_t)x * K1_ + g]; };
+        slice_off_ = 0;
+        for (uint32_t g = 0; g < jlo_; ++g)
+            for (int r = 0; r < world_; ++r)
+                for (uint32_t x = 0; x < SUB_; ++x) slice_off_ += sz(r, g, x);
+        // level B's segments: (owned group, source rank, sub-stream), all sub-streams of a group consecutive
+        const uint32_t per_group = (uint32_t)world_ * SUB_;
+        const size_t nseg = (size_t)G2_ * per_group;
+        std::vector<uint64_t> st(nseg + 1, 0), en(nseg + 1, 0);
+        recv_total_ = 0;
+        max_len2_ = 0;
+        n_tiles2_ = 0;
+        const uint64_t block = (uint64_t)G2_ * SUB_ * capA_;                                // elements received from one rank
+        for (uint32_t k = 0; k < G2_; ++k)
+            for (int r = 0; r < world_; ++r)
+                for (uint32_t x = 0; x < SUB_; ++x) {
+                    const size_t s = ((size_t)k * world_ + r) * SUB_ + x;
+                    const uint64_t z = sz(r, jlo_ + k, x);
+                    st[s] = (uint64_t)r * block + ((uint64_t)k * SUB_ + x) * capA_;
+                    en[s] = st[s] + z;
+                    recv_total_ += z;
+                    max_len2_ = z > max_len2_ ? z : max_len2_;
+                    n_tiles2_ += tiles_of(z);
+                }
+        seg2_.G = (uint32_t)nseg;
+        if (nseg) {
+            be_.h2d(seg2_.seg_start, st.data(), (nseg + 1) * sizeof(uint64_t));
+            be_.h2d(seg2_.seg_end, en.data(), (nseg + 1) * sizeof(uint64_t));
+            be_.sync();                                  // st / en live on this frame
+        }
+        direct_planned_ = true;
+        return CAPS_SA_FB_NONE;
+    }
+
+    // d_recv_*: the blocks received from ranks 0 .. world-1, in rank order (world 1: the send buffers themselves)
+    void sort_owned(const void* d_recv_keys, const void* d_recv_sa, void* dSA, void* dLCP) override
+    {
+        if (!direct_planned_) throw std::invalid_argument("shard_plan has not accepted the direct path");
+        BackendEvent e0 = be_.record();
+        if (recv_total_) {
+            ::caps::prepare_segments(be_, seg2_, n_tiles2_ + 1, nullptr, nullptr, true);
+            if (bits_ == 2) sort_owned_bits<2>(d_recv_keys, d_recv_sa, dSA, dLCP);
+            else sort_owned_bits<8>(d_recv_keys, d_recv_sa, dSA, dLCP);
+            dSA_ = static_cast<idx_t*>(dSA);
+        }
+        BackendEvent e1 = be_.record();
+        be_.sync();
+        ms_sort_ = be_.elapsed_ms(e0, e1);
+        double* out[4] = {&ms_tile_sort_, &ms_level_b_, &ms_count_, &ms_merge_};
+        for (size_t c = 0; c < clocks_.size() && c < 4; ++c) {
+            *out[c] = 0;
+            for (auto& sp : clocks_[c].spans) *out[c] += be_.elapsed_ms(sp.first, sp.second);
+        }
+        clocks_.clear();
+        be_.release_events();
+    }
+
     uint64_t last_sa() override
     {
         if (!recv_total_) return ~0ull;
@@ -315,7 +480,72 @@ private:
     SegBufs seg1_, segS_, seg2_;
     uint64_t *pkey_ = nullptr, *sizes_ = nullptr, *lstart_ = nullptr, *desc_ = nullptr, *partial_ = nullptr;
     idx_t *psa_ = nullptr, *Pm_ = nullptr, *ruler_ = nullptr;
-    double ms_phase1_ = 0, ms_pivots_ = 0, ms_collate_ = 0, ms_phase2_ = 0;
+    double ms_phase1_ = 0, ms_pivots_ = 0, ms_collate_ = 0, ms_phase2_ = 0, ms_scatter_ = 0, ms_sort_ = 0;
+    // direct path
+    double ms_level_a_ = 0, ms_level_b_ = 0, ms_tile_sort_ = 0, ms_count_ = 0, ms_merge_ = 0;
+    BackendEvent a0_, a1_;
+    std::vector<KernelClock> clocks_;
+    int direct_fb_ = CAPS_SA_FB_SHAPE;
+    bool direct_planned_ = false;
+    uint32_t PG_ = 0, K1_ = 0, SUB_ = 1, n_streams_ = 0, my_tiles_ = 0;
+    uint64_t capA_ = 0;
+    uint64_t *gkey_ = nullptr, *dstat_ = nullptr;
+    uint16_t* glut_ = nullptr;
+    idx_t* dcur_ = nullptr;
+
+    // pivots (identical on every rank: same text, same samples) + level A over this rank's tiles
+    template <int BITS> void scatter_bits(void* d_send_keys, void* d_send_sa, uint32_t* dflag)
+    {
+        const uint64_t m = m_total_;
+        CAPS_LAUNCH((sample_text_kernel<idx_t, BITS>), (uint32_t)((m + 255) / 256), 256, be_, (const uint32_t*)P_, (uint64_t)0, n_, m,
+                    SA_.key, SA_.sa);
+        CAPS_LAUNCH(uniform_segments_kernel, 1, 256, be_, segS_.seg_start, 1u, m, m);
+        prepare_segments(be_, segS_, tiles_of(m));
+        ElemBuf<idx_t> smp = sort<BITS>(segS_, tiles_of(m), m, false, SA_, SB_, m, 0, false, false).uniform();
+        CAPS_LAUNCH((pick_pivots_kernel<idx_t>), (p_ + 255) / 256, 256, be_, (const uint64_t*)smp.key, (const idx_t*)smp.sa, m, p_,
+                    pkey_, psa_);
+        CAPS_LAUNCH(group_keys_kernel, (p_ + 255) / 256, 256, be_, (const uint64_t*)pkey_, p_, PG_, K1_, gkey_, dflag);
+        CAPS_LAUNCH(split_lut_kernel, (SPLIT_LUT_CELLS + 256) / 256, 256, be_, (const uint64_t*)gkey_, K1_ - 1, glut_, dflag + 1);
+        be_.memset(dcur_, 0, (size_t)n_streams_ * sizeof(idx_t));
+        a0_ = be_.record();
+        if (my_tiles_)
+            CAPS_LAUNCH((group_scatter_kernel<idx_t, BITS>), my_tiles_, TILE_NT, be_, (const uint32_t*)P_, packed_words(n_, BITS), (uint64_t)0,
+                        n_, (const uint64_t*)gkey_, K1_, (const uint16_t*)glut_, (const uint32_t*)(dflag + 1), SUB_, capA_, dcur_,
+                        static_cast<uint64_t*>(d_send_keys), static_cast<idx_t*>(d_send_sa), (uint32_t)rank_, (uint32_t)world_);
+        a1_ = be_.record();
+    }
+
+    template <int BITS> void sort_owned_bits(const void* d_recv_keys, const void* d_recv_sa, void* dSA, void* dLCP)
+    {
+        SortOpts o;
+        o.need_lcp = true;
+        o.skip_finished = true;
+        o.bk = &bk_;
+        o.range_mode = 1;                         // group g holds the keys in (gkey[g-1], gkey[g]]
+        o.pkey = gkey_;
+        o.part_off = jlo_;
+        o.part_total = K1_;
+        o.sub = (uint32_t)world_ * SUB_;
+        o.seg_ends = true;
+        o.in_key = static_cast<const uint64_t*>(d_recv_keys);
+        o.in_sa = d_recv_sa;
+        o.final_sa = dSA;
+        o.final_lcp = dLCP;
+        o.bnd.first_key = bk_.first_key;
+        o.bnd.last_key = bk_.last_key;
+        o.bnd.first_sa = bk_.first_sa;
+        o.bnd.last_sa = bk_.last_sa;
+        o.slot_stats = slot_stats_;
+        o.speculate = std::getenv("CAPS_SA_NO_SLOTS") == nullptr;
+        KernelClock tile_clock, scatter_clock, count_clock, merge_clock;
+        o.tile_clock = &tile_clock;
+        o.scatter_clock = &scatter_clock;
+        o.count_clock = &count_clock;
+        o.merge_clock = &merge_clock;
+        SortResult<idx_t> r = segmented_sort<idx_t, BITS>(be_, P_, n_, tdesc_, seg2_, n_tiles2_, max_len2_, A_, B_, recv_total_, o);
+        clocks_ = {tile_clock, scatter_clock, count_clock, merge_clock};
+        finalize<idx_t, BITS>(be_, P_, n_, r, static_cast<idx_t*>(dSA), static_cast<idx_t*>(dLCP));
+    }
 
     template <typename T> T* get(size_t count)
     {

@@ -103,7 +103,8 @@ class ShardBuffers:
     the text's device) and re-used by every build."""
 
     def __init__(self, info: dict, dev, dt):
-        cap, loc = max(info["capacity"], 1), max(info["local_elems"], 1)
+        cap, loc = max(info["capacity"], 1), max(info["send_capacity"], info["local_elems"], 1)
+        self.report = torch.zeros(info["n_streams"] + 2, dtype=torch.int64, device=dev)
         self.sk = torch.empty(max(info["m_local"], 1), dtype=torch.int64, device=dev)
         self.ss = torch.empty(max(info["m_local"], 1), dtype=dt, device=dev)
         self.sizes = torch.empty(info["p"], dtype=torch.int64, device=dev)
@@ -143,7 +144,43 @@ def build_sharded(lib, T: torch.Tensor, p: int = 0, idx_bits: int | None = None,
         inf = sh.info()
         P = inf["p"]
         B = bufs if bufs is not None else ShardBuffers(inf, dev, dt)
-        # ---- phase 1 + samples
+        # ---- direct path: same pivots on every rank, level A on the rank's tiles, ONE exchange, level B + tile sort
+        if inf["direct_fallback"] == 0:
+            sh.scatter(B.send_k.data_ptr(), B.send_s.data_ptr(), B.report.data_ptr())
+            lap("scatter")
+            reports = torch.empty(world * B.report.numel(), dtype=torch.int64, device=dev)
+            dist.all_gather_into_tensor(reports, B.report)
+            reports_h = reports.cpu().numpy().astype(np.uint64).reshape(world, B.report.numel())
+            code, sc, rc = sh.plan(reports_h)
+            lap("plan")
+            if code == 0:
+                sc = [int(x) for x in sc]
+                rc = [int(x) for x in rc]
+                t0 = time.perf_counter()
+                if world == 1:
+                    recv_k, recv_s = B.send_k, B.send_s               # nothing to exchange: level B reads the streams in place
+                else:
+                    recv_k, recv_s = B.recv_k, B.recv_s
+                    plan = exchange_plan(rc, sc, 8, dev)
+                    all_to_all_v(recv_k[:sum(rc)], B.send_k[:sum(sc)], rc, sc, plan)
+                    all_to_all_v(recv_s[:sum(rc)], B.send_s[:sum(sc)], rc, sc, plan)
+                if dev.type == "cuda":
+                    torch.cuda.synchronize(dev)
+                ms_exchange = 1e3 * (time.perf_counter() - t0)
+                lap("exchange")
+                sh.sort_owned(recv_k.data_ptr(), recv_s.data_ptr(), B.SA.data_ptr(), B.LCP.data_ptr())
+                lap("sort")
+                info = _finish(sh, B.LCP, dev, rank, world)
+                lap("boundary")
+                total = info["recv_total"]
+                info["ms_exchange"] = ms_exchange
+                info["path"] = "direct"
+                info["exchange_elems_sent"] = sum(sc) - sc[rank]
+                if prof is not None:
+                    info["host_profile_ms"] = prof
+                return B.SA[:total], B.LCP[:total], info["slice_off"], info
+            inf = dict(inf, direct_fallback=code)
+        # ---- samplesort path: phase 1 + samples
         sk, ss = B.sk, B.ss
         lap("alloc_samples")
         sh.phase1(sk.data_ptr(), ss.data_ptr())
@@ -182,21 +219,12 @@ def build_sharded(lib, T: torch.Tensor, p: int = 0, idx_bits: int | None = None,
         lap("alloc_out")
         sh.phase2(recv_k.data_ptr(), recv_s.data_ptr(), SA.data_ptr(), LCP.data_ptr())
         lap("phase2")
-        # ---- boundary LCP between consecutive slices
-        mine = sh.last_sa()
-        last = torch.tensor([mine - (1 << 64) if mine >= (1 << 63) else mine], dtype=torch.int64, device=dev)
-        lasts = torch.empty(world, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(lasts, last)
-        prev = 0xFFFFFFFFFFFFFFFF
-        for r in range(rank - 1, -1, -1):
-            v = int(lasts[r].item())
-            if v != -1:
-                prev = v
-                break
-        sh.fix_first_lcp(prev, LCP.data_ptr())
-        info = sh.info()
+        info = _finish(sh, LCP, dev, rank, world)
         lap("boundary")
         info["ms_exchange"] = ms_exchange
+        info["path"] = "samplesort"
+        info["direct_fallback"] = inf["direct_fallback"]
+        info["exchange_elems_sent"] = sum(sc) - sc[rank]
         if prof is not None:
             info["host_profile_ms"] = prof
         info["send_counts"] = sc
@@ -207,10 +235,25 @@ def build_sharded(lib, T: torch.Tensor, p: int = 0, idx_bits: int | None = None,
             sh.close()
 
 
+def _finish(sh, LCP, dev, rank: int, world: int) -> dict:
+    """Boundary LCP between consecutive slices: every rank needs the last SA value of the nearest non-empty slice below."""
+    mine = sh.last_sa()
+    last = torch.tensor([mine - (1 << 64) if mine >= (1 << 63) else mine], dtype=torch.int64, device=dev)
+    lasts = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(lasts, last)
+    prev = 0xFFFFFFFFFFFFFFFF
+    for v in reversed(lasts[:rank].tolist()):
+        if v != -1:
+            prev = v & 0xFFFFFFFFFFFFFFFF
+            break
+    sh.fix_first_lcp(prev, LCP.data_ptr())
+    return sh.info()
+
+
 def bench_main(args, rank: int, local_rank: int, world: int):
-    """bench.py's N > 1 leg: same C3 text on every GPU, strong scaling."""
+    """bench.py's N > 1 leg: same text on every GPU, strong scaling."""
     import caps_sa_amd
-    from bench import WORKLOADS, make_text
+    from bench import WORKLOADS, make_text, roofline, cpu_baseline
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world == 1 and "RANK" not in os.environ:          # forced single-rank run without torchrun
@@ -220,16 +263,16 @@ def bench_main(args, rank: int, local_rank: int, world: int):
     else:
         dist.init_process_group("nccl", device_id=dev)
     L = caps_sa_amd.lib()
-    n_bases, desc = WORKLOADS[args.workload]
+    n_bases, kind, desc = WORKLOADS[args.workload]
     if args.bases:
-        n_bases, desc = args.bases, f"custom: {args.bases} random DNA bases + remapped newline, p={args.p}"
+        n_bases, desc = args.bases, f"custom: {args.bases} bases of kind {kind} + remapped newline, p={args.p}"
     n = n_bases + 1
     idx_bits = 32 if n <= 0xFFFFFFFF else 64
-    T = make_text(torch, n_bases, args.seed, dev)          # identical on every rank (same seed)
+    w = idx_bits // 8
+    T = make_text(torch, n_bases, args.seed, dev, kind)          # identical on every rank (same seed)
     stream = torch.cuda.current_stream().cuda_stream
 
     sh = L.shard(T.data_ptr(), n, args.p, idx_bits, rank, world, stream)     # workspace of the rank, allocated once
-
     bufs = ShardBuffers(sh.info(), dev, _idx_dtype(idx_bits))
 
     def step():
@@ -241,32 +284,56 @@ def bench_main(args, rank: int, local_rank: int, world: int):
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    infos = []
     for _ in range(args.steps):
         SA, LCP, off, info = step()
+        infos.append(info)
     dist.barrier()
     torch.cuda.synchronize()
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
-    errs = None
-    if args.verify:
-        errs = verify_sharded(L, T, SA, LCP, off, idx_bits)
+    errs = None if args.no_verify else verify_sharded(L, T, SA, LCP, off, idx_bits)
     if rank == 0:
+        info = infos[-1]
+        direct = all(i["path"] == "direct" for i in infos)
+        mine = info["recv_total"]
+        roof = None
+        if direct:        # rank 0's kernels over ITS share of the suffixes, same convention as at N = 1
+            k = len(infos)
+            roof = roofline({"level_a_scatter": (sum(i["ms_level_a"] for i in infos), k, sum(i["level_a_elems"] for i in infos)),
+                             "level_b_scatter": (sum(i["ms_level_b"] for i in infos), k, sum(i["recv_total"] for i in infos)),
+                             "tile_sort_kernel": (sum(i["ms_tile_sort"] for i in infos), k, sum(i["recv_total"] for i in infos)),
+                             "merge_pass_kernel": (sum(i["ms_merge_passes"] for i in infos), k if info["ms_merge_passes"] > 0 else 0,
+                                                   sum(i["recv_total"] for i in infos))}, w, "")
+            if roof:
+                roof["scope"] = f"rank 0 of {world}: its kernels over its {mine} suffixes"
+        ms_x = sum(i["ms_exchange"] for i in infos) / len(infos)
+        sent = info["exchange_elems_sent"] * (8 + w)
+        keys = ("ms_scatter", "ms_exchange", "ms_sort") if direct else ("ms_phase1", "ms_pivots", "ms_collate", "ms_exchange", "ms_phase2")
         out = {
             "metric": "suffixes/sec (SA+LCP build)", "value": n / (elapsed / args.steps), "unit": "suffixes/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": f"u{idx_bits}",
             "data": "synthetic",
             "config": {"workload": desc, "n": n, "subproblems": info["p"], "bits_per_char": info["bits_per_char"],
+                       "construction": "direct (same pivots on every rank, one scatter of every world-th tile into groups, ONE "
+                                       "all-to-all of (key, sa), per-group sort)" if direct
+                                       else f"samplesort (fallback reason {info.get('direct_fallback')})",
+                       "groups": info["direct_groups"], "streams_per_group": info["direct_sub"],
                        "workspace": "preallocated",
-                       "parallelism": f"{world} GPUs: text replicated, subarrays and partitions sharded, "
-                                      "one RCCL all-to-all-v"},
-            "rank0_ms": {k: info[k] for k in ("ms_phase1", "ms_pivots", "ms_collate", "ms_exchange", "ms_phase2")},
+                       "parallelism": f"{world} GPUs, one process each: text replicated, tiles of the text and groups of partitions "
+                                      "sharded, one RCCL all-to-all over xGMI"},
+            "rank0_ms": {k_: info[k_] for k_ in keys},
+            "exchange": {"ms": ms_x, "bytes_sent_per_rank": sent, "GBps_per_rank": (sent / 1e9) / (ms_x * 1e-3) if ms_x > 0 and sent else None,
+                         "note": "keys and indices in two all-to-all calls; region gaps (10 %) travel too"},
             "rank0_host_profile_ms": info.get("host_profile_ms"),
-            "roofline": None, "cpu_baseline": None,
+            "roofline": roof,
+            "verify_errors": errs,
+            "cpu_baseline": None,
         }
-        if errs is not None:
-            out["verify_errors"] = errs
+        if world == 1 and not args.no_cpu_baseline:          # the CPU baseline is timed at N = 1 only (rank 0)
+            out["cpu_baseline"] = cpu_baseline(T, min(args.cpu_sample, n), args.p, n)
         print(json.dumps(out))
     sh.close()
     dist.destroy_process_group()

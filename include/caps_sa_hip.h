@@ -73,7 +73,8 @@ typedef struct caps_sa_stats {
     uint32_t path_direct, path_fallback;
     uint32_t direct_groups;        /* groups of consecutive partitions the text was scattered into */
     uint32_t direct_reserved_;
-    uint64_t direct_max_group;     /* largest group (elements) */
+    uint64_t direct_max_group;     /* largest stream of a group (elements) */
+    double level_a_ms;             /* direct path: the text -> groups scatter (also counted in bucket_scatter_ms) */
 } caps_sa_stats;
 
 #define CAPS_SA_FB_NONE 0
@@ -210,6 +211,16 @@ typedef struct caps_sa_shard_info {
     uint64_t slice_off;            /* position of the rank's slice in the global SA/LCP */
     uint64_t capacity;             /* most elements this shard can receive (size of recv / SA / LCP buffers) */
     double ms_phase1, ms_pivots, ms_collate, ms_phase2;
+    /* direct path (shard_scatter / shard_plan / shard_sort) */
+    uint32_t direct_fallback;      /* CAPS_SA_FB_NONE: the shape allows the direct path; else why not */
+    uint32_t direct_groups, direct_sub, n_streams;   /* groups, sub-streams per group, streams = groups x sub-streams */
+    uint64_t stream_cap;           /* elements a stream region holds */
+    uint64_t send_capacity;        /* elements the send buffers must hold (either path) */
+    double ms_scatter, ms_sort;
+    /* kernel families of the last direct build on this rank (HIP events on its stream) */
+    double ms_level_a, ms_level_b, ms_tile_sort, ms_merge_passes;
+    uint64_t level_a_elems;        /* text positions this rank distributed */
+    uint32_t slot_splits, slot_splits_redone;
 } caps_sa_shard_info;
 
 int caps_sa_hip_shard_create(const void* dT, uint64_t n, uint64_t subproblem_count, int idx_bytes, int rank, int world,
@@ -225,6 +236,23 @@ int caps_sa_hip_shard_collate(caps_sa_shard* s, const uint64_t* all_sizes, void*
                               uint64_t* send_counts, uint64_t* recv_counts);
 /* d_recv_*: [recv_total], source-rank-major; dSA/dLCP: idx[recv_total] out */
 int caps_sa_hip_shard_phase2(caps_sa_shard* s, const void* d_recv_keys, const void* d_recv_sa, void* dSA, void* dLCP);
+/*
+ * Direct path of a sharded build (what Builder::run_direct does on one GPU; no sort_subarrays, no locate_pivots):
+ *
+ *   shard_create -> shard_scatter -> [all_gather of the reports] -> shard_plan
+ *   -> [all-to-all of the (key, sa) blocks; world 1: none] -> shard_sort -> [all_gather last SA] -> shard_fix_first_lcp
+ *
+ * shard_scatter: packs the text, derives the pivots (every rank the same ones, from the same samples of the text) and
+ * distributes the suffixes of every world-th tile of the text into stream regions of d_send_keys (u64[send_capacity]) /
+ * d_send_sa (idx[send_capacity]); the block for rank d is contiguous.  d_report: u64[n_streams + 2], this rank's stream
+ * sizes and flags.  shard_plan: all_reports = HOST u64[world][n_streams + 2]; returns 0 and the elements to send to /
+ * receive from every rank (gaps of the regions included), or a positive CAPS_SA_FB_* code -- the same on every rank --
+ * when the text cannot be split by keys alone: the ranks then run the samplesort sequence above (shard_phase1 ...).
+ * shard_sort: d_recv_* = the received blocks in rank order; dSA / dLCP: idx[capacity] out, recv_total entries valid.
+ */
+int caps_sa_hip_shard_scatter(caps_sa_shard* s, void* d_send_keys, void* d_send_sa, void* d_report);
+int caps_sa_hip_shard_plan(caps_sa_shard* s, const uint64_t* all_reports, uint64_t* send_counts, uint64_t* recv_counts);
+int caps_sa_hip_shard_sort(caps_sa_shard* s, const void* d_recv_keys, const void* d_recv_sa, void* dSA, void* dLCP);
 /* last SA value of the slice (UINT64_MAX when the slice is empty) */
 int caps_sa_hip_shard_last_sa(caps_sa_shard* s, uint64_t* last_sa);
 /* prev_sa: last SA value of the nearest non-empty lower rank (UINT64_MAX: none) */

@@ -19,8 +19,19 @@ def main():
     import caps_sa_dist
     caps_sa_dist.A2A_MAX_BYTES = int(os.environ.get("CAPS_A2A_MAX_BYTES", caps_sa_dist.A2A_MAX_BYTES))
     import oracle as O
-    from emul_util import emul
-    E = emul()
+    from emul_util import emul, emul_small
+    E = emul_small() if os.environ.get("CAPS_EMUL_SMALL") == "1" else emul()
+    if os.environ.get("CAPS_DIST_CASE") == "imbalance":
+        # samplesort path, 3 partitions for 2 ranks: one rank would own 2/3 of the suffixes -- more than any shard's
+        # buffers hold.  Every rank must fail (together, before the exchange), none may hang.
+        T = torch.from_numpy(np.random.RandomState(5).choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=2_000_000))
+        try:
+            caps_sa_dist.build_sharded(E, T, 3, 32)
+        except Exception as e:                                       # noqa: BLE001
+            print(f"rank {rank}: refused: {e}", flush=True)
+            dist.destroy_process_group()
+            sys.exit(0 if "imbalanced" in str(e) else 1)
+        sys.exit(1)
     cases = []
     rs = np.random.RandomState(11)
     dna = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -31,6 +42,9 @@ def main():
     cases.append((rs.choice(dna, size=100), 0, 32))                          # p_eff = 6
     cases.append((rs.choice(dna, size=600_000), 8, 32))                      # big enough for the slot splits (kept)
     cases.append((rs.choice(dna, size=500_000, p=[0.6, 0.2, 0.1, 0.1]), 6, 64))   # ... and redone on skewed keys
+    runs = rs.choice(dna, size=180_000)
+    runs[20_000:26_000] = ord("G")                                           # an N-block: long run -> every rank falls back together
+    cases.append((runs, 0, 32))
     ok = True
     for T_np, p, bits in cases:
         T = torch.from_numpy(T_np.copy())
@@ -48,7 +62,8 @@ def main():
         SAo, LCPo = (O.naive_sa_lcp(T_np, idx_bits=bits) if T_np.size <= 200_000 else O.build_sa_lcp(T_np, p=p, idx_bits=bits)[:2])
         good = np.array_equal(SA_all.view(dt), SAo) and np.array_equal(LCP_all.view(dt), LCPo)
         if rank == 0:
-            print(f"case n={T_np.size} p={p} bits={bits} counts={counts} {'OK' if good else 'MISMATCH'}", flush=True)
+            print(f"case n={T_np.size} p={p} bits={bits} path={info['path']} fb={info.get('direct_fallback')} counts={counts} "
+                  f"{'OK' if good else 'MISMATCH'}", flush=True)
         ok = ok and good
     dist.destroy_process_group()
     sys.exit(0 if ok else 1)

@@ -18,6 +18,30 @@ def build_world(lib, T: torch.Tensor, p: int, world: int, idx_bits: int = 32):
         infos = [s.info() for s in shards]
         P = infos[0]["p"]
         bufs = [ShardBuffers(i, dev, dt) for i in infos]
+        sync = (lambda: torch.cuda.synchronize()) if dev.type == "cuda" else (lambda: None)
+        if infos[0]["direct_fallback"] == 0:
+            # direct path: scatter -> [all_gather reports] -> plan -> [all-to-all of the blocks] -> sort
+            for s, B in zip(shards, bufs):
+                s.scatter(B.send_k.data_ptr(), B.send_s.data_ptr(), B.report.data_ptr())
+            sync()
+            reports_h = torch.stack([B.report for B in bufs]).cpu().numpy().astype(np.uint64)
+            plans = [s.plan(reports_h) for s in shards]
+            codes = {c for c, _, _ in plans}
+            assert len(codes) == 1, f"ranks disagree on the path: {codes}"
+            if codes == {0}:
+                sc = [[int(x) for x in a] for _, a, _ in plans]
+                rc = [[int(x) for x in b] for _, _, b in plans]
+                for r in range(world):
+                    assert [sc[q][r] for q in range(world)] == rc[r], "send/receive counts disagree"
+                    ro = 0
+                    for q in range(world):
+                        so, c = sum(sc[q][:r]), sc[q][r]
+                        bufs[r].recv_k[ro:ro + c] = bufs[q].send_k[so:so + c]
+                        bufs[r].recv_s[ro:ro + c] = bufs[q].send_s[so:so + c]
+                        ro += c
+                for s, B in zip(shards, bufs):
+                    s.sort_owned(B.recv_k.data_ptr(), B.recv_s.data_ptr(), B.SA.data_ptr(), B.LCP.data_ptr())
+                return _stitch(shards, bufs, n, sync, "direct")
         for s, B in zip(shards, bufs):
             s.phase1(B.sk.data_ptr(), B.ss.data_ptr())
         all_k = torch.cat([B.sk[:i["m_local"]] for B, i in zip(bufs, infos)])          # all_gather(samples)
@@ -46,23 +70,27 @@ def build_world(lib, T: torch.Tensor, p: int, world: int, idx_bits: int = 32):
                 ro += c
         for s, B in zip(shards, bufs):
             s.phase2(B.recv_k.data_ptr(), B.recv_s.data_ptr(), B.SA.data_ptr(), B.LCP.data_ptr())
-        lasts = [s.last_sa() for s in shards]                                             # all_gather(last SA)
-        for r, (s, B) in enumerate(zip(shards, bufs)):
-            prev = 0xFFFFFFFFFFFFFFFF
-            for q in range(r - 1, -1, -1):
-                if lasts[q] != 0xFFFFFFFFFFFFFFFF:
-                    prev = lasts[q]
-                    break
-            s.fix_first_lcp(prev, B.LCP.data_ptr())
-        if dev.type == "cuda":
-            torch.cuda.synchronize()
-        infos = [s.info() for s in shards]
-        offs = [i["slice_off"] for i in infos]
-        lens = [sum(x) for x in rc]
-        assert offs == [sum(lens[:r]) for r in range(world)] and sum(lens) == n
-        SA = torch.cat([B.SA[:c] for B, c in zip(bufs, lens)])
-        LCP = torch.cat([B.LCP[:c] for B, c in zip(bufs, lens)])
-        return SA, LCP
+        return _stitch(shards, bufs, n, sync, "samplesort")
     finally:
         for s in shards:
             s.close()
+
+
+def _stitch(shards, bufs, n, sync, path):
+    lasts = [s.last_sa() for s in shards]                                             # all_gather(last SA)
+    for r, (s, B) in enumerate(zip(shards, bufs)):
+        prev = 0xFFFFFFFFFFFFFFFF
+        for q in range(r - 1, -1, -1):
+            if lasts[q] != 0xFFFFFFFFFFFFFFFF:
+                prev = lasts[q]
+                break
+        s.fix_first_lcp(prev, B.LCP.data_ptr())
+    sync()
+    infos = [s.info() for s in shards]
+    offs = [i["slice_off"] for i in infos]
+    lens = [i["recv_total"] for i in infos]
+    assert offs == [sum(lens[:r]) for r in range(len(shards))] and sum(lens) == n, (offs, lens, n)
+    SA = torch.cat([B.SA[:c] for B, c in zip(bufs, lens)])
+    LCP = torch.cat([B.LCP[:c] for B, c in zip(bufs, lens)])
+    build_world.last_path = path
+    return SA, LCP

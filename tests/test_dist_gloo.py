@@ -11,17 +11,38 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,port,a2a_limit", [(2, 29531, 0), (3, 29532, 0), (2, 29534, 4096), (4, 29535, 0)])
-def test_sharded_build_matches_oracle(world, port, a2a_limit):
-    """a2a_limit > 0: exchange in rounds of that many bytes per peer (the path taken on GPUs when a
-    sub-subarray block exceeds RCCL's safe message size)."""
-    from emul_util import emul
-    emul()   # build the emulation library once, before the ranks race for it
+@pytest.mark.parametrize("world,port,a2a_limit,small,path", [
+    (2, 29531, 0, 0, "auto"), (3, 29532, 0, 0, "auto"), (2, 29534, 4096, 0, "auto"), (4, 29535, 0, 0, "auto"),
+    (2, 29536, 0, 1, "auto"), (3, 29537, 4096, 1, "auto"), (2, 29538, 0, 0, "classic"), (2, 29539, 0, 1, "classic")])
+def test_sharded_build_matches_oracle(world, port, a2a_limit, small, path):
+    """a2a_limit > 0: exchange in rounds of that many bytes per peer (the path taken on GPUs when a block exceeds
+    RCCL's safe message size).  small: the kernels' 256-element-tile build (more tiles, groups and streams per case:
+    the direct path on every case that is not tiny).  path: CAPS_SA_PATH (classic = samplesort path on every case)."""
+    from emul_util import emul, emul_small
+    (emul_small if small else emul)()   # build the emulation library once, before the ranks race for it
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py")]
-    env = dict(os.environ)
+    env = dict(os.environ, CAPS_SA_PATH=path, CAPS_EMUL_SMALL=str(small))
     if a2a_limit:
         env["CAPS_A2A_MAX_BYTES"] = str(a2a_limit)
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert r.stdout.count(" OK") == 7, r.stdout
+    assert r.stdout.count(" OK") == 8, r.stdout
+    if path == "classic":
+        assert "path=direct" not in r.stdout
+    else:
+        assert r.stdout.count("path=direct") >= (4 if small else 3), r.stdout
+        assert "fb=3" in r.stdout                      # the long run: CAPS_SA_FB_LONG_RUNS, agreed on by every rank
+
+
+def test_imbalanced_ownership_fails_on_every_rank_together():
+    """with p < 4 x world the midpoint ownership can give a rank more than its buffers hold; every rank must
+    raise before the exchange instead of one raising and the others waiting for it."""
+    from emul_util import emul
+    emul()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29540", os.path.join(ROOT, "tests", "dist_worker.py")]
+    env = dict(os.environ, CAPS_SA_PATH="classic", CAPS_DIST_CASE="imbalance")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("refused") == 2, r.stdout

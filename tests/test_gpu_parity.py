@@ -194,7 +194,7 @@ def test_c3_3g_device_resident(L, sa_path):
         assert st["path_fallback"] == 0 and st["slot_splits_redone"] == 0 and st["direct_groups"] == 1000, st
 
 
-def test_sharded_driver_single_rank_rccl(L):
+def test_sharded_driver_single_rank_rccl(L, sa_path):
     """The multi-GPU driver (caps_sa_dist.py) with the real kernels and backend nccl (RCCL) at
     world size 1 -- all a 1-GPU box allows; world sizes 2 and 3 run on CPU over gloo
     (tests/test_dist_gloo.py).  Checked with the device verifier and against the 1-GPU build."""
@@ -214,6 +214,7 @@ def test_sharded_driver_single_rank_rccl(L):
         T = lut[torch.randint(0, 4, (n,), device="cuda", generator=g, dtype=torch.int64)]
         SA, LCP, off, info = caps_sa_dist.build_sharded(L, T, 500, 32)
         assert off == 0 and SA.numel() == n
+        assert info["path"] == ("samplesort" if sa_path == "classic" else "direct"), info
         assert L.verify_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr()) == 0
         SA1 = torch.empty(n, dtype=torch.int32, device="cuda")
         LCP1 = torch.empty(n, dtype=torch.int32, device="cuda")
@@ -448,9 +449,10 @@ def test_host_entry_point_cache_and_pinned_results(L, oracle):
 
 @pytest.mark.parametrize("world,n,p,bits", [(2, 20_000_001, 8000, 32), (3, 6_000_000, 500, 32), (4, 9_000_001, 0, 64),
                                             (8, 40_000_000, 8000, 32)])
-def test_shard_kernels_at_world_sizes_above_one_loopback(L, world, n, p, bits):
+def test_shard_kernels_at_world_sizes_above_one_loopback(L, sa_path, world, n, p, bits):
     """Every rank's shard on the one GPU of the box, collectives replaced by copies
-    (tests/loopback_world.py): result == the single-GPU build, bit for bit."""
+    (tests/loopback_world.py): result == the single-GPU build, bit for bit.  Both constructions; world 3 carries a long
+    run, on which every rank of the direct path must fall back together."""
     import torch
     from loopback_world import build_world
     g = torch.Generator(device="cuda")
@@ -468,3 +470,4 @@ def test_shard_kernels_at_world_sizes_above_one_loopback(L, world, n, p, bits):
     SA, LCP = build_world(L, T, p, world, bits)
     assert torch.equal(SA, SA1)
     assert torch.equal(LCP, LCP1)
+    assert build_world.last_path == ("direct" if sa_path != "classic" and world != 3 else "samplesort")
