@@ -94,12 +94,14 @@ class ShardInfo(ctypes.Structure):
 
 
 SHARD_EXPORTS = ["shard_create", "shard_destroy", "shard_info", "shard_phase1", "shard_pivots", "shard_collate",
-                 "shard_phase2", "shard_last_sa", "shard_fix_first_lcp", "shard_scatter", "shard_plan", "shard_sort"]
+                 "shard_phase2", "shard_last_sa", "shard_fix_first_lcp", "shard_scatter", "shard_plan", "shard_sort",
+                 "shard_phase1_arrays"]
 
 EXPORTS = ["device_count", "last_error", "version", "workspace_bytes", "release_cache", "host_alloc", "host_free"] + SHARD_EXPORTS + [
     f"{name}_{sfx}"
     for sfx in ("u32", "u64")
-    for name in ("build", "build_device", "verify_device", "sort_suffixes", "sort_segments", "merge", "upper_bound", "lcp")
+    for name in ("build", "build_device", "verify_device", "verify_slice_device", "sort_suffixes", "sort_segments", "merge",
+                 "upper_bound", "lcp")
 ]
 
 
@@ -138,6 +140,8 @@ class CapsLib:
             f(f"build_device_{sfx}").argtypes = [_vp, _u64, _u64, _u64, _vp, _vp, _vp, _u64, _vp, ctypes.POINTER(Stats)]
             f(f"verify_device_{sfx}").restype = _ci
             f(f"verify_device_{sfx}").argtypes = [_vp, _u64, _vp, _vp, _vp, ctypes.POINTER(_u64)]
+            f(f"verify_slice_device_{sfx}").restype = _ci
+            f(f"verify_slice_device_{sfx}").argtypes = [_vp, _u64, _vp, _vp, _u64, _ci, _vp, ctypes.POINTER(_u64)]
             f(f"sort_suffixes_{sfx}").restype = _ci
             f(f"sort_suffixes_{sfx}").argtypes = [_vp, _u64, _vp, _u64, _vp, _vp, _ci]
             f(f"sort_segments_{sfx}").restype = _ci
@@ -169,6 +173,8 @@ class CapsLib:
         f("shard_plan").argtypes = [_vp, _vp, _vp, _vp]
         f("shard_sort").restype = _ci
         f("shard_sort").argtypes = [_vp, _vp, _vp, _vp, _vp]
+        f("shard_phase1_arrays").restype = _ci
+        f("shard_phase1_arrays").argtypes = [_vp, _vp, _vp, ctypes.POINTER(_u64), ctypes.POINTER(_u64)]
         f("shard_last_sa").restype = _ci
         f("shard_last_sa").argtypes = [_vp, ctypes.POINTER(_u64)]
         f("shard_fix_first_lcp").restype = _ci
@@ -244,6 +250,14 @@ class CapsLib:
         sfx, _ = _sfx(idx_bits)
         err = _u64(0)
         self._check(self._f(f"verify_device_{sfx}")(dT_ptr, n, dSA_ptr, dLCP_ptr, stream or None, ctypes.byref(err)))
+        return err.value
+
+    def verify_slice_device(self, dT_ptr: int, n: int, dSA_ptr: int, dLCP_ptr: int, cnt: int, is_head: bool, idx_bits: int = 32,
+                            stream: int = 0) -> int:
+        sfx, _ = _sfx(idx_bits)
+        err = _u64(0)
+        self._check(self._f(f"verify_slice_device_{sfx}")(dT_ptr, n, dSA_ptr, dLCP_ptr, cnt, 1 if is_head else 0, stream or None,
+                                                          ctypes.byref(err)))
         return err.value
 
     # ------------------------------------------------------------------ kernel-level entry points
@@ -358,6 +372,12 @@ class Shard:
 
     def sort_owned(self, d_recv_keys: int, d_recv_sa: int, dSA: int, dLCP: int):
         self.lib._check(self.lib._f("shard_sort")(self.h, d_recv_keys or None, d_recv_sa or None, dSA or None, dLCP or None))
+
+    def phase1_arrays(self, d_keys_out: int = 0, d_sa_out: int = 0):
+        """Copies the rank's sorted subarrays (after phase1()) into the given device buffers; -> (count, subarray length)."""
+        c, sl = _u64(0), _u64(0)
+        self.lib._check(self.lib._f("shard_phase1_arrays")(self.h, d_keys_out or None, d_sa_out or None, ctypes.byref(c), ctypes.byref(sl)))
+        return c.value, sl.value
 
     def last_sa(self) -> int:
         v = _u64(0)

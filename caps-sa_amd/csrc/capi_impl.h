@@ -176,11 +176,14 @@ int build_host(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context, 
 }
 
 template <typename idx_t>
-int verify_device(const void* dT, uint64_t n, const void* dSA, const void* dLCP, void* stream, uint64_t* n_errors)
+int verify_device(const void* dT, uint64_t n, const void* dSA, const void* dLCP, void* stream, uint64_t* n_errors,
+                  uint64_t cnt = ~0ull, uint32_t head = 1)
 {
     if (!n_errors) return fail(CAPS_SA_EINVAL, "null n_errors");
     *n_errors = 0;
-    if (n == 0) return CAPS_SA_OK;
+    if (cnt == ~0ull) cnt = n;
+    if (cnt > n) return fail(CAPS_SA_EINVAL, "more entries than suffixes");
+    if (n == 0 || cnt == 0) return CAPS_SA_OK;
     if (!dT || !dSA || !dLCP) return fail(CAPS_SA_EINVAL, "null pointer");
     return guarded([&]() -> int {
         Backend be(static_cast<decltype(Backend::stream)>(stream));
@@ -190,9 +193,9 @@ int verify_device(const void* dT, uint64_t n, const void* dSA, const void* dLCP,
         uint64_t* err = da.get<uint64_t>(1);
         be.memset(seen, 0, words * sizeof(uint32_t));
         be.memset(err, 0, sizeof(uint64_t));
-        const uint64_t want = (n + 255) / 256;
+        const uint64_t want = (cnt + 255) / 256;
         CAPS_LAUNCH((verify_kernel<idx_t>), want < 16384 ? want : 16384, 256, be, static_cast<const int8_t*>(dT), n,
-                    static_cast<const idx_t*>(dSA), static_cast<const idx_t*>(dLCP), seen, err);
+                    static_cast<const idx_t*>(dSA), static_cast<const idx_t*>(dLCP), cnt, head, seen, err);
         be.d2h(n_errors, err, sizeof(uint64_t));
         be.sync();
         return CAPS_SA_OK;
@@ -503,6 +506,9 @@ int CAPS_API(workspace_bytes)(uint64_t n, uint64_t subproblem_count, int idx_byt
     int CAPS_API(verify_device_##SFX)(const void* dT, uint64_t n, const void* dSA, const void* dLCP, void* stream,          \
                                       uint64_t* n_errors)                                                                  \
     { return caps::verify_device<IDX>(dT, n, dSA, dLCP, stream, n_errors); }                                               \
+    int CAPS_API(verify_slice_device_##SFX)(const void* dT, uint64_t n, const void* dSA, const void* dLCP, uint64_t cnt,    \
+                                            int is_head, void* stream, uint64_t* n_errors)                                 \
+    { return caps::verify_device<IDX>(dT, n, dSA, dLCP, stream, n_errors, cnt, is_head ? 1u : 0u); }                       \
     int CAPS_API(sort_suffixes_##SFX)(const char* T, uint64_t n, const IDX* idx, uint64_t cnt, IDX* osa, IDX* olcp, int d) \
     { return caps::sort_suffixes<IDX>(T, n, idx, cnt, osa, olcp, d); }                                                     \
     int CAPS_API(sort_segments_##SFX)(const char* T, uint64_t n, const IDX* idx, uint64_t cnt, const uint64_t* seg,        \
@@ -583,6 +589,11 @@ int CAPS_API(shard_sort)(caps_sa_shard* s, const void* k, const void* a, void* d
 {
     if (!s) return caps::fail(CAPS_SA_EINVAL, "null shard");
     return caps::guarded([&]() -> int { s->impl->sort_owned(k, a, dSA, dLCP); return CAPS_SA_OK; });
+}
+int CAPS_API(shard_phase1_arrays)(caps_sa_shard* s, void* d_keys_out, void* d_sa_out, uint64_t* count, uint64_t* subarray_len)
+{
+    if (!s || !count || !subarray_len) return caps::fail(CAPS_SA_EINVAL, "null pointer");
+    return caps::guarded([&]() -> int { s->impl->phase1_arrays(d_keys_out, d_sa_out, count, subarray_len); return CAPS_SA_OK; });
 }
 int CAPS_API(shard_last_sa)(caps_sa_shard* s, uint64_t* last_sa)
 {

@@ -2843,15 +2843,17 @@ GLOBAL_FN LAUNCH_BOUNDS(64) first_lcp_kernel(KCTX const uint32_t* __restrict__ P
 // cpp:512-536): works on the RAW text with byte loops, independent of the packed text
 // and keys.  err[0] += #violations; seen is an n-bit set for the permutation check.
 // ----------------------------------------------------------------------------------
+// cnt entries of SA / LCP are checked (cnt = n: the whole arrays; cnt < n: a slice of them, e.g. one rank's -- then
+// "no value twice" is all the permutation check can say).  head != 0: entry 0 is the head of the suffix array (LCP 0).
 template <typename idx_t>
 GLOBAL_FN LAUNCH_BOUNDS(256) verify_kernel(KCTX const int8_t* __restrict__ T, uint64_t n, const idx_t* __restrict__ SA,
-                                           const idx_t* __restrict__ LCP, uint32_t* __restrict__ seen,
+                                           const idx_t* __restrict__ LCP, uint64_t cnt, uint32_t head, uint32_t* __restrict__ seen,
                                            uint64_t* __restrict__ err)
 {
     PAR(tid) {
         const uint64_t stride = (uint64_t)K_GRID_DIM * K_BLOCK_DIM;
         uint64_t bad = 0;
-        for (uint64_t i = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid; i < n; i += stride) {
+        for (uint64_t i = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid; i < cnt; i += stride) {
             const uint64_t b = SA[i];
             if (b >= n) { ++bad; continue; }
             const uint32_t bit = 1u << (b & 31);
@@ -2861,7 +2863,7 @@ GLOBAL_FN LAUNCH_BOUNDS(256) verify_kernel(KCTX const int8_t* __restrict__ T, ui
             const uint32_t old = atomicOr(&seen[b >> 5], bit);
 #endif
             if (old & bit) ++bad;
-            if (i == 0) { if (LCP[0] != 0) ++bad; continue; }
+            if (i == 0) { if (head && LCP[0] != 0) ++bad; continue; }
             const uint64_t a = SA[i - 1];
             if (a >= n) continue;                        // counted by its own thread
             const uint64_t cap = n - (a > b ? a : b);

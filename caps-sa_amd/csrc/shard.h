@@ -56,6 +56,7 @@ struct ShardBase {
     virtual void scatter(void* d_send_keys, void* d_send_sa, void* d_report) = 0;
     virtual int plan(const uint64_t* all_reports, uint64_t* send_counts, uint64_t* recv_counts) = 0;
     virtual void sort_owned(const void* d_recv_keys, const void* d_recv_sa, void* dSA, void* dLCP) = 0;
+    virtual void phase1_arrays(void* d_keys_out, void* d_sa_out, uint64_t* count, uint64_t* subarray_len) = 0;
 };
 
 template <typename idx_t> class Shard : public ShardBase {
@@ -79,6 +80,8 @@ public:
         if (const char* force = std::getenv("CAPS_SA_PATH")) if (std::string(force) == "classic") direct_fb_ = CAPS_SA_FB_FORCED;
         const uint64_t ga_tiles = (n + GA_E - 1) / GA_E;
         my_tiles_ = (uint32_t)(ga_tiles > (uint64_t)rank ? (ga_tiles - rank + world - 1) / world : 0);
+        my_elems_ = (uint64_t)my_tiles_ * GA_E;
+        if (my_tiles_ && (ga_tiles - 1) % world == (uint64_t)rank) my_elems_ -= ga_tiles * GA_E - n;   // the text's last tile is short
         if (direct_fb_ == CAPS_SA_FB_NONE) {
             SUB_ = ga_tiles / world >= 32ull * DIRECT_SUB ? DIRECT_SUB : 1u;
             if (const char* e = std::getenv("CAPS_SA_DIRECT_SUB")) if (std::atoi(e) >= 1 && (uint32_t)std::atoi(e) <= DIRECT_SUB) SUB_ = (uint32_t)std::atoi(e);
@@ -148,7 +151,7 @@ public:
         o->send_capacity = std::max<uint64_t>(local_n_, direct_fb_ == CAPS_SA_FB_NONE ? (uint64_t)n_streams_ * capA_ : 0);
         o->ms_scatter = ms_scatter_; o->ms_sort = ms_sort_;
         o->ms_level_a = ms_level_a_; o->ms_level_b = ms_level_b_ + ms_count_; o->ms_tile_sort = ms_tile_sort_; o->ms_merge_passes = ms_merge_;
-        o->level_a_elems = (uint64_t)my_tiles_ * GA_E < n_ ? (uint64_t)my_tiles_ * GA_E : n_;
+        o->level_a_elems = my_elems_;
         o->slot_splits = slot_stats_[0]; o->slot_splits_redone = slot_stats_[1];
     }
 
@@ -173,6 +176,16 @@ public:
         be_.sync();
         ms_phase1_ = be_.elapsed_ms(e0, e1);
         be_.release_events();
+    }
+
+    // the sorted subarrays of this rank after phase1 (differential tests): local element i of subarray g is at g * s + i
+    void phase1_arrays(void* d_keys_out, void* d_sa_out, uint64_t* count, uint64_t* subarray_len) override
+    {
+        *count = local_n_;
+        *subarray_len = s_;
+        if (d_keys_out && cur_.key) be_.d2d(d_keys_out, cur_.key, local_n_ * sizeof(uint64_t));
+        if (d_sa_out && cur_.sa) be_.d2d(d_sa_out, cur_.sa, local_n_ * sizeof(idx_t));
+        be_.sync();
     }
 
     void pivots(const void* d_all_keys, const void* d_all_sa, void* d_local_sizes) override
@@ -488,7 +501,7 @@ private:
     int direct_fb_ = CAPS_SA_FB_SHAPE;
     bool direct_planned_ = false;
     uint32_t PG_ = 0, K1_ = 0, SUB_ = 1, n_streams_ = 0, my_tiles_ = 0;
-    uint64_t capA_ = 0;
+    uint64_t capA_ = 0, my_elems_ = 0;
     uint64_t *gkey_ = nullptr, *dstat_ = nullptr;
     uint16_t* glut_ = nullptr;
     idx_t* dcur_ = nullptr;

@@ -145,6 +145,14 @@ int caps_sa_hip_verify_device_u32(const void* dT, uint64_t n, const void* dSA, c
 int caps_sa_hip_verify_device_u64(const void* dT, uint64_t n, const void* dSA, const void* dLCP,
                                   void* hip_stream, uint64_t* n_errors);
 
+/* The same checks on a SLICE of the arrays (cnt entries starting anywhere in the suffix array: one rank's share of a
+ * sharded build): values in range and none twice within the slice, adjacent order, exact LCP; is_head != 0: entry 0 is
+ * the head of the suffix array (its LCP must be 0), else entry 0's LCP is not checked (its predecessor is not in the slice). */
+int caps_sa_hip_verify_slice_device_u32(const void* dT, uint64_t n, const void* dSA, const void* dLCP, uint64_t cnt,
+                                        int is_head, void* hip_stream, uint64_t* n_errors);
+int caps_sa_hip_verify_slice_device_u64(const void* dT, uint64_t n, const void* dSA, const void* dLCP, uint64_t cnt,
+                                        int is_head, void* hip_stream, uint64_t* n_errors);
+
 /* ---- kernel-level entry points (host buffers) for differential tests -------------- */
 
 /* merge_sort (src/Suffix_Array.cpp:112-129) of an arbitrary list of cnt distinct suffix
@@ -253,6 +261,10 @@ int caps_sa_hip_shard_phase2(caps_sa_shard* s, const void* d_recv_keys, const vo
 int caps_sa_hip_shard_scatter(caps_sa_shard* s, void* d_send_keys, void* d_send_sa, void* d_report);
 int caps_sa_hip_shard_plan(caps_sa_shard* s, const uint64_t* all_reports, uint64_t* send_counts, uint64_t* recv_counts);
 int caps_sa_hip_shard_sort(caps_sa_shard* s, const void* d_recv_keys, const void* d_recv_sa, void* dSA, void* dLCP);
+/* Differential tests: copies this rank's sorted subarrays after shard_phase1 into d_keys_out (u64[count]) / d_sa_out
+ * (idx[count]) (either may be NULL: sizes only); subarray g of the rank = entries [g * subarray_len, (g + 1) * subarray_len),
+ * the last one to the end. */
+int caps_sa_hip_shard_phase1_arrays(caps_sa_shard* s, void* d_keys_out, void* d_sa_out, uint64_t* count, uint64_t* subarray_len);
 /* last SA value of the slice (UINT64_MAX when the slice is empty) */
 int caps_sa_hip_shard_last_sa(caps_sa_shard* s, uint64_t* last_sa);
 /* prev_sa: last SA value of the nearest non-empty lower rank (UINT64_MAX: none) */
