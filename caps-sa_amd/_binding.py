@@ -55,7 +55,7 @@ class Stats(ctypes.Structure):
         ("path_direct", ctypes.c_uint32),
         ("path_fallback", ctypes.c_uint32),
         ("direct_groups", ctypes.c_uint32),
-        ("direct_reserved_", ctypes.c_uint32),
+        ("direct_quantile", ctypes.c_uint32),
         ("direct_max_group", ctypes.c_uint64),
         ("level_a_ms", ctypes.c_double),
     ]

@@ -1956,16 +1956,29 @@ constexpr uint32_t SPLIT_LUT_CELLS = 1u << SPLIT_LUT_BITS;
 // word index (in P) of the first staged word for a tile whose first text position is pos0
 template <int BITS> HD uint64_t text_win_base(uint64_t pos0) { return pos0 / TextTraits<BITS>::CPW; }
 
+// MAP: how a key finds its bucket inside its parent segment --
+//   MAP_LINEAR   linear interpolation over the segment's key range (bps[g]);
+//   MAP_GROUPED  equalised split: fine linear bucket (fbps[g]) -> group table (gfirst) -> bucket slot;
+//   MAP_SPLIT    splitter table: bucket = #{splitters < key} among the bps[g].B - 1 sorted keys of the segment's table
+//                (split + parent * split_stride, parent = g / in_sub; one table for all when split_stride = 0), staged in
+//                LDS and searched branch-free in lockstep for the thread's elements -- through a LUT over the keys' top
+//                bits when split_lut is given (level A of the direct path: one table over the whole key range), from
+//                scratch otherwise (level B in quantile mode: the knots of the segment's group).  Keys only: all
+//                suffixes with one key value land in one bucket, so buckets are consecutive slices of the suffix order.
+constexpr int MAP_LINEAR = 0, MAP_GROUPED = 1, MAP_SPLIT = 2;
+
 // Persistent workgroups (a tile is little work: launching one workgroup per tile is bound by
 // the wave launch rate).
-template <typename idx_t, int BITS, int SRC>
+template <typename idx_t, int BITS, int SRC, int MAP = MAP_LINEAR>
 GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_count_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n_words,
                                                      uint64_t text_base, const uint64_t* __restrict__ in_key, RunSrc<idx_t> rsrc,
                                                      const BucketParams* __restrict__ bps, const uint64_t* __restrict__ bstart,
-                                                     uint64_t* __restrict__ count)
+                                                     uint64_t* __restrict__ count, const uint64_t* __restrict__ split,
+                                                     uint32_t split_stride, uint32_t in_sub)
 {
     constexpr bool FROM_TEXT = SRC == SRC_TEXT, FROM_RUNS = SRC == SRC_RUNS;
     SHARED_ARRAY(uint32_t, hist, BUCKET_LDS);
+    SHARED_ARRAY(uint64_t, stab, MAP == MAP_SPLIT ? BUCKET_LDS : 1);
     SHARED_ARRAY(uint32_t, twin, FROM_TEXT ? TEXT_WIN : 1);
     SHARED_ARRAY(uint64_t, lsrc, FROM_RUNS ? TILE_E : 1);
     SHARED_ARRAY(idx_t, lrow, FROM_RUNS ? TILE_E : 1);
@@ -1985,25 +1998,48 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_count_kernel(KCTX SegDesc sd, const uint
         const bool lds = bp.B <= BUCKET_LDS;
         const uint64_t w0 = text_win_base<BITS>(text_base + start);
         RUNS_TILE_SETUP
+        const uint32_t n_split = MAP == MAP_SPLIT ? bp.B - 1 : 0u;
+        const uint64_t* tab = MAP == MAP_SPLIT ? split + (uint64_t)(g / in_sub) * split_stride : nullptr;
         PAR(tid) {
             if (lds) for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM) hist[i] = 0;
+            if (MAP == MAP_SPLIT && lds) for (uint32_t i = tid; i < n_split; i += K_BLOCK_DIM) stab[i] = tab[i];
             if (FROM_TEXT)
                 for (uint32_t i = tid; i < TEXT_WIN; i += K_BLOCK_DIM) twin[i] = w0 + i < n_words ? P[w0 + i] : 0u;
             if (FROM_RUNS) { RUNS_STAGE(tid) }
         }
         SYNC();
+        const uint32_t top = pow2_above(n_split);
         PAR(tid) {
+            uint64_t key[TILE_EPT];
+            uint32_t bk[TILE_EPT];
+            UNROLL
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                const uint32_t e = tid + k * TILE_NT;
+                key[k] = 0;
+                if (e < cnt)
+                    key[k] = FROM_TEXT ? window64<BITS>(twin, text_base + start + e - w0 * TextTraits<BITS>::CPW)
+                           : FROM_RUNS ? in_key[run_source<idx_t>(rsrc, runs_staged, lrow, lsrc, run_ns, run_rowR, run_rowA,
+                                                                  run_a, run_b, run_x0 + e)]
+                                       : in_key[start + e];
+                bk[k] = MAP == MAP_SPLIT ? 0u : bucket_of(bp, key[k]);
+            }
+            if (MAP == MAP_SPLIT) {
+                const uint64_t* tb = lds ? stab : tab;                        // more knots than LDS holds: search in HBM
+                for (uint32_t st = top >> 1; st >= 1; st >>= 1) {
+                    UNROLL
+                    for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                        const uint32_t idx = bk[k] + st - 1;
+                        const uint64_t mk = tb[idx < n_split ? idx : n_split - 1];
+                        if (idx < n_split && mk < key[k]) bk[k] += st;
+                    }
+                }
+            }
             UNROLL
             for (uint32_t k = 0; k < TILE_EPT; ++k) {
                 const uint32_t e = tid + k * TILE_NT;
                 if (e < cnt) {
-                    const uint64_t key = FROM_TEXT ? window64<BITS>(twin, text_base + start + e - w0 * TextTraits<BITS>::CPW)
-                                       : FROM_RUNS ? in_key[run_source<idx_t>(rsrc, runs_staged, lrow, lsrc, run_ns, run_rowR, run_rowA,
-                                                                              run_a, run_b, run_x0 + e)]
-                                                   : in_key[start + e];
-                    const uint32_t bk = bucket_of(bp, key);
-                    if (lds) FETCH_ADD_U32(&hist[bk], 1u);
-                    else ATOMIC_ADD_U64(&count[b0 + bk], 1ull);
+                    if (lds) FETCH_ADD_U32(&hist[bk[k]], 1u);
+                    else ATOMIC_ADD_U64(&count[b0 + bk[k]], 1ull);
                 }
             }
         }
@@ -2023,14 +2059,6 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_count_kernel(KCTX SegDesc sd, const uint
 // cursor bump per (tile, non-empty bucket); the tile is then re-ordered by bucket in LDS so
 // that consecutive lanes write consecutive slots (a bucket receives a run of consecutive
 // elements from every tile instead of 64 scattered 8-byte stores per wave instruction).
-// MAP: how a key finds its bucket inside its parent segment --
-//   MAP_LINEAR   linear interpolation over the segment's key range (bps[g]);
-//   MAP_GROUPED  equalised split: fine linear bucket (fbps[g]) -> group table (gfirst) -> bucket slot;
-//   MAP_SPLIT    splitter table (direct path, level A): bucket = #{splitters < key} among the bps[g].B - 1 sorted keys
-//                split[0 .. B-2], staged in LDS and searched branch-free in lockstep for the thread's elements.  Keys only:
-//                all suffixes with one key value land in one bucket, so buckets are consecutive slices of the suffix order.
-constexpr int MAP_LINEAR = 0, MAP_GROUPED = 1, MAP_SPLIT = 2;
-
 template <typename idx_t, int BITS, int SRC, int MAP>
 GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n_words,
                                                        uint64_t text_base, const uint64_t* __restrict__ in_key,
@@ -2041,7 +2069,8 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
                                                        uint64_t* __restrict__ out_key, idx_t* __restrict__ out_sa,
                                                        const BucketParams* __restrict__ fbps, const uint32_t* __restrict__ gfirst,
                                                        const uint64_t* __restrict__ split, const uint16_t* __restrict__ split_lut,
-                                                       const uint32_t* __restrict__ split_span, uint32_t sub)
+                                                       const uint32_t* __restrict__ split_span, uint32_t sub, uint32_t split_stride,
+                                                       uint32_t in_sub)
 {
     // sub > 1 (slots only; level A of the direct path): bucket i owns `sub` slots, one per sub-stream; the tiles of a
     // launch are dealt to the sub-streams round-robin by block index, i.e. (observed dispatch order, MI355X_MICROARCH
@@ -2102,13 +2131,14 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
                   "text window + splitter table fit the key staging array");
     static_assert((SPLIT_LUT_CELLS + 1) * sizeof(uint16_t) <= TILE_E * sizeof(idx_t), "splitter LUT fits the index staging array");
     const uint32_t n_split = MAP == MAP_SPLIT && bp.B > 1 ? bp.B - 1 : 0u;
+    const uint64_t* tab = MAP == MAP_SPLIT ? split + (uint64_t)(g / in_sub) * split_stride : nullptr;
     RUNS_TILE_SETUP
     if (lds || FROM_TEXT || FROM_RUNS) {
         PAR(tid) {
             if (lds) for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0;
             if (MAP == MAP_SPLIT && lds) {
-                for (uint32_t i = tid; i < n_split; i += K_BLOCK_DIM) stab[i] = split[i];
-                for (uint32_t i = tid; i <= SPLIT_LUT_CELLS; i += K_BLOCK_DIM) slut[i] = split_lut[i];
+                for (uint32_t i = tid; i < n_split; i += K_BLOCK_DIM) stab[i] = tab[i];
+                if (split_lut) for (uint32_t i = tid; i <= SPLIT_LUT_CELLS; i += K_BLOCK_DIM) slut[i] = split_lut[i];
             }
             if (grouped)                                   // slot i owns the fine buckets [gfirst[i], gfirst[i + 1]) (F for unused slots)
                 for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM) {
@@ -2123,7 +2153,8 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
     }
     if (MAP == MAP_SPLIT && lds) {
         // keys first, then the TILE_EPT table searches of a thread in lockstep (independent LDS reads in flight together)
-        const uint32_t top = pow2_above(split_span[0]);      // candidates per LUT cell (block-uniform): depth of the search
+        // depth of the search: the candidates per LUT cell (block-uniform), or all of the table without a LUT
+        const uint32_t top = pow2_above(split_lut ? split_span[0] : n_split);
         TL_DECL(uint32_t, rh, TILE_EPT);
         PAR(tid) {
             UNROLL
@@ -2139,8 +2170,8 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
                 const uint32_t cell = (uint32_t)(key >> (64 - SPLIT_LUT_BITS));
                 TL(rk, tid, k) = key;
                 TL(rs, tid, k) = sa;
-                TL(rb, tid, k) = slut[cell];
-                TL(rh, tid, k) = slut[cell + 1];
+                TL(rb, tid, k) = split_lut ? slut[cell] : 0u;
+                TL(rh, tid, k) = split_lut ? slut[cell + 1] : n_split;
             }
             for (uint32_t s = top >> 1; s >= 1; s >>= 1) {
                 UNROLL
@@ -2174,7 +2205,7 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
                 else {
                     if (MAP == MAP_SPLIT) {                                  // too many splitters for the LDS table: search in HBM
                         uint32_t a = 0, z = bp.B - 1;
-                        while (a < z) { const uint32_t mid = (a + z) >> 1; if (split[mid] < key) a = mid + 1; else z = mid; }
+                        while (a < z) { const uint32_t mid = (a + z) >> 1; if (tab[mid] < key) a = mid + 1; else z = mid; }
                         bk = a;
                     } else {
                         bk = bucket_of(fbp, key);
@@ -2280,8 +2311,11 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) group_scatter_kernel(KCTX
                                                       const uint16_t* __restrict__ split_lut, const uint32_t* __restrict__ split_span,
                                                       uint32_t sub, uint64_t slot_cap, idx_t* __restrict__ cursor,
                                                       uint64_t* __restrict__ out_key, idx_t* __restrict__ out_sa,
-                                                      uint32_t tile_first, uint32_t tile_stride)
+                                                      uint32_t tile_first, uint32_t tile_stride,
+                                                      const uint64_t* __restrict__ region_start, const uint64_t* __restrict__ region_cap)
 {
+    // region_start != null: stream s = g * sub + sx owns [region_start[s], + region_cap[s]) instead of the uniform
+    // [s * slot_cap, + slot_cap) -- groups that share a frequent key get the room of all of them (group_caps_kernel).
     // Workgroup b takes tile tile_first + b * tile_stride of [text_base, text_base + len): a rank of a sharded build takes
     // every world-th tile (its share of the text is then a fine-grained interleave, balanced whatever the text's composition
     // does along its length); one GPU: tile_first = 0, tile_stride = 1.
@@ -2349,7 +2383,9 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) group_scatter_kernel(KCTX
             idx_t ob = 0;
             if (c) {
                 const idx_t old = caps_fetch_add(&cursor[(uint64_t)sx * K1 + i], (idx_t)c);
-                ob = (uint64_t)old + c <= slot_cap ? (idx_t)(((uint64_t)i * sub + sx) * slot_cap + old) : NO_SLOT;
+                const uint64_t st = (uint64_t)i * sub + sx;
+                const uint64_t r0 = region_start ? region_start[st] : st * slot_cap, rc = region_start ? region_cap[st] : slot_cap;
+                ob = (uint64_t)old + c <= rc ? (idx_t)(r0 + old) : NO_SLOT;
             }
             obase[i] = ob;
         }
@@ -2517,9 +2553,21 @@ GLOBAL_FN LAUNCH_BOUNDS(256) sample_text_kernel(KCTX const uint32_t* __restrict_
 GLOBAL_FN LAUNCH_BOUNDS(256) group_keys_kernel(KCTX const uint64_t* __restrict__ pkey, uint32_t p, uint32_t PG, uint32_t K1,
                                                uint64_t* __restrict__ gkey, uint32_t* __restrict__ flag)
 {
+    // flag[3] = longest run of pivots with one key (how much of the text a single key value covers, in partitions)
     PAR(tid) {
         const uint32_t j = K_BLOCK_IDX * K_BLOCK_DIM + tid;
-        if (j + 2 < p && pkey[j] >= pkey[j + 1]) flag[0] = 1;           // benign race: every writer stores 1
+        if (j + 2 < p && pkey[j] >= pkey[j + 1]) {
+            flag[0] = 1;                                                // benign race: every writer stores 1
+            if (j == 0 || pkey[j - 1] != pkey[j]) {                     // head of a run
+                uint32_t len = 2;
+                while (j + len < p - 1 && pkey[j + len] == pkey[j]) ++len;
+#ifdef CAPS_EMUL
+                if (len > flag[3]) flag[3] = len;
+#else
+                atomicMax(&flag[3], len);
+#endif
+            }
+        }
         if (j + 1 < K1) gkey[j] = pkey[(uint64_t)(j + 1) * PG - 1];
     }
 }
@@ -2561,22 +2609,111 @@ GLOBAL_FN LAUNCH_BOUNDS(256) split_lut_kernel(KCTX const uint64_t* __restrict__ 
 // The groups as segments in fixed-capacity regions: group g = [g * cap, g * cap + size_g) of the level-A output.
 template <typename idx_t>
 GLOBAL_FN LAUNCH_BOUNDS(256) slot_segments_kernel(KCTX const idx_t* __restrict__ sizes, uint32_t K1, uint32_t sub, uint32_t stream_major,
-                                                  uint64_t cap, uint64_t* __restrict__ seg_start, uint64_t* __restrict__ seg_end,
-                                                  uint64_t* __restrict__ total)
+                                                  uint64_t cap, const uint64_t* __restrict__ region_start,
+                                                  const uint64_t* __restrict__ region_cap, uint64_t* __restrict__ seg_start,
+                                                  uint64_t* __restrict__ seg_end, uint64_t* __restrict__ total)
 {
     // segment s = g * sub + x is sub-stream x of group g; its size is sizes[x * K1 + g] (stream_major: group_scatter_kernel's
-    // cursors) or sizes[s] (bucket_scatter_kernel's)
+    // cursors) or sizes[s] (bucket_scatter_kernel's); its region: [s * cap, + cap), or region_start / region_cap when given
     PAR(tid) {
         const uint32_t G = K1 * sub;
         const uint32_t s = K_BLOCK_IDX * K_BLOCK_DIM + tid;
         if (s < G) {
             const uint64_t z = (uint64_t)sizes[stream_major ? (uint64_t)(s % sub) * K1 + s / sub : s];
-            seg_start[s] = (uint64_t)s * cap;
-            seg_end[s] = (uint64_t)s * cap + (z < cap ? z : cap);      // an overflowed stream is reported through total[1]
+            const uint64_t r0 = region_start ? region_start[s] : (uint64_t)s * cap, rc = region_start ? region_cap[s] : cap;
+            seg_start[s] = r0;
+            seg_end[s] = r0 + (z < rc ? z : rc);                       // an overflowed stream is reported through total[1]
             ATOMIC_ADD_U64(total, z);
-            if (z > cap) ATOMIC_MAX_U64(total + 1, z);
+            if (z > rc) ATOMIC_MAX_U64(total + 1, z);
         }
-        if (s == G) seg_start[s] = (uint64_t)G * cap;
+        if (s == G) seg_start[s] = region_start ? region_start[G - 1] + region_cap[G - 1] : (uint64_t)G * cap;
+    }
+}
+
+// ---- quantile mode of the direct path (skewed key distributions: every real genome) ------------------------
+// skew_probe_kernel: the pivots are quantiles (equal numbers of suffixes between consecutive ones); level B's linear
+// bucket map over a group's key range assumes they are also equally SPACED inside the group.  flag[0] |= 1 when some
+// partition's share of its group's key range is below SKEW_MIN / (partitions in the group): its buckets would overflow.
+constexpr double SKEW_MIN = 0.7;          // uniform keys: 1 +- 4 % (sampling noise of ppp = 700 samples per partition)
+
+GLOBAL_FN LAUNCH_BOUNDS(256) skew_probe_kernel(KCTX const uint64_t* __restrict__ pkey, uint32_t p, uint32_t PG, uint32_t K1,
+                                               uint32_t* __restrict__ flag)
+{
+    PAR(tid) {
+        const uint32_t j = K_BLOCK_IDX * K_BLOCK_DIM + tid;           // partition j = keys in (pkey[j-1], pkey[j]]
+        if (j < p) {
+            const uint32_t g = j / PG, j0 = g * PG, j1 = (j0 + PG < p ? j0 + PG : p);      // its group: partitions [j0, j1)
+            if (j1 - j0 >= 2) {
+                const double glo = j0 ? (double)pkey[j0 - 1] : 0.0, ghi = j1 < p ? (double)pkey[j1 - 1] : 18446744073709551615.0;
+                const double lo = j ? (double)pkey[j - 1] : 0.0, hi = j + 1 < p ? (double)pkey[j] : 18446744073709551615.0;
+                if (ghi > glo && (hi - lo) * (double)(j1 - j0) < SKEW_MIN * (ghi - glo)) flag[0] = 1;
+            }
+        }
+    }
+}
+
+// knots[k] (k < NB - 1) = the sample at quantile (k + 1) / NB of the sorted samples: bucket k holds the keys in
+// (knots[k-1], knots[k]]; the groups are runs of KPG consecutive buckets, gkey[g] = knots[(g + 1) * KPG - 1].
+GLOBAL_FN LAUNCH_BOUNDS(256) knots_kernel(KCTX const uint64_t* __restrict__ skey, uint64_t m, uint64_t NB, uint32_t KPG, uint32_t K1,
+                                          uint64_t* __restrict__ knots, uint64_t* __restrict__ gkey)
+{
+    PAR(tid) {
+        const uint64_t k = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (k < NB) {
+            // the last bucket of the last group ends at the top of the key range
+            const uint64_t v = k + 1 < NB ? skey[((k + 1) * m) / NB] : ~0ull;
+            knots[k] = v;
+            if ((k + 1) % KPG == 0 && (k + 1) / KPG < K1) gkey[(k + 1) / KPG - 1] = v;
+        }
+    }
+}
+
+// Capacity of the streams of every group in quantile mode.  Every bucket is expected to hold n / NB suffixes -- except
+// that all suffixes of a frequent key land in the FIRST of the buckets whose knot is that key (the others, (key, key],
+// stay empty).  So group g is expected to hold (KPG - lead + tail) buckets' worth: lead = its leading buckets that repeat
+// the previous group's last knot (empty), tail = the buckets of later groups that repeat its own last knot (theirs go to g).
+// caps[g * sub + x] = base * (KPG - lead + tail) / KPG + token: the shares add up to base * K1.
+GLOBAL_FN LAUNCH_BOUNDS(256) group_caps_kernel(KCTX const uint64_t* __restrict__ knots, uint64_t NB, uint32_t KPG, uint32_t K1,
+                                               uint32_t sub, uint64_t base, uint64_t token, uint64_t* __restrict__ caps)
+{
+    PAR(tid) {
+        const uint32_t g = K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (g < K1) {
+            const uint64_t k0 = (uint64_t)g * KPG, k1 = k0 + KPG;       // the group's buckets [k0, k1)
+            uint64_t lead = 0, tail = 0;
+            if (g > 0) while (k0 + lead < k1 && knots[k0 + lead] == knots[k0 - 1]) ++lead;
+            if (lead < KPG) while (k1 + tail < NB && knots[k1 + tail] == knots[k1 - 1]) ++tail;
+            const uint64_t worth = KPG - lead + tail;
+            const uint64_t c = base * worth / KPG + token;              // base < 2^33, worth < 2^22
+            for (uint32_t x = 0; x < sub; ++x) caps[(uint64_t)g * sub + x] = c;
+        }
+    }
+}
+
+// Quantile mode's counterpart of bucket_plan_kernel: every parent (group) has exactly KPG buckets; all its `sub`
+// sub-streams carry that map, the bucket count is credited to the last one (see bucket_plan_kernel).
+GLOBAL_FN LAUNCH_BOUNDS(256) knot_plan_kernel(KCTX uint32_t G, uint32_t sub, uint32_t KPG, BucketParams* __restrict__ bp,
+                                              uint64_t* __restrict__ segB)
+{
+    PAR(tid) {
+        const uint32_t g = K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (g < G) {
+            BucketParams q = make_bucket_params(0, ~0ull, KPG);     // only B is used by MAP_SPLIT
+            bp[g] = q;
+            segB[g] = (g % sub == sub - 1 || g == G - 1) ? KPG : 0;
+        }
+    }
+}
+
+// The tile sort's bin map of every bucket in quantile mode: linear over (knots[i-1], knots[i]].
+GLOBAL_FN LAUNCH_BOUNDS(256) knot_ranges_kernel(KCTX const uint64_t* __restrict__ knots, uint64_t NB, BucketParams* __restrict__ tile_map)
+{
+    PAR(tid) {
+        const uint64_t i = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (i < NB) {
+            const uint64_t lo = i ? knots[i - 1] : 0, hi = knots[i];
+            tile_map[i] = make_bucket_params(lo < hi ? lo + (i ? 1 : 0) : hi, hi, TILE_BINS);
+        }
     }
 }
 

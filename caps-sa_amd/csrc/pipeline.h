@@ -71,6 +71,10 @@ constexpr uint32_t kMaxPasses = 96;
 #define CAPS_DIRECT_SUB 8
 #endif
 constexpr uint32_t DIRECT_SUB = CAPS_DIRECT_SUB;
+// Quantile mode of the direct path (skewed keys): mean bucket size (sampling noise on top: sigma = 1 / sqrt(QUANTILE_SPB)) and
+// samples drawn per bucket.
+constexpr uint32_t BUCKET_Q = (TILE_E * 3) / 4;
+constexpr uint32_t QUANTILE_SPB = 48;
 
 // Fine buckets per bucket slot of the equalised split (bucket_group_kernel), as far as the LDS histograms hold them.
 #ifndef CAPS_EQ_FINE
@@ -98,7 +102,8 @@ struct BucketBufs {
     uint32_t* gfirst = nullptr;       // [nb_cap] first fine bucket of every slot's group
     uint32_t nb_cap = 0;
     uint64_t tile_cap = 0;
-    static uint32_t bucket_bound(uint64_t n_elems, uint32_t G) { return (uint32_t)(n_elems / BUCKET_TARGET + 2 * (uint64_t)G + 2); }
+    // buckets of a sort: mean size BUCKET_TARGET (linear maps) or BUCKET_Q (quantile mode), at least two per segment
+    static uint32_t bucket_bound(uint64_t n_elems, uint32_t G) { return (uint32_t)(n_elems / BUCKET_Q + 2 * (uint64_t)G + 2); }
 };
 
 template <typename idx_t> struct Plan {
@@ -117,9 +122,13 @@ template <typename idx_t> struct Plan {
     idx_t* rulerT = nullptr;
     uint64_t* sizes = nullptr;
     uint64_t* gkey = nullptr;        // [p]   direct path: the pivot keys that close the groups
-    uint64_t* dstat = nullptr;       // [4]   direct path: {elements scattered, largest overflowed group, (u32 pivot-tie flag, u32 LUT span), -}
+    uint64_t* dstat = nullptr;       // [4]   direct path: {elements scattered, largest overflowed stream, (u32 pivot-tie flag, u32 LUT span),
+                                     //         (u32 skew flag, u32 longest run of equal pivot keys)}
     idx_t* dcur = nullptr;           // [gseg] direct path: level A's cursors = sizes of the groups' sub-streams
     uint16_t* glut = nullptr;        // [SPLIT_LUT_CELLS + 1] direct path: LUT over the group keys (split_lut_kernel)
+    uint64_t* knots = nullptr;       // [nb_cap] quantile mode: upper key of every bucket
+    uint64_t* rcap = nullptr;        // [gseg]   quantile mode: capacity of every stream's region
+    uint64_t* rstart = nullptr;      // [gseg+1]                 ... and where it starts
     uint64_t* partial = nullptr;     // [PART_CHUNKS * p] partial column sums of Pm
     SegBufs seg1, seg2, segS;
     TileDesc* desc = nullptr;        // [tile_cap] per-pass tile descriptors
@@ -193,6 +202,9 @@ Plan<idx_t> make_plan(uint64_t n, uint64_t p_arg, char* base)
         pl.dstat = ar.take<uint64_t>(4);
         pl.dcur = ar.take<idx_t>(gseg);
         pl.glut = ar.take<uint16_t>(SPLIT_LUT_CELLS + 2);
+        pl.knots = ar.take<uint64_t>(pl.bk.nb_cap);
+        pl.rcap = ar.take<uint64_t>(gseg);
+        pl.rstart = ar.take<uint64_t>((size_t)gseg + 1);
         pl.partial = ar.take<uint64_t>((size_t)PART_CHUNKS * p);
         segs(pl.seg2, gseg, pl.tile_cap);
         pl.seg2.G = p;
@@ -382,6 +394,8 @@ struct SortOpts {
     uint32_t sub = 1;             // > 1: every `sub` consecutive segments are sub-streams of one parent and share its buckets
     const uint64_t* in_key = nullptr;   // non-null: the elements are read from these arrays (indexed like the segments)
     const void* in_sa = nullptr;        //   instead of `cur`, which then only receives results
+    const uint64_t* knots = nullptr;    // non-null (quantile mode): parent q's buckets are (knots[q * KPG + i - 1], knots[q * KPG + i]],
+    uint32_t knots_per_parent = 0;      //   i < KPG = knots_per_parent -- count pass + exact scatter, no slots, no equalising
     const void* runs = nullptr;   // RunSrc<idx_t>*: the segments are partitions still spread over the sorted subarrays in
                                   //   `cur` (requires the bucket split: bk != null and max_len > TILE_E)
     bool unify = false;           // gather the result into buf[0] (consumers that index whole segments)
@@ -427,6 +441,14 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         const BucketBufs& bk = *o.bk;
         const SegDesc psd = s.desc();
         const uint64_t* s_end = o.seg_ends ? (const uint64_t*)s.seg_end : (const uint64_t*)nullptr;
+        const bool by_knots = o.knots != nullptr;
+        if (by_knots) {
+            const uint64_t NB = (uint64_t)(s.G / o.sub) * o.knots_per_parent;
+            if (NB > bk.nb_cap) throw std::invalid_argument("more knot buckets than the bucket tables hold");
+            CAPS_LAUNCH(knot_plan_kernel, (s.G + 255) / 256, 256, be, s.G, o.sub, o.knots_per_parent, bk.params, bk.segB);
+            CAPS_LAUNCH(scan_sizes_kernel, 1, 1024, be, (const uint64_t*)bk.segB, s.G, bk.bstart);
+            CAPS_LAUNCH(knot_ranges_kernel, (uint32_t)((NB + 255) / 256), 256, be, o.knots, NB, bk.tile_map);
+        } else {
         CAPS_LAUNCH(bucket_plan_kernel, (s.G + 255) / 256, 256, be, (const uint64_t*)s.seg_start, s_end, s.G, o.range_mode, o.pkey, o.part_off,
                     o.part_total ? o.part_total : s.G, 1u, 1u, o.sub,
                     bk.params, bk.segB);
@@ -434,6 +456,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         CAPS_LAUNCH(bucket_ranges_kernel, (bk.nb_cap + 255) / 256, 256, be, (const uint64_t*)bk.bstart, s.G,
                     (const BucketParams*)bk.params, o.pkey, o.range_mode, o.part_off, o.part_total ? o.part_total : s.G, o.sub,
                     bk.tile_map, (const BucketParams*)nullptr, (const uint32_t*)nullptr);
+        }
         seg_map = bk.tile_map;
         mark("bucket plan");
         const uint32_t pgrid = n_tiles < be.persistent_blocks() ? n_tiles : be.persistent_blocks();
@@ -451,12 +474,13 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
 #define CAPS_SCATTER_LAUNCH(SRC_, MAP_, ikey, isa)                                                                          \
             CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, SRC_, MAP_>), n_tiles, TILE_NT, be, psd, P, n_words, tbase, ikey, isa, rsrc, \
                         (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, sub_start, (uint64_t)cap, static_cast<idx_t*>(bk.cursor),       \
-                        okey, osa, fbps, gfirst, (const uint64_t*)nullptr, (const uint16_t*)nullptr, (const uint32_t*)nullptr, 1u)
+                        okey, osa, fbps, gfirst, o.knots, (const uint16_t*)nullptr, (const uint32_t*)nullptr, 1u, o.knots_per_parent, o.sub)
             const uint64_t* nokey = nullptr;
             const idx_t* nosa = nullptr;
             if (from_text) { if (grouped) CAPS_SCATTER_LAUNCH(SRC_TEXT, MAP_GROUPED, nokey, nosa); else CAPS_SCATTER_LAUNCH(SRC_TEXT, MAP_LINEAR, nokey, nosa); }
             else if (runs) { if (grouped) CAPS_SCATTER_LAUNCH(SRC_RUNS, MAP_GROUPED, src_key, src_sa);
                              else CAPS_SCATTER_LAUNCH(SRC_RUNS, MAP_LINEAR, src_key, src_sa); }
+            else if (by_knots) CAPS_SCATTER_LAUNCH(SRC_ARRAYS, MAP_SPLIT, src_key, src_sa);
             else { if (grouped) CAPS_SCATTER_LAUNCH(SRC_ARRAYS, MAP_GROUPED, src_key, src_sa);
                    else CAPS_SCATTER_LAUNCH(SRC_ARRAYS, MAP_LINEAR, src_key, src_sa); }
 #undef CAPS_SCATTER_LAUNCH
@@ -479,9 +503,12 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         // slot buffer viewed over `oth`; the scatter's cursors end as the exact bucket sizes.  If every bucket fits
         // its slot (keys roughly uniform inside their ranges: random DNA) the tile sort reads the slots and writes
         // the buckets compactly into `cur`; otherwise the split is redone below with the count pass.
-        const uint64_t slot_elems = (uint64_t)bk.nb_cap * TILE_E;
+        // buckets this split can have: at most len / BUCKET_TARGET + 2 per parent segment (bucket_plan_kernel)
+        const uint64_t nb_here = std::min<uint64_t>(bk.nb_cap, n_elems / BUCKET_TARGET + 2 * (uint64_t)(s.G / o.sub) + 2);
+        const uint64_t slot_elems = nb_here * TILE_E;
         bool slots = false;
-        if (o.speculate && oth.region_bytes >= slot_elems * (sizeof(uint64_t) + sizeof(idx_t)) &&
+        if (by_knots && (from_text || runs)) throw std::invalid_argument("quantile buckets read (key, sa) arrays");
+        if (o.speculate && !by_knots && oth.region_bytes >= slot_elems * (sizeof(uint64_t) + sizeof(idx_t)) &&
             slot_elems + TILE_E < (uint64_t)std::numeric_limits<idx_t>::max()) {
             slot_key = oth.key;
             slot_sa = reinterpret_cast<idx_t*>(reinterpret_cast<char*>(oth.key) + slot_elems * sizeof(uint64_t));
@@ -499,7 +526,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
             // Count split.  Equalised (bk.fcount): the count pass fills EQ_FINE times finer buckets, bucket_group_kernel
             // packs consecutive fine buckets into the segment's bucket slots (exact sizes, balanced whatever the key
             // distribution inside the segment), and the scatter looks the slot up from the fine bucket.
-            const bool equalise = bk.fcount != nullptr && !o.no_equalise && !std::getenv("CAPS_SA_NO_EQUALISE");
+            const bool equalise = !by_knots && bk.fcount != nullptr && !o.no_equalise && !std::getenv("CAPS_SA_NO_EQUALISE");
             const BucketParams* cparams = bk.params;
             const uint64_t* cstart = bk.bstart;
             uint64_t* ccount = bk.count;
@@ -515,15 +542,19 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
             be.memset(bk.count, 0, (size_t)bk.nb_cap * sizeof(uint64_t));
             be.memset(bk.cursor, 0, (size_t)bk.nb_cap * sizeof(idx_t));
             BackendEvent c0 = be.record();
+            const uint64_t* no_tab = nullptr;
             if (from_text)
                 CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, SRC_TEXT>), pgrid, TILE_NT, be, psd, P, n_words, tbase, (const uint64_t*)nullptr, rsrc,
-                            cparams, cstart, ccount);
+                            cparams, cstart, ccount, no_tab, 0u, 1u);
             else if (runs)
                 CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, SRC_RUNS>), pgrid, TILE_NT, be, psd, P, n_words, tbase, src_key, rsrc,
-                            cparams, cstart, ccount);
+                            cparams, cstart, ccount, no_tab, 0u, 1u);
+            else if (by_knots)
+                CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, SRC_ARRAYS, MAP_SPLIT>), pgrid, TILE_NT, be, psd, P, n_words, tbase, src_key, rsrc,
+                            cparams, cstart, ccount, o.knots, o.knots_per_parent, o.sub);
             else
                 CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, SRC_ARRAYS>), pgrid, TILE_NT, be, psd, P, n_words, tbase, src_key, rsrc,
-                            cparams, cstart, ccount);
+                            cparams, cstart, ccount, no_tab, 0u, 1u);
             if (equalise) {
                 CAPS_LAUNCH(bucket_group_kernel, s.G < 16384 ? (s.G ? s.G : 1) : 16384, 256, be, s.G, (const uint64_t*)bk.segB, (const uint64_t*)bk.bstart,
                             (const uint64_t*)bk.fsegB, (const uint64_t*)bk.fstart, (const uint64_t*)bk.fcount, bk.count, bk.gfirst);
@@ -700,7 +731,7 @@ private:
     uint32_t passes1_ = 0, passes2_ = 0, passesS_ = 0;
     BackendEvent e2_, e3_, e4_, e5_, e6_, e7_, la0_, la1_;
     uint64_t max_part_ = 0;
-    uint32_t path_direct_ = 0, path_fallback_ = 0, direct_groups_ = 0;
+    uint32_t path_direct_ = 0, path_fallback_ = 0, direct_groups_ = 0, direct_quantile_ = 0;
     uint64_t direct_max_group_ = 0;
 
     // timed: the full-size sorts (phase 1, phase 2) feed the kernel clocks of caps_sa_stats;
@@ -881,10 +912,16 @@ private:
         be_.memset(pl_.dstat, 0, 4 * sizeof(uint64_t));
         uint32_t* dflag = reinterpret_cast<uint32_t*>(pl_.dstat + 2);
         CAPS_LAUNCH(group_keys_kernel, (p + 255) / 256, 256, be_, (const uint64_t*)pl_.pkey, p, PG, K1, pl_.gkey, dflag);
-        CAPS_LAUNCH(split_lut_kernel, (SPLIT_LUT_CELLS + 256) / 256, 256, be_, (const uint64_t*)pl_.gkey, K1 - 1, pl_.glut, dflag + 1);
-        e3_ = be_.record();
+        CAPS_LAUNCH(skew_probe_kernel, (p + 255) / 256, 256, be_, (const uint64_t*)pl_.pkey, p, PG, K1, dflag + 2);
+        uint32_t probe[4];
+        be_.d2h(probe, dflag, sizeof probe);
+        be_.sync();                                   // {pivot-key ties, -, skewed, longest run of equal pivot keys}
 
-        // ---- level A (a9 without a8): the text -> K1 groups, each as SUB sub-streams in their own regions of buffer A
+        // ---- how level B will cut the groups into buckets.  Linear: interpolation between the group's end keys, buckets
+        //      in fixed-capacity slots, no count pass -- right when the keys are about uniform inside a group.  Quantile:
+        //      bucket boundaries are quantiles of QUANTILE_SPB x more samples (count pass + exact scatter); the groups are
+        //      runs of KPG buckets, and groups that end at one and the same key (a frequent key: a long repeat, an N-block)
+        //      share the room of all of them.  Chosen when the pivots say so (ties or skew); CAPS_SA_DIRECT_MODE forces.
         const ElemBuf<idx_t>& A = pl_.A;
         const uint32_t n_tilesA = tiles_of(n);
         const char* sub_env = std::getenv("CAPS_SA_DIRECT_SUB");          // measurement: 1 = one stream per group
@@ -897,6 +934,48 @@ private:
         if (capA > idx_max / n_streams) capA = idx_max / n_streams;     // region offsets are idx_t in the scatter
         uint64_t* a_key = A.key;
         idx_t* a_sa = reinterpret_cast<idx_t*>(reinterpret_cast<char*>(A.key) + (uint64_t)n_streams * capA * sizeof(uint64_t));
+
+        const char* mode_env = std::getenv("CAPS_SA_DIRECT_MODE");
+        bool quantile = probe[0] != 0 || probe[2] != 0;
+        if (mode_env && std::string(mode_env) == "linear") quantile = false;
+        if (mode_env && std::string(mode_env) == "quantile") quantile = true;
+        const uint64_t NBt = (n + BUCKET_Q - 1) / BUCKET_Q;
+        const uint32_t KPG = (uint32_t)((NBt + K1 - 1) / K1);
+        const uint64_t NB = (uint64_t)K1 * KPG;
+        uint64_t m2 = NB * QUANTILE_SPB;
+        if (m2 > n / 4) m2 = n / 4;
+        if (quantile && (KPG < 2 || KPG > BUCKET_LDS || NB > pl_.bk.nb_cap || m2 < 8 * NB || m2 > (1ull << 31))) quantile = false;
+        // a single key that covers a large part of the text (a^n) is the samplesort path's business: its exact comparator
+        // splits such a stretch over the partitions, keys cannot
+        if (quantile && probe[3] > p / 32) { path_fallback_ = CAPS_SA_FB_PIVOT_TIES; return false; }
+        if (!quantile && probe[0] != 0) { path_fallback_ = CAPS_SA_FB_PIVOT_TIES; return false; }
+        uint64_t *rstart = nullptr, *rcap = nullptr;
+        direct_quantile_ = quantile ? 1u : 0u;
+        if (quantile) {
+            // more samples, sorted in the (still idle) big buffers; their quantiles are the bucket boundaries and, every KPG-th, the group keys
+            CAPS_LAUNCH((sample_text_kernel<idx_t, BITS>), (uint32_t)((m2 + 255) / 256), 256, be_, (const uint32_t*)pl_.P, (uint64_t)0, n, m2,
+                        pl_.A.key, pl_.A.sa);
+            SegBufs sseg = pl_.seg1;
+            sseg.G = 1;
+            CAPS_LAUNCH(uniform_segments_kernel, 1, 256, be_, sseg.seg_start, 1u, m2, m2);
+            prepare_segments(sseg, tiles_of(m2));
+            SortOpts oq;
+            oq.bk = &pl_.bk;
+            oq.unify = true;
+            SortResult<idx_t> rq = seg_sort<BITS>(sseg, tiles_of(m2), m2, pl_.A, pl_.B, m2, oq, false);
+            ElemBuf<idx_t> smp2 = rq.uniform();
+            CAPS_LAUNCH(knots_kernel, (uint32_t)((NB + 255) / 256), 256, be_, (const uint64_t*)smp2.key, m2, NB, KPG, K1, pl_.knots, pl_.gkey);
+            rstart = pl_.rstart;
+            rcap = pl_.rcap;
+            const uint64_t token = 2 * GA_E / K1 + 16;                   // room for the stray elements of an (expectedly) empty stream
+            CAPS_LAUNCH(group_caps_kernel, (K1 + 255) / 256, 256, be_, (const uint64_t*)pl_.knots, NB, KPG, K1, SUB,
+                        capA > token ? capA - token : capA, token, rcap);
+            CAPS_LAUNCH(scan_sizes_kernel, 1, 1024, be_, (const uint64_t*)rcap, n_streams, rstart);
+        }
+        CAPS_LAUNCH(split_lut_kernel, (SPLIT_LUT_CELLS + 256) / 256, 256, be_, (const uint64_t*)pl_.gkey, K1 - 1, pl_.glut, dflag + 1);
+        e3_ = be_.record();
+
+        // ---- level A (a9 without a8): the text -> K1 groups, each as SUB sub-streams in their own regions of buffer A
         CAPS_LAUNCH(uniform_segments_kernel, 1, 256, be_, pl_.seg1.seg_start, 1u, n, n);
         SegBufs whole = pl_.seg1;
         whole.G = 1;
@@ -914,13 +993,13 @@ private:
             if (big_tiles)
                 CAPS_LAUNCH((group_scatter_kernel<idx_t, BITS>), (uint32_t)((n + GA_E - 1) / GA_E), TILE_NT, be_, (const uint32_t*)pl_.P,
                             packed_words(n, BITS), (uint64_t)0, n, (const uint64_t*)pl_.gkey, K1, (const uint16_t*)pl_.glut,
-                            (const uint32_t*)(dflag + 1), SUB, capA, pl_.dcur, a_key, a_sa, 0u, 1u);
+                            (const uint32_t*)(dflag + 1), SUB, capA, pl_.dcur, a_key, a_sa, 0u, 1u, (const uint64_t*)rstart, (const uint64_t*)rcap);
             else
                 CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, SRC_TEXT, MAP_SPLIT>), n_tilesA, TILE_NT, be_, whole.desc(), (const uint32_t*)pl_.P,
                             packed_words(n, BITS), (uint64_t)0, (const uint64_t*)nullptr, (const idx_t*)nullptr, RunSrc<idx_t>(),
                             (const BucketParams*)pl_.bk.params, (const uint64_t*)pl_.bk.bstart, (const uint64_t*)nullptr, capA,
                             pl_.dcur, a_key, a_sa, (const BucketParams*)nullptr, (const uint32_t*)nullptr,
-                            (const uint64_t*)pl_.gkey, (const uint16_t*)pl_.glut, (const uint32_t*)(dflag + 1), SUB);
+                            (const uint64_t*)pl_.gkey, (const uint16_t*)pl_.glut, (const uint32_t*)(dflag + 1), SUB, 0u, 1u);
             BackendEvent s1 = be_.record();
             scatter_clock_.spans.push_back({s0, s1});
             scatter_clock_.elems.push_back(n);
@@ -930,7 +1009,7 @@ private:
         SegBufs groups = pl_.seg2;
         groups.G = n_streams;
         CAPS_LAUNCH((slot_segments_kernel<idx_t>), (n_streams + 256) / 256, 256, be_, (const idx_t*)pl_.dcur, K1, SUB, big_tiles ? 1u : 0u, capA,
-                    groups.seg_start, groups.seg_end, pl_.dstat);
+                    (const uint64_t*)rstart, (const uint64_t*)rcap, groups.seg_start, groups.seg_end, pl_.dstat);
         ::caps::prepare_segments(be_, groups, n / TILE_E + n_streams + 1, nullptr, nullptr, true);
         uint64_t out2[2], dstat[4];
         be_.d2h(out2, groups.out2, sizeof out2);
@@ -938,7 +1017,6 @@ private:
         be_.sync();                                   // out2 = {#tiles, largest sub-stream (clamped to its region)}
         direct_groups_ = K1;
         direct_max_group_ = dstat[1] ? dstat[1] : out2[1];
-        if ((uint32_t)dstat[2] != 0) { path_fallback_ = CAPS_SA_FB_PIVOT_TIES; return false; }
         if (dstat[1] != 0 || dstat[0] != n) { path_fallback_ = CAPS_SA_FB_GROUP_OVERFLOW; return false; }
         const uint32_t n_tiles2 = (uint32_t)out2[0];
         max_part_ = out2[1];
@@ -956,6 +1034,7 @@ private:
         o2.part_total = K1;
         o2.sub = SUB;
         o2.seg_ends = true;
+        if (quantile) { o2.knots = pl_.knots; o2.knots_per_parent = KPG; }
         o2.in_key = a_key;
         o2.in_sa = a_sa;
         set_final(o2, dSA, dLCP);
@@ -995,7 +1074,6 @@ private:
             uint32_t PG = 0, K1 = 0;
             const char* force = std::getenv("CAPS_SA_PATH");
             if (force && std::string(force) == "classic") path_fallback_ = CAPS_SA_FB_FORCED;
-            else if (be_.long_runs) path_fallback_ = CAPS_SA_FB_LONG_RUNS;
             else path_fallback_ = (uint32_t)direct_shape(n, p, pl_.m, &PG, &K1);
             if (path_fallback_ == CAPS_SA_FB_NONE && run_direct<BITS>(dSA, dLCP, PG, K1, e1)) path_direct_ = 1;
             else {
@@ -1042,6 +1120,7 @@ private:
             st->path_direct = path_direct_;
             st->path_fallback = path_fallback_;
             st->direct_groups = direct_groups_;
+            st->direct_quantile = direct_quantile_;
             st->direct_max_group = direct_max_group_;
             st->level_a_ms = direct_groups_ ? be_.elapsed_ms(la0_, la1_) : 0.0;
             st->slot_splits = slot_stats_[0];

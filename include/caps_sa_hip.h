@@ -72,7 +72,7 @@ typedef struct caps_sa_stats {
      * path_fallback: why a build that tried the direct path took the samplesort path after all (CAPS_SA_FB_*). */
     uint32_t path_direct, path_fallback;
     uint32_t direct_groups;        /* groups of consecutive partitions the text was scattered into */
-    uint32_t direct_reserved_;
+    uint32_t direct_quantile;      /* 1: level B's buckets were sample quantiles (skewed keys / frequent keys), 0: linear maps */
     uint64_t direct_max_group;     /* largest stream of a group (elements) */
     double level_a_ms;             /* direct path: the text -> groups scatter (also counted in bucket_scatter_ms) */
 } caps_sa_stats;
