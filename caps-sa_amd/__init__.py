@@ -52,13 +52,16 @@ class SuffixArray:
     unless ``idx_bits`` is given.
     """
 
-    def __init__(self, T, subproblem_count: int = 0, max_context: int = 0, idx_bits: int | None = None, device: int = 0):
+    def __init__(self, T, subproblem_count: int = 0, max_context: int = 0, idx_bits: int | None = None, device: int = 0,
+                 devices: list[int] | None = None, pinned: bool = False):
         self._T = CapsLib._text(T)
         self._n = int(self._T.size)
         self._p = int(subproblem_count)
         self._ctx = int(max_context)
         self._bits = idx_bits or (32 if self._n <= 0xFFFFFFFF else 64)
         self._device = device
+        self._devices = list(devices) if devices else None      # several GPUs from this process (caps_sa_hip_build_multi_*)
+        self._pinned = pinned                                    # page-locked result arrays (what the C++ mirror allocates)
         self._SA = None
         self._LCP = None
         self.stats: dict | None = None
@@ -70,7 +73,10 @@ class SuffixArray:
         return self._n
 
     def construct(self) -> None:
-        self._SA, self._LCP, self.stats = lib().build(self._T, self._p, self._ctx, self._bits, self._device)
+        if self._devices:
+            self._SA, self._LCP, self.stats = lib().build_multi(self._T, self._devices, self._p, self._ctx, self._bits, self._pinned)
+        else:
+            self._SA, self._LCP, self.stats = lib().build(self._T, self._p, self._ctx, self._bits, self._device, self._pinned)
 
     def SA(self) -> np.ndarray:
         if self._SA is None:

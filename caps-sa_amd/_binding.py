@@ -100,7 +100,7 @@ SHARD_EXPORTS = ["shard_create", "shard_destroy", "shard_info", "shard_phase1", 
 EXPORTS = ["device_count", "last_error", "version", "workspace_bytes", "release_cache", "host_alloc", "host_free"] + SHARD_EXPORTS + [
     f"{name}_{sfx}"
     for sfx in ("u32", "u64")
-    for name in ("build", "build_device", "verify_device", "verify_slice_device", "sort_suffixes", "sort_segments", "merge",
+    for name in ("build", "build_multi", "build_device", "verify_device", "verify_slice_device", "sort_suffixes", "sort_segments", "merge",
                  "upper_bound", "lcp")
 ]
 
@@ -136,6 +136,8 @@ class CapsLib:
         for sfx in ("u32", "u64"):
             f(f"build_{sfx}").restype = _ci
             f(f"build_{sfx}").argtypes = [_vp, _u64, _u64, _u64, _vp, _vp, _ci, ctypes.POINTER(Stats)]
+            f(f"build_multi_{sfx}").restype = _ci
+            f(f"build_multi_{sfx}").argtypes = [_vp, _u64, _u64, _u64, _vp, _vp, _vp, _ci, ctypes.POINTER(Stats)]
             f(f"build_device_{sfx}").restype = _ci
             f(f"build_device_{sfx}").argtypes = [_vp, _u64, _u64, _u64, _vp, _vp, _vp, _u64, _vp, ctypes.POINTER(Stats)]
             f(f"verify_device_{sfx}").restype = _ci
@@ -235,6 +237,28 @@ class CapsLib:
         st = Stats()
         self._check(self._f(f"build_{sfx}")(T.ctypes.data, T.size, p, max_context, SA.ctypes.data, LCP.ctypes.data,
                                             device, ctypes.byref(st)))
+        return SA, LCP, st.as_dict()
+
+    def build_into(self, T, SA: np.ndarray, LCP: np.ndarray, p: int = 0, max_context: int = 0, idx_bits: int = 32, device: int = 0) -> dict:
+        """construct() into caller-owned result arrays (e.g. pinned_empty ones, re-used between calls) -> stats dict."""
+        T = self._text(T)
+        sfx, dt = _sfx(idx_bits)
+        assert SA.dtype == dt and LCP.dtype == dt and SA.size >= T.size and LCP.size >= T.size
+        st = Stats()
+        self._check(self._f(f"build_{sfx}")(T.ctypes.data, T.size, p, max_context, SA.ctypes.data, LCP.ctypes.data,
+                                            device, ctypes.byref(st)))
+        return st.as_dict()
+
+    def build_multi(self, T, devices, p: int = 0, max_context: int = 0, idx_bits: int = 32, pinned: bool = False):
+        """construct() on several GPUs from this process (caps_sa_hip_build_multi_*) -> (SA, LCP, stats dict)."""
+        T = self._text(T)
+        sfx, dt = _sfx(idx_bits)
+        SA = self.pinned_empty(T.size, dt) if pinned else np.empty(T.size, dtype=dt)
+        LCP = self.pinned_empty(T.size, dt) if pinned else np.empty(T.size, dtype=dt)
+        devs = (ctypes.c_int * len(devices))(*devices)
+        st = Stats()
+        self._check(self._f(f"build_multi_{sfx}")(T.ctypes.data, T.size, p, max_context, SA.ctypes.data, LCP.ctypes.data,
+                                                  devs, len(devices), ctypes.byref(st)))
         return SA, LCP, st.as_dict()
 
     # ------------------------------------------------------------------ device-resident build

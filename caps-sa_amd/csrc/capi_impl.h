@@ -4,10 +4,14 @@
 // caps_sa_hip.hip (product: symbols caps_sa_hip_*) and, for the host emulation used by
 // CPU-side logic tests, by tests/emul/emul_lib.cpp (symbols caps_sa_emul_*).
 #pragma once
+#include <chrono>
 #include <cstring>
+#include <exception>
 #include <limits>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pipeline.h"
@@ -136,6 +140,7 @@ int build_host(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context, 
 {
     if (int rc = check_common<idx_t>(T, n, max_context)) return rc;
     if (n && (!SA || !LCP)) return fail(CAPS_SA_EINVAL, "null output");
+    DeviceScope restore_device_;
     if (int rc = set_device(device)) return rc;
     return guarded([&]() -> int {
         HostPathCache& hc = host_cache();
@@ -173,6 +178,194 @@ int build_host(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context, 
         if (stats) *stats = local;
         return CAPS_SA_OK;
     });
+}
+
+// ---- one process, several GPUs (`devices, n_devices` under construct(); 8e) -----------------------------
+// The sharded direct path of shard.h with one Shard per device, driven from this process: text replicated, every device
+// distributes every n_devices-th tile of it (level A), the blocks of (key, sa) go straight from device to device (peer
+// copies over xGMI: inside one process nothing else is needed -- the multi-PROCESS driver, caps_sa_dist.py, does the same
+// exchange with RCCL), every device sorts its groups, and the slices of SA / LCP are copied to the caller's arrays by
+// all devices at once.  A device may be listed more than once (several ranks share it: how a one-GPU box tests this).
+// Texts the direct path does not take (long repeats) are built on devices[0] alone.
+template <typename idx_t> struct MultiRank {
+    int dev = 0;
+    decltype(Backend::stream) stream = nullptr;
+    std::unique_ptr<Backend> be;
+    std::unique_ptr<Shard<idx_t>> sh;
+    std::vector<void*> owned;
+    uint8_t* dT = nullptr;
+    uint64_t *send_k = nullptr, *recv_k = nullptr, *report = nullptr;
+    idx_t *send_s = nullptr, *recv_s = nullptr, *dSA = nullptr, *dLCP = nullptr;
+    caps_sa_shard_info info;
+    std::vector<uint64_t> sc, rc;
+    template <typename T> T* get(size_t count)
+    {
+        T* q = static_cast<T*>(be->alloc((count ? count : 1) * sizeof(T)));
+        owned.push_back(q);
+        return q;
+    }
+    ~MultiRank()
+    {
+        if (set_device(dev) != CAPS_SA_OK) return;
+        sh.reset();
+        if (be) for (void* q : owned) be->free(q);
+        be.reset();
+        Backend::destroy_stream(stream);
+    }
+};
+
+// fn(rank) on every rank, each on a thread of its own with its device current (emulation: one after the other)
+template <typename R, typename F> void for_each_rank(std::vector<std::unique_ptr<R>>& ranks, F&& fn)
+{
+#ifdef CAPS_EMUL
+    for (auto& r : ranks) fn(*r);
+#else
+    std::vector<std::thread> th;
+    std::vector<std::exception_ptr> err(ranks.size());
+    for (size_t i = 0; i < ranks.size(); ++i)
+        th.emplace_back([&, i]() {
+            try {
+                if (set_device(ranks[i]->dev) != CAPS_SA_OK) throw HipError("hipSetDevice failed");
+                fn(*ranks[i]);
+            } catch (...) { err[i] = std::current_exception(); }
+        });
+    for (auto& t : th) t.join();
+    for (auto& e : err) if (e) std::rethrow_exception(e);
+#endif
+}
+
+template <typename idx_t>
+int build_host(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context, idx_t* SA, idx_t* LCP, int device,
+               caps_sa_stats* stats);
+
+template <typename idx_t>
+int build_multi(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context, idx_t* SA, idx_t* LCP, const int* devices,
+                int n_devices, caps_sa_stats* stats)
+{
+    if (!devices || n_devices < 1) return fail(CAPS_SA_EINVAL, "no devices");
+    if (int rc = check_common<idx_t>(T, n, max_context)) return rc;
+    if (n && (!SA || !LCP)) return fail(CAPS_SA_EINVAL, "null output");
+    if (n_devices == 1) return build_host<idx_t>(T, n, p_arg, max_context, SA, LCP, devices[0], stats);
+    DeviceScope restore_device_;
+    for (int i = 0; i < n_devices; ++i)
+        if (int rc = set_device(devices[i])) return rc;
+    int fallback = CAPS_SA_FB_NONE;
+    const int rc = guarded([&]() -> int {
+        using clock = std::chrono::steady_clock;
+        const auto t0 = clock::now();
+        uint32_t p_eff = 0, ppp = 0;
+        effective_params(n, p_arg, &p_eff, &ppp);
+        if (p_eff < 2) { fallback = CAPS_SA_FB_SHAPE; return CAPS_SA_OK; }
+        const int world = n_devices;
+        std::vector<std::unique_ptr<MultiRank<idx_t>>> ranks;
+        for (int r = 0; r < world; ++r) {
+            std::unique_ptr<MultiRank<idx_t>> q(new MultiRank<idx_t>);
+            q->dev = devices[r];
+            if (int e = set_device(q->dev)) return e;
+            q->stream = Backend::create_stream();
+            q->be.reset(new Backend(q->stream));
+            q->dT = q->template get<uint8_t>(n);
+            q->be->h2d(q->dT, T, n);
+            q->sh.reset(new Shard<idx_t>(q->dT, n, p_arg, r, world, q->stream));
+            q->sh->info(&q->info);
+            ranks.push_back(std::move(q));
+        }
+        if (ranks[0]->info.direct_fallback != CAPS_SA_FB_NONE) { fallback = (int)ranks[0]->info.direct_fallback; return CAPS_SA_OK; }
+        const size_t W = (size_t)ranks[0]->info.n_streams + 2;
+        for (auto& q : ranks) {
+            if (int e = set_device(q->dev)) return e;
+            q->send_k = q->template get<uint64_t>(q->info.send_capacity);
+            q->send_s = q->template get<idx_t>(q->info.send_capacity);
+            q->recv_k = q->template get<uint64_t>(q->info.capacity);
+            q->recv_s = q->template get<idx_t>(q->info.capacity);
+            q->dSA = q->template get<idx_t>(q->info.capacity);
+            q->dLCP = q->template get<idx_t>(q->info.capacity);
+            q->report = q->template get<uint64_t>(W);
+        }
+        const auto t1 = clock::now();
+        // ---- level A on every device; the reports; the plan (identical on all ranks)
+        for_each_rank(ranks, [&](MultiRank<idx_t>& q) { q.sh->scatter(q.send_k, q.send_s, q.report); });
+        std::vector<uint64_t> all(W * world);
+        for (int r = 0; r < world; ++r) {
+            if (int e = set_device(ranks[r]->dev)) return e;
+            ranks[r]->be->d2h(all.data() + W * r, ranks[r]->report, W * sizeof(uint64_t));
+            ranks[r]->be->sync();
+        }
+        for (auto& q : ranks) {
+            q->sc.assign(world, 0);
+            q->rc.assign(world, 0);
+            if (int e = set_device(q->dev)) return e;
+            const int code = q->sh->plan(all.data(), q->sc.data(), q->rc.data());
+            if (code != CAPS_SA_FB_NONE) { fallback = code; return CAPS_SA_OK; }
+        }
+        // ---- the exchange: block d of rank r's send buffers -> slot r of rank d's receive buffers
+        for (int r = 0; r < world; ++r) {
+            MultiRank<idx_t>& src = *ranks[r];
+            if (int e = set_device(src.dev)) return e;
+            uint64_t so = 0;
+            for (int d = 0; d < world; ++d) {
+                MultiRank<idx_t>& dst = *ranks[d];
+                const uint64_t cnt = src.sc[d];
+                if (cnt != dst.rc[r]) throw std::runtime_error("send / receive counts disagree");
+                uint64_t ro = 0;
+                for (int q = 0; q < r; ++q) ro += dst.rc[q];
+                src.be->peer_copy(dst.recv_k + ro, dst.dev, src.send_k + so, src.dev, cnt * sizeof(uint64_t));
+                src.be->peer_copy(dst.recv_s + ro, dst.dev, src.send_s + so, src.dev, cnt * sizeof(idx_t));
+                so += cnt;
+            }
+        }
+        for (auto& q : ranks) { if (int e = set_device(q->dev)) return e; q->be->sync(); }
+        const auto t2 = clock::now();
+        // ---- level B + tile sort of the owned groups; boundary LCPs between the slices
+        for_each_rank(ranks, [&](MultiRank<idx_t>& q) { q.sh->sort_owned(q.recv_k, q.recv_s, q.dSA, q.dLCP); });
+        uint64_t prev = ~0ull;
+        for (auto& q : ranks) {
+            if (int e = set_device(q->dev)) return e;
+            q->sh->fix_first_lcp(prev, q->dLCP);
+            const uint64_t last = q->sh->last_sa();
+            if (last != ~0ull) prev = last;
+            q->sh->info(&q->info);
+        }
+        const auto t3 = clock::now();
+        // ---- every device copies its slice to the caller's arrays
+        uint64_t covered = 0;
+        for (auto& q : ranks) {
+            if (q->info.slice_off != covered) throw std::runtime_error("the ranks' slices do not tile the suffix array");
+            covered += q->info.recv_total;
+        }
+        if (covered != n) throw std::runtime_error("the ranks' slices do not cover the suffix array");
+        for_each_rank(ranks, [&](MultiRank<idx_t>& q) {
+            q.be->d2h(SA + q.info.slice_off, q.dSA, q.info.recv_total * sizeof(idx_t));
+            q.be->d2h(LCP + q.info.slice_off, q.dLCP, q.info.recv_total * sizeof(idx_t));
+            q.be->sync();
+        });
+        const auto t4 = clock::now();
+        if (stats) {
+            auto ms = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            *stats = caps_sa_stats();
+            stats->n = n;
+            stats->idx_bytes = sizeof(idx_t);
+            stats->p_eff = ranks[0]->info.p;
+            stats->ppp = ranks[0]->info.ppp;
+            stats->bits_per_char = ranks[0]->info.bits_per_char;
+            stats->path_direct = 1;
+            stats->direct_groups = ranks[0]->info.direct_groups;
+            stats->ms_h2d = ms(t0, t1);                       // device setup: allocations + the text to every device
+            stats->ms_partition = ms(t1, t2);                 // level A + exchange (host wall clock, all devices)
+            stats->ms_merge_partitions = ms(t2, t3);          // level B + tile sort + boundary LCPs
+            stats->ms_d2h = ms(t3, t4);
+            stats->ms_total = ms(t1, t3);
+            for (auto& q : ranks) { stats->slot_splits += q->info.slot_splits; stats->slot_splits_redone += q->info.slot_splits_redone; }
+        }
+        return CAPS_SA_OK;
+    });
+    if (rc != CAPS_SA_OK) return rc;
+    if (fallback != CAPS_SA_FB_NONE) {
+        const int rc1 = build_host<idx_t>(T, n, p_arg, max_context, SA, LCP, devices[0], stats);
+        if (rc1 == CAPS_SA_OK && stats && stats->path_fallback == CAPS_SA_FB_NONE) stats->path_fallback = (uint32_t)fallback;
+        return rc1;
+    }
+    return CAPS_SA_OK;
 }
 
 template <typename idx_t>
@@ -257,6 +450,7 @@ int sort_suffixes(const char* T, uint64_t n, const idx_t* idx, uint64_t cnt, idx
     if (cnt == 0) return CAPS_SA_OK;
     if (!idx || !out_sa || !out_lcp) return fail(CAPS_SA_EINVAL, "null pointer");
     if (int rc = check_positions(idx, cnt, n, "suffix position out of range")) return rc;
+    DeviceScope restore_device_;
     if (int rc = set_device(device)) return rc;
     return guarded([&]() -> int {
         Backend be(nullptr);
@@ -309,6 +503,7 @@ int sort_segments(const char* T, uint64_t n, const idx_t* idx, uint64_t cnt, con
         n_tiles += tiles_of(len);
     }
     if (int rc = check_positions(idx, cnt, n, "suffix position out of range")) return rc;
+    DeviceScope restore_device_;
     if (int rc = set_device(device)) return rc;
     return guarded([&]() -> int {
         Backend be(nullptr);
@@ -360,6 +555,7 @@ int merge_runs(const char* T, uint64_t n, const idx_t* X, uint64_t len_x, const 
     if ((len_x && (!X || !LX)) || (len_y && (!Y || !LY)) || !Z || !LZ) return fail(CAPS_SA_EINVAL, "null pointer");
     if (int rc = check_positions(X, len_x, n, "suffix position out of range")) return rc;
     if (int rc = check_positions(Y, len_y, n, "suffix position out of range")) return rc;
+    DeviceScope restore_device_;
     if (int rc = set_device(device)) return rc;
     return guarded([&]() -> int {
         Backend be(nullptr);
@@ -405,6 +601,7 @@ int upper_bounds(const char* T, uint64_t n, const idx_t* X, uint64_t cnt, const 
     if (npiv > 0x7fffffffull) return fail(CAPS_SA_EINVAL, "too many pivots");
     if (int rc = check_positions(X, cnt, n, "suffix position out of range")) return rc;
     if (int rc = check_positions(piv, npiv, n, "pivot position out of range")) return rc;
+    DeviceScope restore_device_;
     if (int rc = set_device(device)) return rc;
     return guarded([&]() -> int {
         Backend be(nullptr);
@@ -442,6 +639,7 @@ int lcp_pairs(const char* T, uint64_t n, const idx_t* a, const idx_t* b, uint64_
     if (!a || !b || !out) return fail(CAPS_SA_EINVAL, "null pointer");
     if (int rc = check_positions(a, cnt, n, "suffix position out of range")) return rc;
     if (int rc = check_positions(b, cnt, n, "suffix position out of range")) return rc;
+    DeviceScope restore_device_;
     if (int rc = set_device(device)) return rc;
     return guarded([&]() -> int {
         Backend be(nullptr);
@@ -475,6 +673,7 @@ void CAPS_API(release_cache)(void)
 {
     caps::HostPathCache& hc = caps::host_cache();
     std::lock_guard<std::mutex> lock(hc.mu);
+    caps::DeviceScope restore_device_;
     if (hc.device >= 0 && caps::set_device(hc.device) != CAPS_SA_OK) return;
     caps::release_host_cache_locked(hc);
 }
@@ -500,6 +699,9 @@ int CAPS_API(workspace_bytes)(uint64_t n, uint64_t subproblem_count, int idx_byt
     int CAPS_API(build_##SFX)(const char* T, uint64_t n, uint64_t p, uint64_t ctx, IDX* SA, IDX* LCP, int device,          \
                               caps_sa_stats* st)                                                                           \
     { return caps::build_host<IDX>(T, n, p, ctx, SA, LCP, device, st); }                                                   \
+    int CAPS_API(build_multi_##SFX)(const char* T, uint64_t n, uint64_t p, uint64_t ctx, IDX* SA, IDX* LCP,                \
+                                    const int* devices, int n_devices, caps_sa_stats* st)                                  \
+    { return caps::build_multi<IDX>(T, n, p, ctx, SA, LCP, devices, n_devices, st); }                                      \
     int CAPS_API(build_device_##SFX)(const void* dT, uint64_t n, uint64_t p, uint64_t ctx, void* dSA, void* dLCP,          \
                                      void* ws, uint64_t ws_bytes, void* stream, caps_sa_stats* st)                         \
     { return caps::build_device<IDX>(dT, n, p, ctx, dSA, dLCP, ws, ws_bytes, stream, st); }                                \

@@ -27,6 +27,15 @@ inline void hip_check(hipError_t e, const char* what)
 
 struct BackendEvent { hipEvent_t ev = nullptr; };
 
+// The host-buffer entry points select their device; the caller's current device is restored when they return.
+struct DeviceScope {
+    int prev = -1;
+    DeviceScope() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
+
 class Backend {
 public:
     hipStream_t stream = nullptr;
@@ -73,6 +82,21 @@ public:
     void d2h(void* h, const void* d, size_t bytes) { if (bytes) CAPS_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, stream)); }
     void d2d(void* d, const void* s, size_t bytes) { if (bytes) CAPS_HIP(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, stream)); }
     void sync() { CAPS_HIP(hipStreamSynchronize(stream)); }
+    // multi-device builds (capi_impl.h build_multi): a stream on the current device; a copy between two devices' memories
+    // (the same device twice is allowed: a plain device copy) -- SDMA over xGMI, no staging through the host
+    static hipStream_t create_stream()
+    {
+        hipStream_t s = nullptr;
+        CAPS_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        return s;
+    }
+    static void destroy_stream(hipStream_t s) { if (s) (void)hipStreamDestroy(s); }
+    void peer_copy(void* dst, int dst_dev, const void* src, int src_dev, size_t bytes)
+    {
+        if (!bytes) return;
+        if (dst_dev == src_dev) CAPS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream));
+        else CAPS_HIP(hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, stream));
+    }
     // Grid of the persistent kernels: as many workgroups as are resident at once
     // (CAPS_TILE_WAVES waves per SIMD = CAPS_TILE_WAVES * 256 / CAPS_TILE_NT workgroups per CU).
     uint32_t persistent_blocks()

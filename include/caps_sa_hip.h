@@ -122,6 +122,19 @@ int caps_sa_hip_build_u64(const char* T, uint64_t n, uint64_t subproblem_count, 
                           uint64_t* SA, uint64_t* LCP, int device, caps_sa_stats* stats);
 
 /*
+ * construct() on several GPUs of one node from ONE process (what Suffix_Array(T, n, p, ctx, devices)
+ * calls): devices[0 .. n_devices) are HIP device ordinals, one rank of the sharded direct path each (a device may be listed
+ * more than once).  The text is copied to every device; every device distributes every n_devices-th tile of it, the
+ * blocks of (key, sa) are copied device to device over xGMI, every device sorts its share of the partitions and copies
+ * its slice of SA / LCP into the caller's arrays.  n_devices = 1 is caps_sa_hip_build_*.  Texts the direct path does not
+ * take (stats->path_fallback says why) are built on devices[0] alone.  stats: host wall-clock per stage, all devices.
+ */
+int caps_sa_hip_build_multi_u32(const char* T, uint64_t n, uint64_t subproblem_count, uint64_t max_context,
+                                uint32_t* SA, uint32_t* LCP, const int* devices, int n_devices, caps_sa_stats* stats);
+int caps_sa_hip_build_multi_u64(const char* T, uint64_t n, uint64_t subproblem_count, uint64_t max_context,
+                                uint64_t* SA, uint64_t* LCP, const int* devices, int n_devices, caps_sa_stats* stats);
+
+/*
  * Same construction with everything resident in HBM: dT (n bytes), dSA, dLCP (n entries)
  * are device pointers on the current device; hip_stream is a hipStream_t (NULL = default
  * stream).  workspace: device memory of at least caps_sa_hip_workspace_bytes(), or NULL

@@ -23,6 +23,7 @@ struct OomError : std::runtime_error {
 };
 
 struct BackendEvent { double t = 0; };
+struct DeviceScope { DeviceScope() {} ~DeviceScope() {} };
 
 class Backend {
 public:
@@ -51,6 +52,9 @@ public:
     void d2h(void* h, const void* d, size_t bytes) { std::memcpy(h, d, bytes); }
     void d2d(void* d, const void* s, size_t bytes) { std::memmove(d, s, bytes); }
     void sync() {}
+    static void* create_stream() { return nullptr; }
+    static void destroy_stream(void*) {}
+    void peer_copy(void* dst, int, const void* src, int, size_t bytes) { std::memmove(dst, src, bytes); }
     uint32_t persistent_blocks() { return 3; }     // small on purpose: exercises the tile loop
     void check_launch(const char*) {}
 };

@@ -243,3 +243,41 @@ def test_equalised_split_never_needs_more_passes_than_the_plain_one(oracle, monk
                 assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo)
                 assert st["merge_passes_phase1"] <= st0["merge_passes_phase1"]
                 assert st["merge_passes_phase2"] <= st0["merge_passes_phase2"]
+
+
+def test_one_process_several_devices(oracle):
+    """caps_sa_*_build_multi_* (capi_impl.h build_multi): one Shard per listed device, blocks copied device to device,
+    slices copied into the caller's arrays; here every "device" is the emulation's host memory."""
+    from emul_util import emul_small
+    E = emul_small()
+    rs = np.random.RandomState(19)
+    for devs, n, p, bits in [([0, 0], 60_000, 0, 32), ([0, 0, 0], 90_001, 700, 32), ([0] * 8, 150_000, 0, 64), ([0], 40_000, 0, 32),
+                             ([0, 0], 3_000, 0, 32)]:
+        T = rs.choice(DNA, size=n)
+        SA, LCP, st = E.build_multi(T, devs, p=p, idx_bits=bits)
+        SAo, LCPo = oracle.naive_sa_lcp(T, idx_bits=bits)
+        assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), (devs, n)
+        assert st["path_direct"] == (1 if n >= 8192 else 0)
+    T = rs.choice(DNA, size=120_000)
+    T[30_000:36_000] = ord("G")                           # a long run: the ranks agree to leave the direct path; devices[0] builds alone
+    SA, LCP, st = E.build_multi(T, [0, 0, 0], p=0)
+    SAo, LCPo = oracle.build_sa_lcp(T, p=64)
+    assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo) and st["path_fallback"] != 0
+
+
+def test_cli_validates_before_it_writes(tmp_path):
+    """arguments are checked and the build runs BEFORE the output file is opened; a bounded context (unsupported)
+    or a malformed count leaves no empty file behind."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-s", "-C", os.path.join(root, "caps-sa_amd"), "caps_sa"])
+    exe = os.path.join(root, "caps-sa_amd", "caps_sa")
+    inp = tmp_path / "in.txt"
+    inp.write_bytes(b"ACGT" * 100)
+    for extra in (["8", "50"], ["x8"], ["8", "-1"]):
+        out = tmp_path / "out.bin"
+        r = subprocess.run([exe, str(inp), str(out)] + extra, capture_output=True, text=True)
+        assert r.returncode != 0 and not out.exists(), (extra, r.stderr)
+    r = subprocess.run([exe, str(inp)], capture_output=True, text=True)
+    assert r.returncode != 0 and "bounded-context" in r.stderr

@@ -471,3 +471,17 @@ def test_shard_kernels_at_world_sizes_above_one_loopback(L, sa_path, world, n, p
     assert torch.equal(SA, SA1)
     assert torch.equal(LCP, LCP1)
     assert build_world.last_path == ("direct" if sa_path != "classic" and world != 3 else "samplesort")
+
+
+@pytest.mark.parametrize("devices,n,p,bits", [([0, 0], 20_000_001, 8000, 32), ([0, 0, 0], 9_000_000, 0, 64), ([0], 5_000_000, 64, 32)])
+def test_one_process_several_ranks_on_this_gpu(L, oracle, devices, n, p, bits):
+    """caps_sa_hip_build_multi_*: the C++ multi-device entry point under Suffix_Array(T, n, p, ctx, devices).  A test box has
+    one GPU, so the device list repeats ordinal 0: every rank is a Shard of its own with its own stream and buffers, the
+    blocks travel by device-to-device copies exactly as they would between two GPUs."""
+    rs = np.random.RandomState(len(devices) * 7 + 1)
+    T = rs.choice(DNA, size=n)
+    SA, LCP, st = L.build_multi(T, devices, p=p, idx_bits=bits, pinned=True)
+    SA1, LCP1, st1 = L.build(T, p=p, idx_bits=bits)
+    assert np.array_equal(SA, SA1) and np.array_equal(LCP, LCP1)
+    assert st["path_direct"] == 1 and st["path_fallback"] == 0
+    L.release_cache()

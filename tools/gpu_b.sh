@@ -9,7 +9,7 @@ tail -3 $O/b_tests.log
 for spec in "$@"; do
   tag=${spec%%:*}; envs=${spec#*:}; [ "$envs" = "$spec" ] && envs=""
   ( IFS=,; for kv in $envs; do export "$kv"; done
-    timeout -k 10 200 python bench.py --workload ${WL:-c3} --steps 5 --warmup 2 --verify --no-cpu-baseline > $O/b_bench_$tag.json 2> $O/b_bench_$tag.err
+    timeout -k 10 200 python bench.py --workload ${WL:-c3} --steps 5 --warmup 2 --verify --no-cpu-baseline --no-host-path > $O/b_bench_$tag.json 2> $O/b_bench_$tag.err
     python - <<PY
 import json
 d=json.loads(open("$O/b_bench_$tag.json").read().strip().splitlines()[-1])
@@ -18,6 +18,6 @@ PY
   )
 done
 if [ -n "$PROF" ]; then
-cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/b_prof -o b -- python3 $GRAFT_REPO_ROOT/bench.py --workload ${WL:-c3} --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$O/b_prof.log 2>&1
+cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/b_prof -o b -- python3 $GRAFT_REPO_ROOT/bench.py --workload ${WL:-c3} --steps 3 --warmup 1 --no-cpu-baseline --no-host-path > $GRAFT_REPO_ROOT/$O/b_prof.log 2>&1
 cd "$GRAFT_REPO_ROOT"; f=$(find $O/b_prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cut -c1-160 $f | head -12
 fi

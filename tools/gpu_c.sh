@@ -6,8 +6,8 @@ export TMPDIR=/tmp
 O=gpurun_out
 timeout -k 10 700 python -m pytest tests -m gpu -x -q > $O/c_tests.log 2>&1; echo "tests rc=$?" | tee -a $O/c_tests.log
 tail -4 $O/c_tests.log
-( time timeout -k 10 300 python bench.py > $O/c_bench_default.json 2> $O/c_bench_default.err ) 2>&1 | grep real
-CAPS_SA_FORCE_SHARDED=1 timeout -k 10 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/c_bench_sharded1.json 2> $O/c_bench_sharded1.err
+( time timeout -k 10 500 python bench.py > $O/c_bench_default.json 2> $O/c_bench_default.err ) 2>&1 | grep real
+CAPS_SA_FORCE_SHARDED=1 timeout -k 10 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-path > $O/c_bench_sharded1.json 2> $O/c_bench_sharded1.err
 python - <<'PY'
 import json
 for f in ("c_bench_default","c_bench_sharded1"):

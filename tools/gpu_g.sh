@@ -8,7 +8,7 @@ for spec in "$@"; do
   wl=${spec%%:*}; envs=${spec#*:}; [ "$envs" = "$spec" ] && envs=""
   tag=$(echo "$spec" | tr ':=,' '___')
   ( IFS=,; for kv in $envs; do export "$kv"; done
-    timeout -k 10 400 python bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline > $O/g_bench_$tag.json 2> $O/g_bench_$tag.err
+    timeout -k 10 400 python bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline --no-host-path > $O/g_bench_$tag.json 2> $O/g_bench_$tag.err
     python - <<PY
 import json
 try:
