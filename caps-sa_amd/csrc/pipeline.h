@@ -25,9 +25,10 @@
 #include "kernels.h"
 #include "../../include/caps_sa_hip.h"
 
-#ifdef CAPS_EMUL
-#include "../../tests/emul/emul_backend.h"
-#else
+// The backend (device memory, copies, launches, events): hip_backend.h in the product.  A translation unit that has
+// already defined one (CAPS_BACKEND_DEFINED: the host emulation of tests/emul, which includes its own before this header)
+// keeps its own -- the product headers never reach into tests/.
+#ifndef CAPS_BACKEND_DEFINED
 #include "hip_backend.h"
 #endif
 

@@ -7,6 +7,7 @@
 // library built from this (tests/emul/libcaps_sa_emul.so) exports caps_sa_emul_* symbols;
 // the product library never links or loads it, and the -m gpu parity tests never use it.
 #pragma once
+#define CAPS_BACKEND_DEFINED 1
 #include <chrono>
 #include <cstdlib>
 #include <cstring>

@@ -13,6 +13,9 @@ extern "C" void caps_emul_count_tile3(bool ok) { ++g_tile_stats[6 + (ok ? 1 : 0)
 extern "C" void caps_sa_emul_tile_stats8(uint64_t* out, int reset) { for (int i = 0; i < 8; ++i) { out[i] = g_tile_stats[i]; if (reset) g_tile_stats[i] = 0; } }
 extern "C" void caps_sa_emul_tile_stats6(uint64_t* out, int reset) { for (int i = 0; i < 6; ++i) { out[i] = g_tile_stats[i]; if (reset) g_tile_stats[i] = 0; } }
 extern "C" void caps_sa_emul_tile_stats(uint64_t* out, int reset) { for (int i = 0; i < 4; ++i) { out[i] = g_tile_stats[i]; if (reset) g_tile_stats[i] = 0; } }
+// the emulation's backend first: pipeline.h then skips the product's hip_backend.h (CAPS_BACKEND_DEFINED)
+#include "../../caps-sa_amd/csrc/kernel_lang.h"
+#include "emul_backend.h"
 #include "../../caps-sa_amd/csrc/capi_impl.h"
 
 namespace caps {
