@@ -39,6 +39,7 @@ namespace caps { struct EmulCtx { uint32_t block_idx, grid_dim, block_dim; }; }
 #define K_BLOCK_DIM (kctx_.block_dim)
 #define PAR(tid) for (uint32_t tid = 0; tid < kctx_.block_dim; ++tid)
 #define SYNC() ((void)0)
+#define SYNC_LDS() ((void)0)
 #define SHARED_ARRAY(type, name, count) std::vector<type> name##_vec_(count); type* name = name##_vec_.data()
 #define TL_DECL(type, name, cnt) std::vector<type> name##_tl_((size_t)kctx_.block_dim * (cnt)); \
     type* const name##_tlp_ = name##_tl_.data(); const uint32_t name##_tlc_ = (cnt)
@@ -76,6 +77,17 @@ static inline uint32_t caps_bswap32(uint32_t x) { return __builtin_bswap32(x); }
 #define K_BLOCK_DIM (blockDim.x)
 #define PAR(tid) for (uint32_t tid = threadIdx.x, par_once_ = 1; par_once_; par_once_ = 0)
 #define SYNC() __syncthreads()
+// Barrier that orders LDS traffic only: s_waitcnt lgkmcnt(0) + s_barrier.  __syncthreads() also drains the wave's
+// outstanding global stores and returning atomics (vmcnt); where nothing that went to global memory is handed to another
+// thread of the workgroup, this one lets them stay in flight across the barrier (the cursor bumps of the scatter kernels
+// return while the tile is scanned and re-ordered in LDS).
+static __device__ __forceinline__ void caps_lds_barrier()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+#define SYNC_LDS() caps_lds_barrier()
 #define SHARED_ARRAY(type, name, count) __shared__ type name[count]
 #define TL_DECL(type, name, cnt) type name##_reg_[cnt]
 #define TL(name, tid, k) name##_reg_[k]

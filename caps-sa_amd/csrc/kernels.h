@@ -669,13 +669,13 @@ DEV_INLINE void block_exclusive_scan(KCTX uint32_t* h)
         if ((int)lane >= d) x += y;
     }
     if (lane == 63) wave_tot[wv] = x;
-    __syncthreads();
+    SYNC_LDS();
     uint32_t run = x - sum;
     for (uint32_t w = 0; w < wv; ++w) run += wave_tot[w];
     UNROLL
     for (uint32_t i = 0; i < BPT; ++i) { h[tid * BPT + i] = run; run += v[i]; }
     if (tid == TILE_NT - 1) h[NBINS] = run;
-    __syncthreads();
+    SYNC_LDS();
 #endif
 }
 DEV_INLINE void block_exclusive_scan_bins(KCTX uint32_t* hist) { block_exclusive_scan<TILE_BINS_>(KCTX_PASS hist); }
@@ -2242,20 +2242,22 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
         return;
     }
     SYNC();
-    PAR(tid) {                                             // one global cursor bump per (tile, non-empty bucket)
-        for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM) {
-            const uint32_t c = hist[i];
-            idx_t ob = 0;
-            if (c) {
-                const uint64_t ci = spec ? (b0 + i) * sub + sx : b0 + i;
-                const idx_t old = caps_fetch_add(&cursor[ci], (idx_t)c);
-                if (!spec) ob = (idx_t)(sub_start[b0 + i] + old);
-                else ob = (uint64_t)old + c <= slot_cap ? (idx_t)(ci * slot_cap + old) : NO_SLOT;
-            }
-            obase[i] = ob;
+    // One global cursor bump per (tile, non-empty bucket).  The returning atomics are only ISSUED here; their results are
+    // needed for the output addresses alone, so they travel while the tile is scanned and re-ordered in LDS (barriers of
+    // LDS scope in between: __syncthreads() would wait for them).
+    constexpr uint32_t BPT = (TILE_BINS + TILE_NT - 1) / TILE_NT;          // buckets per thread
+    TL_DECL(idx_t, co, BPT);
+    TL_DECL(uint32_t, cc, BPT);
+    PAR(tid) {
+        UNROLL
+        for (uint32_t j = 0; j < BPT; ++j) {
+            const uint32_t i = tid + j * TILE_NT;
+            const uint32_t c = i < bp.B ? hist[i] : 0u;
+            TL(cc, tid, j) = c;
+            TL(co, tid, j) = 0;
+            if (c) TL(co, tid, j) = caps_fetch_add(&cursor[spec ? (b0 + i) * sub + sx : b0 + i], (idx_t)c);
         }
     }
-    SYNC();
     block_exclusive_scan_bins(KCTX_PASS hist);             // hist[i] = position of bucket i inside the re-ordered tile
     PAR(tid) {
         UNROLL
@@ -2269,8 +2271,23 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
                 sbk[q] = (uint16_t)bk;
             }
         }
+        UNROLL
+        for (uint32_t j = 0; j < BPT; ++j) {
+            const uint32_t i = tid + j * TILE_NT;
+            if (i < bp.B) {
+                const uint32_t c = TL(cc, tid, j);
+                const idx_t old = TL(co, tid, j);
+                idx_t ob = 0;
+                if (c) {
+                    const uint64_t ci = spec ? (b0 + i) * sub + sx : b0 + i;
+                    if (!spec) ob = (idx_t)(sub_start[b0 + i] + old);
+                    else ob = (uint64_t)old + c <= slot_cap ? (idx_t)(ci * slot_cap + old) : NO_SLOT;
+                }
+                obase[i] = ob;
+            }
+        }
     }
-    SYNC();
+    SYNC_LDS();
     PAR(tid) {
         UNROLL
         for (uint32_t k = 0; k < TILE_EPT; ++k) {
@@ -2376,27 +2393,42 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) group_scatter_kernel(KCTX
         }
     }
     SYNC();
-    // ---- one cursor bump per (tile, non-empty group); then hist -> first position of every group in the re-ordered tile
+    // ---- one cursor bump per (tile, non-empty group), issued here and consumed after the scan (the returning atomics
+    //      travel meanwhile: LDS-scope barriers in between); hist -> first position of every group in the re-ordered tile
+    constexpr uint32_t GPT = (TILE_BINS + TILE_NT - 1) / TILE_NT;          // groups per thread
+    TL_DECL(idx_t, co, GPT);
+    TL_DECL(uint32_t, cc, GPT);
     PAR(tid) {
-        for (uint32_t i = tid; i < K1; i += K_BLOCK_DIM) {
-            const uint32_t c = hist[i];
-            idx_t ob = 0;
-            if (c) {
-                const idx_t old = caps_fetch_add(&cursor[(uint64_t)sx * K1 + i], (idx_t)c);
-                const uint64_t st = (uint64_t)i * sub + sx;
-                const uint64_t r0 = region_start ? region_start[st] : st * slot_cap, rc = region_start ? region_cap[st] : slot_cap;
-                ob = (uint64_t)old + c <= rc ? (idx_t)(r0 + old) : NO_SLOT;
-            }
-            obase[i] = ob;
+        UNROLL
+        for (uint32_t j = 0; j < GPT; ++j) {
+            const uint32_t i = tid + j * TILE_NT;
+            const uint32_t c = i < K1 ? hist[i] : 0u;
+            TL(cc, tid, j) = c;
+            TL(co, tid, j) = 0;
+            if (c) TL(co, tid, j) = caps_fetch_add(&cursor[(uint64_t)sx * K1 + i], (idx_t)c);
         }
     }
-    SYNC();
     block_exclusive_scan_bins(KCTX_PASS hist);
     PAR(tid) {
         UNROLL
         for (uint32_t k = 0; k < GA_EPT; ++k) {
             const uint32_t v = TL(pk, tid, k), g = v >> 14;
             TL(pk, tid, k) = (g << 14) | (hist[g] + (v & 0x3FFFu));       // group << 14 | position q in the re-ordered tile
+        }
+        UNROLL
+        for (uint32_t j = 0; j < GPT; ++j) {
+            const uint32_t i = tid + j * TILE_NT;
+            if (i < K1) {
+                const uint32_t c = TL(cc, tid, j);
+                idx_t ob = 0;
+                if (c) {
+                    const idx_t old = TL(co, tid, j);
+                    const uint64_t st = (uint64_t)i * sub + sx;
+                    const uint64_t r0 = region_start ? region_start[st] : st * slot_cap, rc = region_start ? region_cap[st] : slot_cap;
+                    ob = (uint64_t)old + c <= rc ? (idx_t)(r0 + old) : NO_SLOT;
+                }
+                obase[i] = ob;
+            }
         }
     }
     // ---- write the re-ordered tile, TILE_E positions at a time: perm[q] = group << 14 | element
@@ -2409,7 +2441,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) group_scatter_kernel(KCTX
                 if (e < cnt && q - c0 < TILE_E) perm[q - c0] = (v & ~0x3FFFu) | e;
             }
         }
-        SYNC();
+        SYNC_LDS();
         PAR(tid) {
             UNROLL
             for (uint32_t k = 0; k < TILE_EPT; ++k) {
@@ -2425,7 +2457,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) group_scatter_kernel(KCTX
                 }
             }
         }
-        SYNC();
+        SYNC_LDS();                                  // the chunk's stores need not land before the next chunk is staged
     }
 }
 

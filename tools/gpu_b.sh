@@ -9,7 +9,7 @@ tail -3 $O/b_tests.log
 for spec in "$@"; do
   tag=${spec%%:*}; envs=${spec#*:}; [ "$envs" = "$spec" ] && envs=""
   ( IFS=,; for kv in $envs; do export "$kv"; done
-    timeout -k 10 200 python bench.py --workload ${WL:-c3} --steps 5 --warmup 2 --verify --no-cpu-baseline --no-host-path > $O/b_bench_$tag.json 2> $O/b_bench_$tag.err
+    timeout -k 10 200 python bench.py --workload ${WL:-c3} --steps 5 --warmup 2 ${NOVERIFY:+--no-verify} --no-cpu-baseline --no-host-path > $O/b_bench_$tag.json 2> $O/b_bench_$tag.err
     python - <<PY
 import json
 d=json.loads(open("$O/b_bench_$tag.json").read().strip().splitlines()[-1])
