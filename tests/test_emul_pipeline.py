@@ -281,3 +281,60 @@ def test_cli_validates_before_it_writes(tmp_path):
         assert r.returncode != 0 and not out.exists(), (extra, r.stderr)
     r = subprocess.run([exe, str(inp)], capture_output=True, text=True)
     assert r.returncode != 0 and "bounded-context" in r.stderr
+
+
+def _markov(rs, n, order=3, skew=0.3):
+    trans = rs.dirichlet([skew] * 4, size=4 ** order)
+    cdf = np.cumsum(trans, 1)
+    m = np.zeros(n, dtype=np.int64)
+    u = rs.rand(n)
+    st = 0
+    for i in range(n):
+        c = min(3, int(np.searchsorted(cdf[st], u[i])))
+        m[i] = c
+        st = (st * 4 + c) % (4 ** order)
+    return DNA[m]
+
+
+def test_direct_path_modes_and_fallbacks(oracle, monkeypatch):
+    """The direct path (pipeline.h run_direct) in both level-B modes, chosen by the pivots and forced: linear (interpolated
+    buckets in slots) and quantile (sample-quantile buckets, count + exact scatter); frequent keys (N-block stand-ins) with
+    regions sized by expected bucket-worth; a text that is ONE key (samplesort path).  256-element-tile build."""
+    from emul_util import emul_small
+    E = emul_small()
+    rs = np.random.RandomState(5)
+
+    def run(T, mode=None, sub=None, bits=32):
+        for k, v in (("CAPS_SA_DIRECT_MODE", mode), ("CAPS_SA_DIRECT_SUB", sub)):
+            if v is None:
+                monkeypatch.delenv(k, raising=False)
+            else:
+                monkeypatch.setenv(k, v)
+        SA, LCP, st = E.build(T, p=0, idx_bits=bits)
+        SAo, LCPo = oracle.build_sa_lcp(T, p=64, idx_bits=bits)
+        assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo)
+        return st
+
+    T1 = _markov(rs, 200_000)
+    st = run(T1)
+    assert st["path_direct"] == 1 and st["direct_quantile"] == 1          # the pivots reveal the skew
+    st_lin = run(T1, mode="linear")
+    assert st_lin["direct_quantile"] == 0 and st_lin["merge_passes_phase2"] >= st["merge_passes_phase2"]
+    uni = rs.choice(DNA, size=150_000)
+    assert run(uni, mode="quantile")["direct_quantile"] == 1
+    assert run(uni[:100_001], mode="quantile", bits=64)["direct_quantile"] == 1
+    assert run(uni, mode="linear")["path_direct"] == 1
+    T2 = rs.choice(DNA, size=300_000)
+    T2[50_000:53_000] = ord("G")
+    T2[200_000:200_700] = ord("G")
+    st = run(T2, sub="1")                                                   # one stream per group: the fat group's region holds the run
+    assert st["path_direct"] == 1 and st["direct_quantile"] == 1 and st["long_runs"] == 1
+    run(T2)                                                                 # 8 sub-streams at this tiny size: a 3-tile run overloads 3 of them -> falls back, same result
+    T3 = _markov(rs, 250_000)
+    T3[100_000:104_000] = ord("G")
+    T3[10_000:12_000] = T3[150_000:152_000]
+    run(T3, sub="1")                                                        # skew + N-block + repeat: whichever path it takes, same result
+    st = run(np.full(60_000, ord("A"), dtype=np.uint8))
+    assert st["path_direct"] == 0 and st["path_fallback"] == 4             # CAPS_SA_FB_PIVOT_TIES: one key covers the text
+    T5 = rs.choice(np.frombuffer(b"abcdefgh", dtype=np.uint8), size=120_000, p=[.5, .2, .1, .1, .05, .03, .01, .01])
+    assert run(T5)["bits_per_char"] == 8

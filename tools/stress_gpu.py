@@ -64,7 +64,9 @@ def text(kind, n):
 kinds = ["uniform", "skew", "two", "bytes", "periodic", "planted", "runs", "stretches", "stretches"]
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from sa_check import sa_lcp                 # independent prefix-doubling construction: not quadratic on stretches
-t0 = time.time(); done = 0; oom = 0; stats = {"slot_splits": 0, "slot_splits_redone": 0, "long_runs": 0}
+t0 = time.time(); done = 0; oom = 0
+stats = {"slot_splits": 0, "slot_splits_redone": 0, "long_runs": 0, "path_direct": 0, "direct_quantile": 0}
+fallbacks = {}
 while time.time() - t0 < budget:
     kind = kinds[rs.randint(len(kinds))]
     big = rs.rand() < 0.25
@@ -78,6 +80,13 @@ while time.time() - t0 < budget:
     if os.environ.get("STRESS_CAP_P"): p = p_mem
     bits = 64 if rs.rand() < 0.2 else 32
     T = text(kind, n)
+    # which construction: the default choice, or forced (the library reads these at every build)
+    os.environ["CAPS_SA_PATH"] = str(rs.choice(["auto", "auto", "auto", "classic"]))
+    mode = str(rs.choice(["auto", "auto", "linear", "quantile"]))
+    if mode == "auto": os.environ.pop("CAPS_SA_DIRECT_MODE", None)
+    else: os.environ["CAPS_SA_DIRECT_MODE"] = mode
+    if rs.rand() < 0.3: os.environ["CAPS_SA_DIRECT_SUB"] = str(rs.choice([1, 2, 8]))
+    else: os.environ.pop("CAPS_SA_DIRECT_SUB", None)
     try:
         SA, LCP, st = L.build(T, p=p, idx_bits=bits)
     except caps_sa_amd.CapsSaError as e:         # p^2 matrices beyond the device memory (as in the reference: p^2 on the host)
@@ -89,8 +98,11 @@ while time.time() - t0 < budget:
     ok = np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo)
     if not ok:
         np.save(os.environ.get("STRESS_DUMP", "/tmp/stress_fail_T.npy"), T)
-        print(json.dumps({"FAIL": True, "kind": kind, "n": n, "p": p, "bits": bits}))
+        print(json.dumps({"FAIL": True, "kind": kind, "n": n, "p": p, "bits": bits, "path": os.environ.get("CAPS_SA_PATH"),
+                          "mode": os.environ.get("CAPS_SA_DIRECT_MODE"), "sub": os.environ.get("CAPS_SA_DIRECT_SUB"),
+                          "stats": {k: st[k] for k in ("path_direct", "path_fallback", "direct_quantile", "direct_groups")}}))
         sys.exit(1)
     for k in stats: stats[k] += st[k]
+    if st["path_fallback"]: fallbacks[st["path_fallback"]] = fallbacks.get(st["path_fallback"], 0) + 1
     done += 1
-print(json.dumps({"builds": done, "out_of_memory": oom, "seconds": round(time.time() - t0, 1), **stats}))
+print(json.dumps({"builds": done, "out_of_memory": oom, "seconds": round(time.time() - t0, 1), **stats, "fallbacks_by_code": fallbacks}))
