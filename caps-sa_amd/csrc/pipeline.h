@@ -968,9 +968,13 @@ private:
             CAPS_LAUNCH(knots_kernel, (uint32_t)((NB + 255) / 256), 256, be_, (const uint64_t*)smp2.key, m2, NB, KPG, K1, pl_.knots, pl_.gkey);
             rstart = pl_.rstart;
             rcap = pl_.rcap;
-            const uint64_t token = 2 * GA_E / K1 + 16;                   // room for the stray elements of an (expectedly) empty stream
-            CAPS_LAUNCH(group_caps_kernel, (K1 + 255) / 256, 256, be_, (const uint64_t*)pl_.knots, NB, KPG, K1, SUB,
-                        capA > token ? capA - token : capA, token, rcap);
+            // every stream gets `token` elements of room on top of its share (the stray elements of an expectedly empty stream);
+            // the shares add up to (capA - token) * streams, so all regions together are exactly the capA * streams elements
+            // of the buffer -- which only works when the budget per stream can carry the token (found by tools/stress_gpu.py:
+            // sub-streams forced on a 9-tile text gave regions that overran the buffer)
+            const uint64_t token = 2 * GA_E / K1 + 16;
+            if (capA <= 2 * token) { path_fallback_ = CAPS_SA_FB_SHAPE; direct_quantile_ = 0; return false; }
+            CAPS_LAUNCH(group_caps_kernel, (K1 + 255) / 256, 256, be_, (const uint64_t*)pl_.knots, NB, KPG, K1, SUB, capA - token, token, rcap);
             CAPS_LAUNCH(scan_sizes_kernel, 1, 1024, be_, (const uint64_t*)rcap, n_streams, rstart);
         }
         CAPS_LAUNCH(split_lut_kernel, (SPLIT_LUT_CELLS + 256) / 256, 256, be_, (const uint64_t*)pl_.gkey, K1 - 1, pl_.glut, dflag + 1);

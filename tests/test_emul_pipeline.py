@@ -338,3 +338,18 @@ def test_direct_path_modes_and_fallbacks(oracle, monkeypatch):
     assert st["path_direct"] == 0 and st["path_fallback"] == 4             # CAPS_SA_FB_PIVOT_TIES: one key covers the text
     T5 = rs.choice(np.frombuffer(b"abcdefgh", dtype=np.uint8), size=120_000, p=[.5, .2, .1, .1, .05, .03, .01, .01])
     assert run(T5)["bits_per_char"] == 8
+
+
+def test_forced_substreams_on_a_nine_tile_text(oracle, monkeypatch):
+    """Found by tools/stress_gpu.py on the GPU (and replayed here): quantile mode with 8 sub-streams forced on a text of nine
+    level-A tiles -- the token room per stream exceeded the budget per stream, the regions overran the buffer, SA was not a
+    permutation.  The attempt is now refused (shape) and the samplesort path builds it."""
+    rs = np.random.RandomState(1)
+    T = rs.choice(DNA, size=142_867)
+    SAo, LCPo = oracle.build_sa_lcp(T, p=64)
+    for mode in ("quantile", "linear"):
+        for sub in ("8", "2", "1"):
+            monkeypatch.setenv("CAPS_SA_DIRECT_MODE", mode)
+            monkeypatch.setenv("CAPS_SA_DIRECT_SUB", sub)
+            SA, LCP, st = emul().build(T, p=50)
+            assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), (mode, sub, st)

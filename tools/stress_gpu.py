@@ -87,6 +87,8 @@ while time.time() - t0 < budget:
     else: os.environ["CAPS_SA_DIRECT_MODE"] = mode
     if rs.rand() < 0.3: os.environ["CAPS_SA_DIRECT_SUB"] = str(rs.choice([1, 2, 8]))
     else: os.environ.pop("CAPS_SA_DIRECT_SUB", None)
+    if os.environ.get("STRESS_ONLY_N") and n != int(os.environ["STRESS_ONLY_N"]):
+        continue                                 # replaying one case of a sequence: same random draws, nothing built
     try:
         SA, LCP, st = L.build(T, p=p, idx_bits=bits)
     except caps_sa_amd.CapsSaError as e:         # p^2 matrices beyond the device memory (as in the reference: p^2 on the host)
