@@ -58,6 +58,8 @@ class Stats(ctypes.Structure):
         ("direct_quantile", ctypes.c_uint32),
         ("direct_max_group", ctypes.c_uint64),
         ("level_a_ms", ctypes.c_double),
+        ("direct_key_bits", ctypes.c_uint32),
+        ("reserved_", ctypes.c_uint32),
     ]
 
     def as_dict(self) -> dict:

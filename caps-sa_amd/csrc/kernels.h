@@ -726,6 +726,18 @@ constexpr uint32_t EQ_BIN_LIMIT = CAPS_EQ_BIN_LIMIT;
 // keys (text only on equal keys).
 // LDS: TILE_E x (8 + sizeof(idx_t)).
 // ----------------------------------------------------------------------------------
+// LCP of two neighbours of a sorted tile from their keys, 64-bit or 32-bit (text.h); cs: the 32-bit keys' shift
+template <int BITS, bool RUNS>
+DEV_INLINE uint64_t tile_pair_lcp(const uint32_t* __restrict__ P, uint64_t n, uint64_t ka, uint64_t a, uint64_t kb, uint64_t b, uint32_t)
+{
+    return pair_lcp<BITS, RUNS>(P, n, ka, a, kb, b);
+}
+template <int BITS, bool RUNS>
+DEV_INLINE uint64_t tile_pair_lcp(const uint32_t* __restrict__ P, uint64_t n, uint32_t ka, uint64_t a, uint32_t kb, uint64_t b, uint32_t cs)
+{
+    return pair_lcp32<BITS, RUNS>(P, n, ka, a, kb, b, cs);
+}
+
 // Shared pieces of the two tile sort kernels (macros: they use the kernels' TL registers).
 #define TILE_SORT_PROLOGUE                                                                                      \
     const uint32_t b = K_BLOCK_IDX;                                                                             \
@@ -756,11 +768,14 @@ constexpr uint32_t EQ_BIN_LIMIT = CAPS_EQ_BIN_LIMIT;
                 if (FROM_TEXT) {                                                                                \
                     key = window64<BITS>(P, text_base + start + e);                                             \
                     sa = (idx_t)(text_base + start + e);                                                        \
+                } else if (TILE_KEYS_FROM_TEXT) {   /* 32-bit keys in the slots: the 64-bit key is cut from the text */ \
+                    sa = in_sa[in0 + e];                                                                        \
+                    key = window64<BITS>(P, (uint64_t)sa);                                                      \
                 } else {                                                                                        \
                     key = in_key[in0 + e];                                                                      \
                     sa = in_sa[in0 + e];                                                                        \
                 }                                                                                               \
-                TL(rk, tid, k) = key;                                                                           \
+                TL(rk, tid, k) = (decltype(TL(rk, tid, k) + 0))key;                                             \
                 TL(rs, tid, k) = sa;                                                                            \
             }                                                                                                   \
         }                                                                                                       \
@@ -779,7 +794,7 @@ constexpr uint32_t EQ_BIN_LIMIT = CAPS_EQ_BIN_LIMIT;
             for (uint32_t k = 0; k < TILE_EPT; ++k) {                                                           \
                 const uint32_t e = tid + k * TILE_NT;                                                           \
                 if (e < cnt) {                                                                                  \
-                    const uint64_t key = TL(rk, tid, k);                                                        \
+                    const uint64_t key = (uint64_t)TL(rk, tid, k);                                              \
                     mn = key < mn ? key : mn;                                                                   \
                     mx = key > mx ? key : mx;                                                                   \
                 }                                                                                               \
@@ -815,7 +830,7 @@ constexpr uint32_t EQ_BIN_LIMIT = CAPS_EQ_BIN_LIMIT;
                 const uint64_t key = skey[e];                                                                   \
                 const idx_t sa = ssa[e];                                                                        \
                 uint64_t l = 0;                                                                                 \
-                if (with_lcp && e) l = pair_lcp<BITS, TILE_RUNS>(P, n, skey[e - 1], (uint64_t)ssa[e - 1], key, (uint64_t)sa); \
+                if (with_lcp && e) l = tile_pair_lcp<BITS, TILE_RUNS>(P, n, skey[e - 1], (uint64_t)ssa[e - 1], skey[e], (uint64_t)sa, TILE_KEY_SHIFT); \
                 if (direct) {                                                                                   \
                     fin.sa[start + e] = sa;                                                                     \
                     fin.lcp[start + e] = (idx_t)l;                                                              \
@@ -838,21 +853,29 @@ constexpr uint32_t EQ_BIN_LIMIT = CAPS_EQ_BIN_LIMIT;
 // TILE_BIN_LIMIT elements (always on keys that are roughly uniform in their range: random DNA,
 // buckets of the bucketing stage); otherwise it writes nothing and sets redo[tile], and
 // tile_sort_general_kernel sorts the tile.
-template <typename idx_t, int BITS, bool FROM_TEXT>
+// KT = uint32_t: the slots hold 32-bit keys (text.h key32_of; kshift[bucket] = the shift of the bucket's group).  Only
+// completed segments written straight to SA / LCP (`direct`) exist then; a tile this kernel cannot finish is re-sorted by the
+// kernels below from 64-bit keys cut from the text.
+template <typename idx_t, int BITS, bool FROM_TEXT, typename KT = uint64_t>
 GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
-                                                  uint64_t text_base, uint32_t lcp_mode, uint32_t slot_cap, const uint64_t* in_key,
+                                                  uint64_t text_base, uint32_t lcp_mode, uint32_t slot_cap, const KT* in_key,
                                                   const idx_t* in_sa, uint64_t* out_key, idx_t* out_sa, idx_t* out_lcp,
                                                   FinalOut<idx_t> fin, const BucketParams* __restrict__ seg_map,
-                                                  uint32_t* __restrict__ redo)
+                                                  uint32_t* __restrict__ redo, const uint8_t* __restrict__ kshift)
 {
     constexpr bool TILE_RUNS = false;        // ties here are shallow (suffix_less_tie_bounded), so are the LCPs
+    constexpr bool K32 = sizeof(KT) == 4;
+    constexpr bool TILE_KEYS_FROM_TEXT = false;
+    static_assert(!K32 || !FROM_TEXT, "32-bit keys come from the slots of level B");
     TILE_SORT_PROLOGUE
-    SHARED_ARRAY(uint64_t, skey, TILE_E);
+    const uint32_t TILE_KEY_SHIFT = K32 ? kshift[g] : 0u;                                  // block-uniform
+    const uint32_t tie_from = K32 ? (TILE_KEY_SHIFT + 32u) / BITS : TextTraits<BITS>::KCH;   // chars two equal keys stand for
+    SHARED_ARRAY(KT, skey, TILE_E);
     SHARED_ARRAY(idx_t, ssa, TILE_E);
     SHARED_ARRAY(uint32_t, hist, TILE_BINS + 1);
     SHARED_ARRAY(uint64_t, kmm, 2);          // min / max key of the tile
     SHARED_ARRAY(uint32_t, flag, 1);         // a bin overflowed
-    TL_DECL(uint64_t, rk, TILE_EPT);
+    TL_DECL(KT, rk, TILE_EPT);
     TL_DECL(idx_t, rs, TILE_EPT);
     TL_DECL(uint32_t, rd, TILE_EPT);
     TL_DECL(uint32_t, rb, TILE_EPT);
@@ -910,7 +933,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
                         const uint64_t kj = skey[j];
                         less += kj < key ? 1u : 0u;
                         if (kj == key && j != slot) {                                                               // rare: text
-                            const uint32_t c = suffix_less_tie_bounded<BITS>(P, n, (uint64_t)ssa[j], sa);
+                            const uint32_t c = suffix_less_tie_bounded<BITS>(P, n, (uint64_t)ssa[j], sa, tie_from);
                             if (c == 2u) flag[0] = 1;                                                               // a deep tie: not here
                             less += c & 1u;
                         }
@@ -973,9 +996,13 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_eq_kernel(KCTX 
                                                   uint64_t text_base, uint32_t lcp_mode, uint32_t slot_cap, const uint64_t* in_key,
                                                   const idx_t* in_sa, uint64_t* out_key, idx_t* out_sa, idx_t* out_lcp,
                                                   FinalOut<idx_t> fin, const BucketParams* __restrict__ seg_map,
-                                                  const uint32_t* __restrict__ redo, uint32_t* __restrict__ redo2)
+                                                  const uint32_t* __restrict__ redo, uint32_t* __restrict__ redo2, uint32_t keys_from_text)
 {
+    // keys_from_text != 0: the slots hold 32-bit keys (tile_sort_kernel<..., uint32_t> ran first); this kernel works on the
+    // 64-bit keys, cut from the text at the elements' positions (seg_map is then null: the tile's own key range)
     constexpr bool TILE_RUNS = false;
+    const bool TILE_KEYS_FROM_TEXT = keys_from_text != 0;
+    const uint32_t TILE_KEY_SHIFT = 0;
     SHARED_ARRAY(uint64_t, skey, TILE_E);
     SHARED_ARRAY(idx_t, ssa, TILE_E);
     SHARED_ARRAY(uint32_t, hist, TILE_BINS + 1);
@@ -1134,8 +1161,9 @@ template <typename idx_t, int BITS, bool FROM_TEXT, bool RUNS>
 GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_general_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
                                                           uint64_t text_base, uint32_t lcp_mode, uint32_t slot_cap, const uint64_t* in_key,
                                                           const idx_t* in_sa, uint64_t* out_key, idx_t* out_sa, idx_t* out_lcp,
-                                                          FinalOut<idx_t> fin, const uint32_t* __restrict__ redo)
+                                                          FinalOut<idx_t> fin, const uint32_t* __restrict__ redo, uint32_t keys_from_text)
 {
+    const uint32_t TILE_KEY_SHIFT = 0;
     SHARED_ARRAY(uint64_t, skey, TILE_E);
     SHARED_ARRAY(idx_t, ssa, TILE_E);
     SHARED_ARRAY(uint64_t, smk, 2 * TILE_NT);       // samples (2x: the fixed-depth search may probe past the end)
@@ -1173,6 +1201,9 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_general_kernel(
                 if (FROM_TEXT) {
                     key = window64<BITS>(P, text_base + start + e);
                     sa = (idx_t)(text_base + start + e);
+                } else if (keys_from_text) {                      // 32-bit keys in the slots: the 64-bit key is cut from the text
+                    sa = in_sa[in0 + e];
+                    key = window64<BITS>(P, (uint64_t)sa);
                 } else {
                     key = in_key[in0 + e];
                     sa = in_sa[in0 + e];
@@ -1632,8 +1663,9 @@ GLOBAL_FN LAUNCH_BOUNDS(256) finalize_kernel(KCTX SegDesc sd, const uint32_t* __
 // lcp(last suffix of the nearest non-empty segment below, first suffix of this one).
 template <typename idx_t, int BITS>
 GLOBAL_FN LAUNCH_BOUNDS(256) head_lcp_kernel(KCTX const uint32_t* __restrict__ P, uint64_t n, const uint64_t* __restrict__ seg_start,
-                                             uint32_t G, FinalOut<idx_t> fin)
+                                             uint32_t G, FinalOut<idx_t> fin, uint32_t from_text)
 {
+    // from_text: the boundary records hold 32-bit keys of (possibly) different groups: the head LCPs come from the text
     PAR(tid) {
         const uint64_t g = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
         if (g < G && g > 0) {
@@ -1641,8 +1673,9 @@ GLOBAL_FN LAUNCH_BOUNDS(256) head_lcp_kernel(KCTX const uint32_t* __restrict__ P
             if (seg_start[g + 1] > at && at > 0) {
                 uint64_t h = g - 1;
                 while (seg_start[h + 1] == seg_start[h]) --h;             // at > 0: a non-empty one exists below
-                fin.lcp[at] = (idx_t)pair_lcp<BITS>(P, n, fin.last_key[h], (uint64_t)fin.last_sa[h], fin.first_key[g],
-                                                    (uint64_t)fin.first_sa[g]);
+                fin.lcp[at] = from_text ? (idx_t)deep_lcp<BITS>(P, n, (uint64_t)fin.last_sa[h], (uint64_t)fin.first_sa[g], 0)
+                                        : (idx_t)pair_lcp<BITS>(P, n, fin.last_key[h], (uint64_t)fin.last_sa[h], fin.first_key[g],
+                                                                (uint64_t)fin.first_sa[g]);
             }
         }
     }
@@ -1788,6 +1821,15 @@ constexpr int SRC_ARRAYS = 0, SRC_TEXT = 1, SRC_RUNS = 2;      // where a bucket
 constexpr uint32_t BUCKET_TARGET = (TILE_E * CAPS_BUCKET_EIGHTHS) / 8;   // mean bucket size (headroom for the spread of bucket sizes)
 constexpr uint32_t BUCKET_LDS = TILE_BINS_;            // buckets per segment the LDS histogram can hold
 
+// (kmin exclusive unless the first group, kmax inclusive) in 64-bit keys -> [kmin, kmax] in the group's 32-bit keys
+DEV_INLINE void key32_range(uint64_t& kmin, uint64_t& kmax, bool kmin_exclusive, uint32_t cs)
+{
+    const uint64_t lo = kmin_exclusive ? kmin + 1 : kmin;
+    if (lo > kmax || (kmin_exclusive && kmin == ~0ull)) { kmin = kmax = 0; return; }      // an empty group
+    kmin = key32_of(lo, cs);
+    kmax = key32_of(kmax, cs);
+}
+
 // range_mode 0: keys span the whole 64-bit range (subarrays of text positions);
 // range_mode 1: segment g is partition j = part_off + g of part_total and holds keys in
 // [pkey[j-1], pkey[j]] (partitions between pivots; a shard owns a slice of the partitions).
@@ -1795,8 +1837,10 @@ GLOBAL_FN LAUNCH_BOUNDS(256) bucket_plan_kernel(KCTX const uint64_t* __restrict_
                                                 uint32_t G, uint32_t range_mode,
                                                 const uint64_t* __restrict__ pkey, uint32_t part_off, uint32_t part_total,
                                                 uint32_t enable, uint32_t fine, uint32_t sub,
-                                                BucketParams* __restrict__ bp, uint64_t* __restrict__ segB)
+                                                BucketParams* __restrict__ bp, uint64_t* __restrict__ segB,
+                                                const uint8_t* __restrict__ gshift)
 {
+    // range_mode 2: as 1, in the space of the parent's 32-bit keys (key32_of with gshift[parent], text.h)
     // sub > 1: every `sub` consecutive segments are the sub-streams of ONE parent (a group of the direct path, written
     // by level A as one stream per XCD): they share the parent's key range and its buckets.  All of them get the parent's
     // map; the bucket count is credited to the LAST sub-stream only, so that the exclusive scan of segB gives every
@@ -1808,10 +1852,11 @@ GLOBAL_FN LAUNCH_BOUNDS(256) bucket_plan_kernel(KCTX const uint64_t* __restrict_
             uint64_t len = 0;
             for (uint32_t x = 0; x < sub && first + x < G; ++x) len += seg_end_of(seg_start, seg_end, first + x) - seg_start[first + x];
             uint64_t kmin = 0, kmax = ~0ull;
-            if (range_mode == 1) {                   // the parent is partition part_off + parent of part_total
+            if (range_mode >= 1) {                   // the parent is partition part_off + parent of part_total
                 const uint32_t j = part_off + parent;
                 if (j > 0) kmin = pkey[j - 1];
                 if (j + 1 < part_total) kmax = pkey[j];
+                if (range_mode == 2) key32_range(kmin, kmax, j > 0, gshift[j]);
             }
             uint32_t B = 1;
             if (enable && len > TILE_E && kmax > kmin) B = (uint32_t)((len + BUCKET_TARGET - 1) / BUCKET_TARGET);
@@ -1905,8 +1950,10 @@ GLOBAL_FN LAUNCH_BOUNDS(256) bucket_ranges_kernel(KCTX const uint64_t* __restric
                                                   const BucketParams* __restrict__ bps, const uint64_t* __restrict__ pkey,
                                                   uint32_t range_mode, uint32_t part_off, uint32_t part_total, uint32_t sub,
                                                   BucketParams* __restrict__ tile_map,
-                                                  const BucketParams* __restrict__ fbps, const uint32_t* __restrict__ gfirst)
+                                                  const BucketParams* __restrict__ fbps, const uint32_t* __restrict__ gfirst,
+                                                  const uint8_t* __restrict__ gshift, uint8_t* __restrict__ kshift)
 {
+    // range_mode 2 (32-bit keys): the ranges are in the parent's key32 space; kshift[bucket] = the parent's shift
     // gfirst != null (equalised split): bucket slot i is the group of fine buckets [gfirst[i], gfirst[i + 1]) of fbps[g]
     PAR(tid) {
         const uint64_t i = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
@@ -1919,10 +1966,11 @@ GLOBAL_FN LAUNCH_BOUNDS(256) bucket_ranges_kernel(KCTX const uint64_t* __restric
             const uint32_t g = a;
             const BucketParams bp = bps[g];
             uint64_t kmin = 0, kmax = ~0ull;
-            if (range_mode == 1) {
+            if (range_mode >= 1) {
                 const uint32_t j = part_off + g / sub;            // sub-streams of one parent share its buckets (bucket_plan_kernel)
                 if (j > 0) kmin = pkey[j - 1];
                 if (j + 1 < part_total) kmax = pkey[j];
+                if (range_mode == 2) { key32_range(kmin, kmax, j > 0, gshift[j]); kshift[i] = gshift[j]; }
             }
             const uint32_t bk = (uint32_t)(i - bstart[g]);
             const double range1 = (double)(kmax - kmin) + 1.0;
@@ -2059,14 +2107,15 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_count_kernel(KCTX SegDesc sd, const uint
 // cursor bump per (tile, non-empty bucket); the tile is then re-ordered by bucket in LDS so
 // that consecutive lanes write consecutive slots (a bucket receives a run of consecutive
 // elements from every tile instead of 64 scattered 8-byte stores per wave instruction).
-template <typename idx_t, int BITS, int SRC, int MAP>
+// KT = uint32_t (SRC_ARRAYS, MAP_LINEAR only): the elements carry 32-bit keys in and out, the map lives in their space.
+template <typename idx_t, int BITS, int SRC, int MAP, typename KT = uint64_t>
 GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n_words,
-                                                       uint64_t text_base, const uint64_t* __restrict__ in_key,
+                                                       uint64_t text_base, const KT* __restrict__ in_key,
                                                        const idx_t* __restrict__ in_sa, RunSrc<idx_t> rsrc,
                                                        const BucketParams* __restrict__ bps, const uint64_t* __restrict__ bstart,
                                                        const uint64_t* __restrict__ sub_start, uint64_t slot_cap,
                                                        idx_t* __restrict__ cursor,
-                                                       uint64_t* __restrict__ out_key, idx_t* __restrict__ out_sa,
+                                                       KT* __restrict__ out_key, idx_t* __restrict__ out_sa,
                                                        const BucketParams* __restrict__ fbps, const uint32_t* __restrict__ gfirst,
                                                        const uint64_t* __restrict__ split, const uint16_t* __restrict__ split_lut,
                                                        const uint32_t* __restrict__ split_span, uint32_t sub, uint32_t split_stride,
@@ -2106,10 +2155,11 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
     SHARED_ARRAY(uint32_t, hist, TILE_BINS + 1);          // counts -> exclusive prefix inside the tile
     SHARED_ARRAY(idx_t, obase, TILE_BINS);                // global slot of the tile's first element of bucket i, minus its prefix
                                                           // (idx_t: 72 KiB of LDS at 32-bit indices -> two workgroups per CU)
-    SHARED_ARRAY(uint64_t, skey, TILE_E);
+    static_assert(sizeof(KT) == 8 || (SRC == SRC_ARRAYS && MAP == MAP_LINEAR), "32-bit keys: arrays in, linear map");
+    SHARED_ARRAY(KT, skey, TILE_E);
     SHARED_ARRAY(idx_t, ssa, TILE_E);
     SHARED_ARRAY(uint16_t, sbk, TILE_E);
-    TL_DECL(uint64_t, rk, TILE_EPT);
+    TL_DECL(KT, rk, TILE_EPT);
     TL_DECL(idx_t, rs, TILE_EPT);
     TL_DECL(uint32_t, rb, TILE_EPT);      // bucket
     TL_DECL(idx_t, rr, TILE_EPT);         // rank inside (tile, bucket) or inside the bucket (idx_t: a bucket of a
@@ -2118,14 +2168,15 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
     const bool lds = bp.B > 1 && bp.B <= BUCKET_LDS;
     // FROM_TEXT: the tile's slice of the packed text is staged in the (not yet used) key staging array;
     // FROM_RUNS: the runs the tile spans are staged in the (not yet used) key and index staging arrays
+    // (64-bit keys only: the staging arrays are large enough for these guests)
     uint32_t* twin = reinterpret_cast<uint32_t*>(skey);
-    uint64_t* lsrc = skey;
+    uint64_t* lsrc = reinterpret_cast<uint64_t*>(skey);
     idx_t* lrow = ssa;
     uint16_t* gtab = sbk;                                  // fine bucket -> bucket slot of the segment (sbk is written after its last use)
     static_assert(TILE_E >= BUCKET_LDS && BUCKET_LDS <= 65536, "group table fits the bucket-id staging array");
     const uint64_t w0 = text_win_base<BITS>(text_base + start);
     // MAP_SPLIT: the splitter table sits in the key staging array too, behind the text window
-    uint64_t* stab = skey + TILE_E / 4;
+    uint64_t* stab = reinterpret_cast<uint64_t*>(skey) + TILE_E / 4;
     uint16_t* slut = reinterpret_cast<uint16_t*>(ssa);    // ... and its LUT in the index staging array
     static_assert(TEXT_WIN * sizeof(uint32_t) <= (TILE_E / 4) * sizeof(uint64_t) && TILE_E / 4 + BUCKET_LDS <= TILE_E,
                   "text window + splitter table fit the key staging array");
@@ -2322,15 +2373,19 @@ constexpr uint32_t GA_E = GA_TILES * TILE_E;
 constexpr uint32_t GA_EPT = GA_E / TILE_NT;
 static_assert(GA_E <= (1u << 14) && BUCKET_LDS <= (1u << 11), "group << 14 | position fits a register");
 
-template <typename idx_t, int BITS>
+// KT = uint32_t: the elements leave with 32-bit keys, key32_of(key, gshift[group]) (text.h).
+template <typename idx_t, int BITS, typename KT = uint64_t>
 GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) group_scatter_kernel(KCTX const uint32_t* __restrict__ P, uint64_t n_words,
                                                       uint64_t text_base, uint64_t len, const uint64_t* __restrict__ split, uint32_t K1,
                                                       const uint16_t* __restrict__ split_lut, const uint32_t* __restrict__ split_span,
                                                       uint32_t sub, uint64_t slot_cap, idx_t* __restrict__ cursor,
-                                                      uint64_t* __restrict__ out_key, idx_t* __restrict__ out_sa,
+                                                      KT* __restrict__ out_key, idx_t* __restrict__ out_sa,
                                                       uint32_t tile_first, uint32_t tile_stride,
-                                                      const uint64_t* __restrict__ region_start, const uint64_t* __restrict__ region_cap)
+                                                      const uint64_t* __restrict__ region_start, const uint64_t* __restrict__ region_cap,
+                                                      const uint8_t* __restrict__ gshift)
 {
+    constexpr bool K32 = sizeof(KT) == 4;
+    SHARED_ARRAY(uint8_t, scs, K32 ? BUCKET_LDS : 1);
     // region_start != null: stream s = g * sub + sx owns [region_start[s], + region_cap[s]) instead of the uniform
     // [s * slot_cap, + slot_cap) -- groups that share a frequent key get the room of all of them (group_caps_kernel).
     // Workgroup b takes tile tile_first + b * tile_stride of [text_base, text_base + len): a rank of a sharded build takes
@@ -2359,6 +2414,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) group_scatter_kernel(KCTX
         for (uint32_t i = tid; i < WIN; i += K_BLOCK_DIM) twin[i] = w0 + i < n_words ? P[w0 + i] : 0u;
         for (uint32_t i = tid; i < n_split; i += K_BLOCK_DIM) stab[i] = split[i];
         for (uint32_t i = tid; i <= SPLIT_LUT_CELLS; i += K_BLOCK_DIM) slut[i] = split_lut[i];
+        if (K32) for (uint32_t i = tid; i < K1; i += K_BLOCK_DIM) scs[i] = gshift[i];
     }
     SYNC();
     // ---- classify: group = #{splitters < key} (LUT cell -> a few candidates -> branch-free search), rank inside (tile, group)
@@ -2451,7 +2507,8 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) group_scatter_kernel(KCTX
                     const idx_t ob = obase[g];
                     if (ob != NO_SLOT) {
                         const uint64_t dst = (uint64_t)ob + (q - hist[g]);
-                        out_key[dst] = window64<BITS>(twin, pos0 + e - w0 * CPW);
+                        const uint64_t key = window64<BITS>(twin, pos0 + e - w0 * CPW);
+                        out_key[dst] = K32 ? (KT)key32_of(key, scs[g]) : (KT)key;
                         out_sa[dst] = (idx_t)(pos0 + e);
                     }
                 }
@@ -2601,6 +2658,21 @@ GLOBAL_FN LAUNCH_BOUNDS(256) group_keys_kernel(KCTX const uint64_t* __restrict__
             }
         }
         if (j + 1 < K1) gkey[j] = pkey[(uint64_t)(j + 1) * PG - 1];
+    }
+}
+
+// 32-bit keys (text.h key32_of): gshift[g] = bits all keys of group g share = the common bit prefix of its smallest
+// possible key (the previous group key + 1) and its largest (its own group key), at most 32.
+GLOBAL_FN LAUNCH_BOUNDS(256) group_shift_kernel(KCTX const uint64_t* __restrict__ gkey, uint32_t K1, uint8_t* __restrict__ gshift)
+{
+    PAR(tid) {
+        const uint32_t g = K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (g < K1) {
+            const uint64_t lo = g ? gkey[g - 1] + 1 : 0, hi = g + 1 < K1 ? gkey[g] : ~0ull;
+            const uint64_t x = lo ^ hi;
+            const uint32_t c = x ? (uint32_t)caps_clz64(x) : 32u;
+            gshift[g] = (uint8_t)(lo > hi ? 0u : c < 32u ? c : 32u);       // (lo > hi: gkey[g-1] was the largest key; the group is empty)
+        }
     }
 }
 

@@ -101,6 +101,7 @@ struct BucketBufs {
     uint64_t* fstart = nullptr;       // [G+1]
     uint64_t* fcount = nullptr;       // [EQ_FINE * nb_cap]
     uint32_t* gfirst = nullptr;       // [nb_cap] first fine bucket of every slot's group
+    uint8_t* kshift = nullptr;        // [nb_cap] 32-bit keys: the shift of every bucket's parent group
     uint32_t nb_cap = 0;
     uint64_t tile_cap = 0;
     // buckets of a sort: mean size BUCKET_TARGET (linear maps) or BUCKET_Q (quantile mode), at least two per segment
@@ -127,6 +128,7 @@ template <typename idx_t> struct Plan {
                                      //         (u32 skew flag, u32 longest run of equal pivot keys)}
     idx_t* dcur = nullptr;           // [gseg] direct path: level A's cursors = sizes of the groups' sub-streams
     uint16_t* glut = nullptr;        // [SPLIT_LUT_CELLS + 1] direct path: LUT over the group keys (split_lut_kernel)
+    uint8_t* gshift = nullptr;       // [gseg] direct path, 32-bit keys: the groups' shifts (group_shift_kernel)
     uint64_t* knots = nullptr;       // [nb_cap] quantile mode: upper key of every bucket
     uint64_t* rcap = nullptr;        // [gseg]   quantile mode: capacity of every stream's region
     uint64_t* rstart = nullptr;      // [gseg+1]                 ... and where it starts
@@ -203,6 +205,7 @@ Plan<idx_t> make_plan(uint64_t n, uint64_t p_arg, char* base)
         pl.dstat = ar.take<uint64_t>(4);
         pl.dcur = ar.take<idx_t>(gseg);
         pl.glut = ar.take<uint16_t>(SPLIT_LUT_CELLS + 2);
+        pl.gshift = ar.take<uint8_t>(gseg);
         pl.knots = ar.take<uint64_t>(pl.bk.nb_cap);
         pl.rcap = ar.take<uint64_t>(gseg);
         pl.rstart = ar.take<uint64_t>((size_t)gseg + 1);
@@ -230,6 +233,7 @@ Plan<idx_t> make_plan(uint64_t n, uint64_t p_arg, char* base)
     pl.bk.fstart = ar.take<uint64_t>((size_t)gseg + 1);
     pl.bk.fcount = ar.take<uint64_t>((size_t)EQ_FINE * pl.bk.nb_cap);
     pl.bk.gfirst = ar.take<uint32_t>(pl.bk.nb_cap);
+    pl.bk.kshift = ar.take<uint8_t>(pl.bk.nb_cap);
     pl.pass_elems = ar.take<uint64_t>(kMaxPasses);
     pl.present = ar.take<uint32_t>(8);
     pl.lut = ar.take<uint8_t>(256);
@@ -366,6 +370,8 @@ template <typename idx_t> struct SortResult {
     uint32_t passes = 0;
     bool skip_finished = false;
     bool unified = false;                                             // everything was gathered into buf[0]
+    bool k32 = false;                                                 // sorted with 32-bit keys (boundary LCPs come from the text)
+    bool failed = false;                                              // k32 only: a slot overflowed, nothing was sorted
     SegBufs segs;                                                     // the segments that were sorted (buckets, if bucketed)
     uint32_t n_tiles = 0;
     FinalOut<idx_t> fin;                                              // direct final output (may be empty)
@@ -395,6 +401,9 @@ struct SortOpts {
     uint32_t sub = 1;             // > 1: every `sub` consecutive segments are sub-streams of one parent and share its buckets
     const uint64_t* in_key = nullptr;   // non-null: the elements are read from these arrays (indexed like the segments)
     const void* in_sa = nullptr;        //   instead of `cur`, which then only receives results
+    const uint8_t* gshift = nullptr;    // non-null with range_mode 2: 32-bit keys (text.h key32_of), the parents' shifts
+    bool k32 = false;                   // the elements (in_key, read as uint32_t) carry 32-bit keys; slots only: when a slot
+                                        //   overflows the sort gives up (SortResult::failed) and the caller falls back to 64-bit keys
     const uint64_t* knots = nullptr;    // non-null (quantile mode): parent q's buckets are (knots[q * KPG + i - 1], knots[q * KPG + i]],
     uint32_t knots_per_parent = 0;      //   i < KPG = knots_per_parent -- count pass + exact scatter, no slots, no equalising
     const void* runs = nullptr;   // RunSrc<idx_t>*: the segments are partitions still spread over the sorted subarrays in
@@ -452,11 +461,11 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         } else {
         CAPS_LAUNCH(bucket_plan_kernel, (s.G + 255) / 256, 256, be, (const uint64_t*)s.seg_start, s_end, s.G, o.range_mode, o.pkey, o.part_off,
                     o.part_total ? o.part_total : s.G, 1u, 1u, o.sub,
-                    bk.params, bk.segB);
+                    bk.params, bk.segB, o.gshift);
         CAPS_LAUNCH(scan_sizes_kernel, 1, 1024, be, (const uint64_t*)bk.segB, s.G, bk.bstart);
         CAPS_LAUNCH(bucket_ranges_kernel, (bk.nb_cap + 255) / 256, 256, be, (const uint64_t*)bk.bstart, s.G,
                     (const BucketParams*)bk.params, o.pkey, o.range_mode, o.part_off, o.part_total ? o.part_total : s.G, o.sub,
-                    bk.tile_map, (const BucketParams*)nullptr, (const uint32_t*)nullptr);
+                    bk.tile_map, (const BucketParams*)nullptr, (const uint32_t*)nullptr, o.gshift, bk.kshift);
         }
         seg_map = bk.tile_map;
         mark("bucket plan");
@@ -509,11 +518,27 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         const uint64_t slot_elems = nb_here * TILE_E;
         bool slots = false;
         if (by_knots && (from_text || runs)) throw std::invalid_argument("quantile buckets read (key, sa) arrays");
-        if (o.speculate && !by_knots && oth.region_bytes >= slot_elems * (sizeof(uint64_t) + sizeof(idx_t)) &&
-            slot_elems + TILE_E < (uint64_t)std::numeric_limits<idx_t>::max()) {
+        if (o.k32 && (from_text || runs || by_knots || !o.speculate || !o.in_key || !o.final_sa))
+            throw std::invalid_argument("32-bit keys: a slot split of (key32, sa) arrays with direct output");
+        const bool can_slot = o.speculate && !by_knots &&
+                              oth.region_bytes >= slot_elems * ((o.k32 ? sizeof(uint32_t) : sizeof(uint64_t)) + sizeof(idx_t)) &&
+                              slot_elems + TILE_E < (uint64_t)std::numeric_limits<idx_t>::max();
+        if (o.k32 && !can_slot) { r.failed = true; return r; }          // 32-bit keys exist in slots only
+        if (can_slot) {
             slot_key = oth.key;
             slot_sa = reinterpret_cast<idx_t*>(reinterpret_cast<char*>(oth.key) + slot_elems * sizeof(uint64_t));
             be.memset(bk.cursor, 0, (size_t)bk.nb_cap * sizeof(idx_t));
+            if (o.k32) {             // 32-bit keys in and out: the slot view holds (u32 key | idx) per element
+                slot_sa = reinterpret_cast<idx_t*>(reinterpret_cast<char*>(oth.key) + slot_elems * sizeof(uint32_t));
+                BackendEvent s0 = be.record();
+                CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, SRC_ARRAYS, MAP_LINEAR, uint32_t>), n_tiles, TILE_NT, be, psd, P, (uint64_t)0,
+                            (uint64_t)0, reinterpret_cast<const uint32_t*>(o.in_key), src_sa, rsrc, (const BucketParams*)bk.params,
+                            (const uint64_t*)bk.bstart, (const uint64_t*)nullptr, (uint64_t)TILE_E, static_cast<idx_t*>(bk.cursor),
+                            reinterpret_cast<uint32_t*>(slot_key), slot_sa, (const BucketParams*)nullptr, (const uint32_t*)nullptr,
+                            (const uint64_t*)nullptr, (const uint16_t*)nullptr, (const uint32_t*)nullptr, 1u, 0u, 1u);
+                BackendEvent s1 = be.record();
+                if (o.scatter_clock) { o.scatter_clock->spans.push_back({s0, s1}); o.scatter_clock->elems.push_back(n_elems); }
+            } else
             scatter(nullptr, TILE_E, slot_key, slot_sa);
             CAPS_LAUNCH((widen_kernel<idx_t>), (bk.nb_cap + 255) / 256, 256, be, (const idx_t*)static_cast<idx_t*>(bk.cursor),
                         (uint64_t)bk.nb_cap, bk.count);
@@ -521,6 +546,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
             bucket_tiles();
             slots = out2[1] <= TILE_E;
             if (o.slot_stats) ++o.slot_stats[slots ? 0 : 1];
+            if (o.k32 && !slots) { r.failed = true; return r; }
             if (dbg) std::fprintf(stderr, "[sort] slot split: largest bucket %llu -> %s\n", (unsigned long long)out2[1], slots ? "kept" : "redone");
         }
         if (!slots) {
@@ -533,7 +559,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
             uint64_t* ccount = bk.count;
             if (equalise) {
                 CAPS_LAUNCH(bucket_plan_kernel, (s.G + 255) / 256, 256, be, (const uint64_t*)s.seg_start, s_end, s.G, o.range_mode, o.pkey, o.part_off,
-                            o.part_total ? o.part_total : s.G, 1u, EQ_FINE, o.sub, bk.fparams, bk.fsegB);
+                            o.part_total ? o.part_total : s.G, 1u, EQ_FINE, o.sub, bk.fparams, bk.fsegB, o.gshift);
                 CAPS_LAUNCH(scan_sizes_kernel, 1, 1024, be, (const uint64_t*)bk.fsegB, s.G, bk.fstart);
                 be.memset(bk.fcount, 0, (size_t)EQ_FINE * bk.nb_cap * sizeof(uint64_t));
                 cparams = bk.fparams;
@@ -561,7 +587,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
                             (const uint64_t*)bk.fsegB, (const uint64_t*)bk.fstart, (const uint64_t*)bk.fcount, bk.count, bk.gfirst);
                 CAPS_LAUNCH(bucket_ranges_kernel, (bk.nb_cap + 255) / 256, 256, be, (const uint64_t*)bk.bstart, s.G,
                             (const BucketParams*)bk.params, o.pkey, o.range_mode, o.part_off, o.part_total ? o.part_total : s.G, o.sub,
-                            bk.tile_map, (const BucketParams*)bk.fparams, (const uint32_t*)bk.gfirst);
+                            bk.tile_map, (const BucketParams*)bk.fparams, (const uint32_t*)bk.gfirst, o.gshift, bk.kshift);
             }
             BackendEvent c1 = be.record();
             if (o.count_clock) { o.count_clock->spans.push_back({c0, c1}); o.count_clock->elems.push_back(n_elems); }
@@ -614,20 +640,30 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         throw std::invalid_argument("segments in fixed-capacity regions must be bucketed (results are written compactly)");
     const uint64_t* in_key = slot_cap ? slot_key : (o.in_key && segs.seg_start == s.seg_start) ? o.in_key : cur.key;
     const idx_t* in_sa = slot_cap ? slot_sa : (o.in_key && segs.seg_start == s.seg_start) ? static_cast<const idx_t*>(o.in_sa) : cur.sa;
+    const uint8_t* no_shift = nullptr;
+    r.k32 = o.k32 && slot_cap != 0;
     if (from_text) {
         CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, sd, P, n, o.text_base, lcp_mode, 0u,
-                    (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, seg_map, redo);
+                    (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, seg_map, redo, no_shift);
         if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, true>), ggrid, TILE_NT, be, sd, P, n, o.text_base, lcp_mode, 0u,
-                    (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo, redo2);
+                    (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo, redo2, 0u);
         CAPS_LAUNCH_RUNS(tile_sort_general_kernel, (idx_t, BITS, true), ggrid, TILE_NT, be, sd, P, n, o.text_base, lcp_mode, 0u,
-                    (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo2);
+                    (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo2, 0u);
+    } else if (r.k32) {
+        // 32-bit keys in the slots; the tiles the first kernel cannot finish are re-sorted from 64-bit keys cut from the text
+        CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, false, uint32_t>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
+                    reinterpret_cast<const uint32_t*>(in_key), in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, redo, (const uint8_t*)o.bk->kshift);
+        if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false>), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
+                    (const uint64_t*)nullptr, in_sa, cur.key, cur.sa, cur.lcp, fin, (const BucketParams*)nullptr, (const uint32_t*)redo, redo2, 1u);
+        CAPS_LAUNCH_RUNS(tile_sort_general_kernel, (idx_t, BITS, false), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
+                    (const uint64_t*)nullptr, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo2, 1u);
     } else {
         CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
-                    in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, redo);
+                    in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, redo, no_shift);
         if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false>), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
-                    in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo, redo2);
+                    in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo, redo2, 0u);
         CAPS_LAUNCH_RUNS(tile_sort_general_kernel, (idx_t, BITS, false), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
-                    in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo2);
+                    in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo2, 0u);
     }
     BackendEvent t1 = be.record();
     mark("tile sort");
@@ -669,7 +705,7 @@ void finalize(Backend& be, const uint32_t* P, uint64_t n, const SortResult<idx_t
                     r.passes & 1u, dSA, dLCP, r.fin);
     if (r.fin.sa != nullptr)
         CAPS_LAUNCH((head_lcp_kernel<idx_t, BITS>), (r.segs.G + 255) / 256, 256, be, P, n, (const uint64_t*)r.segs.seg_start, r.segs.G,
-                    r.fin);
+                    r.fin, r.k32 ? 1u : 0u);
 }
 
 // Shape of the direct path's two-level distribution: PG consecutive partitions per group, K1 groups.  Level A
@@ -732,7 +768,7 @@ private:
     uint32_t passes1_ = 0, passes2_ = 0, passesS_ = 0;
     BackendEvent e2_, e3_, e4_, e5_, e6_, e7_, la0_, la1_;
     uint64_t max_part_ = 0;
-    uint32_t path_direct_ = 0, path_fallback_ = 0, direct_groups_ = 0, direct_quantile_ = 0;
+    uint32_t path_direct_ = 0, path_fallback_ = 0, direct_groups_ = 0, direct_quantile_ = 0, direct_k32_ = 0;
     uint64_t direct_max_group_ = 0;
 
     // timed: the full-size sorts (phase 1, phase 2) feed the kernel clocks of caps_sa_stats;
@@ -893,7 +929,7 @@ private:
     // Returns false (nothing of the result written) when the keys cannot balance the groups: two pivots with one key
     // or an overflowing group -- long repeats; the samplesort path then does the build.
     template <int BITS>
-    bool run_direct(idx_t* dSA, idx_t* dLCP, uint32_t PG, uint32_t K1, BackendEvent e1)
+    bool run_direct(idx_t* dSA, idx_t* dLCP, uint32_t PG, uint32_t K1, BackendEvent e1, bool allow_k32 = true)
     {
         const uint64_t n = pl_.n, m = pl_.m;
         const uint32_t p = pl_.p;
@@ -934,7 +970,6 @@ private:
         const uint64_t idx_max = (uint64_t)std::numeric_limits<idx_t>::max() - TILE_E;
         if (capA > idx_max / n_streams) capA = idx_max / n_streams;     // region offsets are idx_t in the scatter
         uint64_t* a_key = A.key;
-        idx_t* a_sa = reinterpret_cast<idx_t*>(reinterpret_cast<char*>(A.key) + (uint64_t)n_streams * capA * sizeof(uint64_t));
 
         const char* mode_env = std::getenv("CAPS_SA_DIRECT_MODE");
         bool quantile = probe[0] != 0 || probe[2] != 0;
@@ -947,11 +982,23 @@ private:
         if (m2 > n / 4) m2 = n / 4;
         if (quantile && (KPG < 2 || KPG > BUCKET_LDS || NB > pl_.bk.nb_cap || m2 < 8 * NB || m2 > (1ull << 31))) quantile = false;
         // a single key that covers a large part of the text (a^n) is the samplesort path's business: its exact comparator
-        // splits such a stretch over the partitions, keys cannot
-        if (quantile && probe[3] > p / 32) { path_fallback_ = CAPS_SA_FB_PIVOT_TIES; return false; }
+        // splits such a stretch over the partitions, keys cannot.  Up to a quarter of the text in one key is fine here: all
+        // its suffixes land in one bucket, which the LCP-merge passes finish (20 passes over n / 4 elements at most)
+        if (quantile && probe[3] > p / 4) { path_fallback_ = CAPS_SA_FB_PIVOT_TIES; return false; }
         if (!quantile && probe[0] != 0) { path_fallback_ = CAPS_SA_FB_PIVOT_TIES; return false; }
         uint64_t *rstart = nullptr, *rcap = nullptr;
         direct_quantile_ = quantile ? 1u : 0u;
+        // 32-bit keys (text.h key32_of; CAPS_SA_KEYS=32): linear mode on 2-bit texts; the elements shrink from 8 + w to 4 + w
+        // bytes through level A, level B and the tile sort.  A slot that overflows in level B sends the build back here with
+        // 64-bit keys.  Measured at C3: level A 13.4 -> 11.1 ms, but level B 16.6 -> 18.1 and the tile sort 17.2 ->
+        // 20.3 ms -- the group's shift + 32 bits are ~20 bases, about ten elements of a tile tie and every tile then waits for
+        // text reads -- 52.3 against 49.8 ms per build: NOT the default.  (Its place is the exchange of a sharded build, where
+        // a third fewer bytes cross xGMI; not wired there yet.)
+        const char* keys_env = std::getenv("CAPS_SA_KEYS");
+        const bool k32 = allow_k32 && !quantile && BITS == 2 && keys_env && std::string(keys_env) == "32";
+        direct_k32_ = k32 ? 1u : 0u;
+        idx_t* a_sa = reinterpret_cast<idx_t*>(reinterpret_cast<char*>(A.key) + (uint64_t)n_streams * capA * (k32 ? sizeof(uint32_t) : sizeof(uint64_t)));
+        if (k32) CAPS_LAUNCH(group_shift_kernel, (K1 + 255) / 256, 256, be_, (const uint64_t*)pl_.gkey, K1, pl_.gshift);
         if (quantile) {
             // more samples, sorted in the (still idle) big buffers; their quantiles are the bucket boundaries and, every KPG-th, the group keys
             CAPS_LAUNCH((sample_text_kernel<idx_t, BITS>), (uint32_t)((m2 + 255) / 256), 256, be_, (const uint32_t*)pl_.P, (uint64_t)0, n, m2,
@@ -992,13 +1039,19 @@ private:
         be_.memset(pl_.dcur, 0, (size_t)n_streams * sizeof(idx_t));
         // CAPS_SA_LEVEL_A=tile: the same distribution by bucket_scatter_kernel<SRC_TEXT, MAP_SPLIT> on TILE_E positions (cross-check)
         const char* la = std::getenv("CAPS_SA_LEVEL_A");
-        const bool big_tiles = !(la && std::string(la) == "tile");
+        const bool big_tiles = k32 || !(la && std::string(la) == "tile");
         {
             BackendEvent s0 = be_.record();
-            if (big_tiles)
+            if (k32)
+                CAPS_LAUNCH((group_scatter_kernel<idx_t, BITS, uint32_t>), (uint32_t)((n + GA_E - 1) / GA_E), TILE_NT, be_, (const uint32_t*)pl_.P,
+                            packed_words(n, BITS), (uint64_t)0, n, (const uint64_t*)pl_.gkey, K1, (const uint16_t*)pl_.glut,
+                            (const uint32_t*)(dflag + 1), SUB, capA, pl_.dcur, reinterpret_cast<uint32_t*>(a_key), a_sa, 0u, 1u,
+                            (const uint64_t*)rstart, (const uint64_t*)rcap, (const uint8_t*)pl_.gshift);
+            else if (big_tiles)
                 CAPS_LAUNCH((group_scatter_kernel<idx_t, BITS>), (uint32_t)((n + GA_E - 1) / GA_E), TILE_NT, be_, (const uint32_t*)pl_.P,
                             packed_words(n, BITS), (uint64_t)0, n, (const uint64_t*)pl_.gkey, K1, (const uint16_t*)pl_.glut,
-                            (const uint32_t*)(dflag + 1), SUB, capA, pl_.dcur, a_key, a_sa, 0u, 1u, (const uint64_t*)rstart, (const uint64_t*)rcap);
+                            (const uint32_t*)(dflag + 1), SUB, capA, pl_.dcur, a_key, a_sa, 0u, 1u, (const uint64_t*)rstart, (const uint64_t*)rcap,
+                            (const uint8_t*)nullptr);
             else
                 CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, SRC_TEXT, MAP_SPLIT>), n_tilesA, TILE_NT, be_, whole.desc(), (const uint32_t*)pl_.P,
                             packed_words(n, BITS), (uint64_t)0, (const uint64_t*)nullptr, (const idx_t*)nullptr, RunSrc<idx_t>(),
@@ -1040,10 +1093,12 @@ private:
         o2.sub = SUB;
         o2.seg_ends = true;
         if (quantile) { o2.knots = pl_.knots; o2.knots_per_parent = KPG; }
+        if (k32) { o2.k32 = true; o2.range_mode = 2; o2.gshift = pl_.gshift; }
         o2.in_key = a_key;
         o2.in_sa = a_sa;
         set_final(o2, dSA, dLCP);
         SortResult<idx_t> r2 = seg_sort<BITS>(groups, n_tiles2, max_part_, pl_.A, pl_.B, n, o2, true);
+        if (r2.failed) return run_direct<BITS>(dSA, dLCP, PG, K1, e1, false);      // a slot overflowed under 32-bit keys: again with 64
         passes2_ = r2.passes;
         e6_ = be_.record();
         finalize<idx_t, BITS>(be_, pl_.P, n, r2, dSA, dLCP);
@@ -1126,6 +1181,7 @@ private:
             st->path_fallback = path_fallback_;
             st->direct_groups = direct_groups_;
             st->direct_quantile = direct_quantile_;
+            st->direct_key_bits = path_direct_ && direct_k32_ ? 32u : 64u;
             st->direct_max_group = direct_max_group_;
             st->level_a_ms = direct_groups_ ? be_.elapsed_ms(la0_, la1_) : 0.0;
             st->slot_splits = slot_stats_[0];

@@ -525,7 +525,7 @@ private:
             CAPS_LAUNCH((group_scatter_kernel<idx_t, BITS>), my_tiles_, TILE_NT, be_, (const uint32_t*)P_, packed_words(n_, BITS), (uint64_t)0,
                         n_, (const uint64_t*)gkey_, K1_, (const uint16_t*)glut_, (const uint32_t*)(dflag + 1), SUB_, capA_, dcur_,
                         static_cast<uint64_t*>(d_send_keys), static_cast<idx_t*>(d_send_sa), (uint32_t)rank_, (uint32_t)world_,
-                        (const uint64_t*)nullptr, (const uint64_t*)nullptr);
+                        (const uint64_t*)nullptr, (const uint64_t*)nullptr, (const uint8_t*)nullptr);
         a1_ = be_.record();
     }
 
@@ -653,6 +653,7 @@ private:
         k.fstart = get<uint64_t>((size_t)G + 1);
         k.fcount = get<uint64_t>((size_t)EQ_FINE * k.nb_cap);
         k.gfirst = get<uint32_t>(k.nb_cap);
+        k.kshift = get<uint8_t>(k.nb_cap);
         return k;
     }
 };

@@ -196,6 +196,26 @@ HD uint64_t pair_lcp(const uint32_t* __restrict__ P, uint64_t n, uint64_t ka, ui
     return deep_lcp<BITS, RUNS>(P, n, a, b, TextTraits<BITS>::KCH);
 }
 
+// ---- 32-bit keys (direct path on 2-bit texts, pipeline.h) ---------------------------------------------------------
+// All keys of a group share their top `cs` bits (the common bit prefix of the group's end keys, at most 32), so the next 32
+// bits order the group's suffixes as far as they go and travel instead of the 64: a third fewer bytes per element through
+// level A, level B and the tile sort.  PREFIX-preserving (a bit field, not a difference), so the LCP of two suffixes with
+// different key32 is still read off the keys: (cs + clz32(ka ^ kb)) / BITS chars; equal key32 = the first (cs + 32) / BITS
+// chars agree, the text decides the rest.
+HD uint32_t key32_of(uint64_t key, uint32_t cs) { return (uint32_t)((key << cs) >> 32); }        // cs <= 32
+
+template <int BITS, bool RUNS = false>
+HD uint64_t pair_lcp32(const uint32_t* __restrict__ P, uint64_t n, uint32_t ka, uint64_t a, uint32_t kb, uint64_t b, uint32_t cs)
+{
+    const uint32_t x = ka ^ kb;
+    if (x) {
+        const uint64_t maxlen = n - (a > b ? a : b);
+        const uint64_t l = (cs + (uint32_t)__builtin_clz(x)) / BITS;
+        return l < maxlen ? l : maxlen;
+    }
+    return deep_lcp<BITS, RUNS>(P, n, a, b, (cs + 32u) / BITS);
+}
+
 // Order of two distinct suffixes whose KEYS are equal: continue in 64-bit windows of the
 // packed text (the rare path on low-LCP texts, the common one on repeats).  Inlined: a call
 // inside the merge kernels would force the registers that hold the prefetched next tile to
@@ -219,13 +239,15 @@ HD bool suffix_less_tie(const uint32_t* __restrict__ P, uint64_t n, uint64_t a, 
 #define CAPS_TIE_WINDOWS 64
 #endif
 constexpr uint32_t TIE_WINDOWS = CAPS_TIE_WINDOWS;
+// from: chars the two suffixes are known to share (the key's KCH; fewer under 32-bit keys, see key32_of).
 template <int BITS>
-HD uint32_t suffix_less_tie_bounded(const uint32_t* __restrict__ P, uint64_t n, uint64_t a, uint64_t b)
+HD uint32_t suffix_less_tie_bounded(const uint32_t* __restrict__ P, uint64_t n, uint64_t a, uint64_t b,
+                                    uint32_t from = TextTraits<BITS>::KCH)
 {
     constexpr uint32_t KCH = TextTraits<BITS>::KCH;
     if (a >= n || b >= n) return a > b ? 1u : 0u;
     const uint64_t maxlen = n - (a > b ? a : b);
-    uint64_t l = KCH;
+    uint64_t l = from;
     for (uint32_t k = 0; k < TIE_WINDOWS && l < maxlen; ++k, l += KCH) {
         const uint64_t wa = window64<BITS>(P, a + l), wb = window64<BITS>(P, b + l);
         if (wa != wb) return wa < wb ? 1u : 0u;

@@ -75,6 +75,8 @@ typedef struct caps_sa_stats {
     uint32_t direct_quantile;      /* 1: level B's buckets were sample quantiles (skewed keys / frequent keys), 0: linear maps */
     uint64_t direct_max_group;     /* largest stream of a group (elements) */
     double level_a_ms;             /* direct path: the text -> groups scatter (also counted in bucket_scatter_ms) */
+    uint32_t direct_key_bits;      /* key bits that travelled with every suffix through the direct path's passes: 64, or 32 */
+    uint32_t reserved_;
 } caps_sa_stats;
 
 #define CAPS_SA_FB_NONE 0

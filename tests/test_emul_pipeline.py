@@ -353,3 +353,22 @@ def test_forced_substreams_on_a_nine_tile_text(oracle, monkeypatch):
             monkeypatch.setenv("CAPS_SA_DIRECT_SUB", sub)
             SA, LCP, st = emul().build(T, p=50)
             assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), (mode, sub, st)
+
+
+def test_32_bit_keys_opt_in(oracle, monkeypatch):
+    """CAPS_SA_KEYS=32: the direct path's elements carry key32_of(key, group shift) (text.h) through level A, level B and the
+    tile sort; order and LCPs stay exact (prefix-preserving keys, ties settled by the text), slot overflow falls back to 64."""
+    rs = np.random.RandomState(2)
+    monkeypatch.setenv("CAPS_SA_DIRECT_MODE", "linear")
+    planted = rs.choice(DNA, size=500_000)
+    for _ in range(40):                                    # repeats of 18-40 bases: ties at 32-bit, not at 64-bit keys
+        a, b, ln = rs.randint(0, 499_000), rs.randint(0, 499_000), rs.randint(18, 40)
+        planted[b:b + ln] = planted[a:a + ln]
+    for T, p, bits in [(rs.choice(DNA, size=1_500_000), 20, 32), (rs.choice(DNA, size=400_000), 50, 32),
+                       (rs.choice(DNA, size=600_001), 0, 64), (planted, 30, 32)]:
+        SAo, LCPo = oracle.build_sa_lcp(T, p=64, idx_bits=bits)
+        for keys, expect in (("32", 32), ("64", 64)):
+            monkeypatch.setenv("CAPS_SA_KEYS", keys)
+            SA, LCP, st = emul().build(T, p=p, idx_bits=bits)
+            assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), (T.size, keys)
+            assert st["path_direct"] == 1 and st["direct_key_bits"] == expect, st

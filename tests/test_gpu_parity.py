@@ -489,3 +489,46 @@ def test_one_process_several_ranks_on_this_gpu(L, oracle, devices, n, p, bits):
     assert np.array_equal(SA, SA1) and np.array_equal(LCP, LCP1)
     assert st["path_direct"] == 1 and st["path_fallback"] == 0
     L.release_cache()
+
+
+def test_genome_like_256mi_with_n_blocks_device(L):
+    """the genome-like workload at BASELINE config 1's size (tools/genome_like.py, seeded: order-5 Markov
+    chain with skewed transitions + planted mutated repeats) with N-block stand-ins on top -- the direct path in quantile
+    mode (frequent keys, fat group regions, run-table comparators).  Exact device verifier."""
+    import os
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from bench import make_text
+    T = make_text(torch, 268_435_456, 42, torch.device("cuda", 0), "genome+n")
+    n = T.numel()
+    SA = torch.empty(n, dtype=torch.int32, device="cuda")
+    LCP = torch.empty(n, dtype=torch.int32, device="cuda")
+    st = L.build_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr(), p=8000)
+    assert L.verify_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr()) == 0
+    brief = {k: st[k] for k in ("path_direct", "path_fallback", "direct_quantile", "long_runs", "direct_groups", "direct_max_group")}
+    assert st["path_direct"] == 1 and st["direct_quantile"] == 1 and st["long_runs"] == 1, brief
+    assert int(LCP.max().item()) >= 1_999_000          # the 2e6-long single-letter block
+
+
+def test_32_bit_keys_opt_in_device(L, monkeypatch):
+    """CAPS_SA_KEYS=32 at BASELINE config 1's size and on 60 M bases with 64-bit indices: exact device verifier, and the same
+    arrays as the default (64-bit keys) build."""
+    import torch
+    for n, p, bits in [(268_435_457, 8000, 32), (60_000_001, 200, 64)]:
+        g = torch.Generator(device="cuda")
+        g.manual_seed(n % 1000)
+        lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda")
+        T = lut[torch.randint(0, 4, (n,), device="cuda", generator=g, dtype=torch.int64)]
+        dt = torch.int32 if bits == 32 else torch.int64
+        out = {}
+        for keys in ("32", "64"):
+            monkeypatch.setenv("CAPS_SA_KEYS", keys)
+            SA = torch.empty(n, dtype=dt, device="cuda")
+            LCP = torch.empty(n, dtype=dt, device="cuda")
+            st = L.build_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr(), p=p, idx_bits=bits)
+            assert st["path_direct"] == 1 and st["direct_key_bits"] == int(keys), st
+            assert L.verify_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr(), idx_bits=bits) == 0
+            out[keys] = (SA, LCP)
+        assert torch.equal(out["32"][0], out["64"][0]) and torch.equal(out["32"][1], out["64"][1])
