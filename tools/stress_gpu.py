@@ -71,8 +71,10 @@ while time.time() - t0 < budget:
     kind = kinds[rs.randint(len(kinds))]
     big = rs.rand() < 0.25
     n = int(rs.randint(33, int(os.environ.get("STRESS_MAX_N", 3_000_000)) if big else 60_000))
-    if os.environ.get("STRESS_MIN_N"):           # sizes the direct path takes (>= 32 tiles)
+    if os.environ.get("STRESS_MIN_N"):           # sizes the direct path takes (>= 32 tiles), for the kinds the oracle is not quadratic on
         n = int(rs.randint(int(os.environ["STRESS_MIN_N"]), int(os.environ.get("STRESS_MAX_N", 3_000_000))))
+        while kind in ("periodic", "runs"):
+            kind = kinds[rs.randint(len(kinds))]
     if kind == "periodic" or kind == "runs":
         n = min(n, 40_000)                       # quadratic in the LCP, for the oracle too
     if kind == "stretches":
