@@ -64,7 +64,7 @@ def text(kind, n):
 kinds = ["uniform", "skew", "two", "bytes", "periodic", "planted", "runs", "stretches", "stretches"]
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from sa_check import sa_lcp                 # independent prefix-doubling construction: not quadratic on stretches
-t0 = time.time(); done = 0; oom = 0
+t0 = time.time(); done = 0; oom = 0; last_note = t0
 stats = {"slot_splits": 0, "slot_splits_redone": 0, "long_runs": 0, "path_direct": 0, "direct_quantile": 0}
 fallbacks = {}
 while time.time() - t0 < budget:
@@ -111,4 +111,7 @@ while time.time() - t0 < budget:
     for k in stats: stats[k] += st[k]
     if st["path_fallback"]: fallbacks[st["path_fallback"]] = fallbacks.get(st["path_fallback"], 0) + 1
     done += 1
+    if time.time() - last_note > 30:             # a sign of life (a silent GPU job is taken to be hung)
+        last_note = time.time()
+        print(json.dumps({"progress": done, "seconds": round(time.time() - t0, 1), "path_direct": stats["path_direct"]}), flush=True)
 print(json.dumps({"builds": done, "out_of_memory": oom, "seconds": round(time.time() - t0, 1), **stats, "fallbacks_by_code": fallbacks}))
