@@ -407,7 +407,7 @@ inline DevText upload_text(Backend& be, DevAllocs& da, const char* T, uint64_t n
     DevText t;
     t.raw = da.get<uint8_t>(n ? n : 1);
     t.P = da.get<uint32_t>(text_alloc_words(n ? n : 1));
-    uint32_t* present = da.get<uint32_t>(8);
+    uint32_t* present = da.get<uint32_t>(16);
     uint8_t* lut = da.get<uint8_t>(256);
     be.h2d(t.raw, T, n);
     t.bits = prepare_text(be, t.raw, n, t.P, present, lut);

@@ -156,9 +156,11 @@ GLOBAL_FN LAUNCH_BOUNDS(256) alphabet_kernel(KCTX const uint8_t* __restrict__ T,
 // Pack raw bytes into BITS-wide codes, big-endian inside each 32-bit word (text.h).
 // lut[256] maps byte -> code (staged in LDS).  One thread per 16 input bytes (one 16-byte
 // load -> one word at BITS = 2, four words at BITS = 8); words past the text are 0.
+// bad != null: the LUT comes from a SAMPLE of the text (prepare_text); a byte it does not know (code 0xFF) raises bad[0] and
+// the caller redoes the preparation with the alphabet of the whole text.
 template <int BITS>
 GLOBAL_FN LAUNCH_BOUNDS(256) pack_kernel(KCTX const uint8_t* __restrict__ T, uint64_t n, const uint8_t* __restrict__ lut,
-                                         uint32_t* __restrict__ P, uint64_t n_words)
+                                         uint32_t* __restrict__ P, uint64_t n_words, uint32_t* __restrict__ bad)
 {
     constexpr uint32_t CPW = TextTraits<BITS>::CPW;
     constexpr uint32_t WPT = 16 / CPW;                    // output words per 16 input bytes
@@ -183,6 +185,7 @@ GLOBAL_FN LAUNCH_BOUNDS(256) pack_kernel(KCTX const uint8_t* __restrict__ T, uin
                 UNROLL
                 for (int k = 0; k < 16; ++k) c[k] = base + k < n ? T[base + k] : 0;
             }
+            uint32_t unknown = 0;
             UNROLL
             for (uint32_t wo = 0; wo < WPT; ++wo) {
                 uint32_t v = 0;
@@ -190,10 +193,12 @@ GLOBAL_FN LAUNCH_BOUNDS(256) pack_kernel(KCTX const uint8_t* __restrict__ T, uin
                 for (uint32_t k = 0; k < CPW; ++k) {
                     const uint64_t i = base + wo * CPW + k;
                     const uint32_t code = i < n ? slut[c[wo * CPW + k]] : 0u;
-                    v |= code << (32 - BITS * (k + 1));
+                    unknown |= code;
+                    v |= (code & ((1u << BITS) - 1u)) << (32 - BITS * (k + 1));
                 }
                 if (u * WPT + wo < n_words) P[u * WPT + wo] = v;
             }
+            if (BITS == 2 && bad && (unknown & 0x80u)) bad[0] = 1;       // benign race: every writer stores 1
         }
     }
 }

@@ -235,7 +235,7 @@ Plan<idx_t> make_plan(uint64_t n, uint64_t p_arg, char* base)
     pl.bk.gfirst = ar.take<uint32_t>(pl.bk.nb_cap);
     pl.bk.kshift = ar.take<uint8_t>(pl.bk.nb_cap);
     pl.pass_elems = ar.take<uint64_t>(kMaxPasses);
-    pl.present = ar.take<uint32_t>(8);
+    pl.present = ar.take<uint32_t>(16);
     pl.lut = ar.take<uint8_t>(256);
     pl.bytes = ar.off + 256;
     return pl;
@@ -253,7 +253,7 @@ inline int build_lut(const uint32_t present[8], uint8_t lut[256])
     int sigma = 0;
     for (int c = 0; c < 256; ++c) sigma += (present[c >> 5] >> (c & 31)) & 1;
     if (sigma <= 4) {
-        for (int c = 0; c < 256; ++c) lut[c] = 0;
+        for (int c = 0; c < 256; ++c) lut[c] = 0xFF;          // not in the alphabet (pack_kernel's validation; never read otherwise)
         int rank = 0;
         for (int v = -128; v < 128; ++v) {          // signed-char order
             const int c = v & 0xFF;
@@ -304,23 +304,46 @@ inline void build_run_table(Backend& be, uint32_t* P, uint64_t n, int bits)
 // preparation on device).  present_dev: 8 x u32, lut_dev: 256 bytes.  Returns BITS.
 inline int prepare_text(Backend& be, const uint8_t* dT, uint64_t n, uint32_t* P, uint32_t* present_dev, uint8_t* lut_dev)
 {
-    be.memset(present_dev, 0, 8 * sizeof(uint32_t));
-    {
-        const uint64_t want = (n + 16 * 256 - 1) / (16 * 256);
+    // present_dev: 16 x u32 -- [0..8) the presence bits, [8] pack_kernel's "unknown byte" flag
+    auto alphabet = [&](uint64_t len, uint32_t present[8]) {
+        be.memset(present_dev, 0, 16 * sizeof(uint32_t));
+        const uint64_t want = (len + 16 * 256 - 1) / (16 * 256);
         const uint32_t grid = (uint32_t)(want < 4096 ? (want ? want : 1) : 4096);
-        CAPS_LAUNCH(alphabet_kernel, grid, 256, be, dT, n, present_dev);
-    }
+        CAPS_LAUNCH(alphabet_kernel, grid, 256, be, dT, len, present_dev);
+        be.d2h(present, present_dev, 8 * sizeof(uint32_t));
+        be.sync();
+    };
+    auto pack = [&](int bits, const uint8_t lut[256], uint32_t* bad) {
+        be.h2d(lut_dev, lut, 256);
+        const uint64_t n_words = packed_words(n, bits);
+        const uint64_t want = (n_words / (bits == 2 ? 1 : 4) + 255) / 256 + 1;
+        const uint32_t grid = (uint32_t)(want < 65536 ? want : 65536);
+        if (bits == 2) CAPS_LAUNCH(pack_kernel<2>, grid, 256, be, dT, n, (const uint8_t*)lut_dev, P, n_words, bad);
+        else CAPS_LAUNCH(pack_kernel<8>, grid, 256, be, dT, n, (const uint8_t*)lut_dev, P, n_words, bad);
+    };
     uint32_t present[8];
-    be.d2h(present, present_dev, sizeof present);
-    be.sync();
     uint8_t lut[256];
+    // Large texts: the alphabet of the first MiB is tried first -- a scan of all of T costs as much as packing it (0.68 of the
+    // 1.8 ms this function takes at 3e9 bytes).  The pack kernel checks every byte against it; a byte the sample did not show
+    // (the codes are ranks in the WHOLE text's alphabet) sends us to the exact path below.
+#ifdef CAPS_EMUL
+    constexpr uint64_t SAMPLE = 1u << 12;             // small, so that the CPU logic tests take this route (and its redo)
+#else
+    constexpr uint64_t SAMPLE = 1u << 20;
+#endif
+    if (n >= 16 * SAMPLE && !std::getenv("CAPS_SA_FULL_ALPHABET")) {
+        alphabet(SAMPLE, present);
+        if (build_lut(present, lut) == 2) {
+            pack(2, lut, present_dev + 8);
+            uint32_t bad = 0;
+            be.d2h(&bad, present_dev + 8, sizeof bad);
+            build_run_table(be, P, n, 2);             // ends with a sync: `bad` has arrived, lut[] may go
+            if (!bad) return 2;
+        }
+    }
+    alphabet(n, present);
     const int bits = build_lut(present, lut);
-    be.h2d(lut_dev, lut, 256);
-    const uint64_t n_words = packed_words(n, bits);
-    const uint64_t want = (n_words / (bits == 2 ? 1 : 4) + 255) / 256 + 1;
-    const uint32_t grid = (uint32_t)(want < 65536 ? want : 65536);
-    if (bits == 2) CAPS_LAUNCH(pack_kernel<2>, grid, 256, be, dT, n, (const uint8_t*)lut_dev, P, n_words);
-    else CAPS_LAUNCH(pack_kernel<8>, grid, 256, be, dT, n, (const uint8_t*)lut_dev, P, n_words);
+    pack(bits, lut, nullptr);
     build_run_table(be, P, n, bits);              // ends with a sync (lut[] lives on this stack frame)
     return bits;
 }

@@ -104,7 +104,7 @@ public:
                 cap_ = std::max<uint64_t>(cap_, own_max + TILE_E);
             }
             P_ = get<uint32_t>(text_alloc_words(n));
-            present_ = get<uint32_t>(8);
+            present_ = get<uint32_t>(16);
             lut_ = get<uint8_t>(256);
             A_ = elems(cap_);
             B_ = elems(cap_);

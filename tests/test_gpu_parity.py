@@ -532,3 +532,17 @@ def test_32_bit_keys_opt_in_device(L, monkeypatch):
             assert L.verify_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr(), idx_bits=bits) == 0
             out[keys] = (SA, LCP)
         assert torch.equal(out["32"][0], out["64"][0]) and torch.equal(out["32"][1], out["64"][1])
+
+
+def test_alphabet_guessed_from_a_sample_is_validated(L, oracle):
+    """prepare_text packs with the alphabet of the text's first MiB and validates every byte while packing: a symbol that
+    only shows up later (here the 5th, which also changes the code width) sends the preparation to the exact path."""
+    rs = np.random.RandomState(77)
+    T = rs.choice(DNA, size=20_000_000)
+    T[19_000_000] = ord("N")
+    st = _same(L, oracle, T, 300)
+    assert st["bits_per_char"] == 8
+    T = rs.choice(DNA, size=20_000_000)
+    T[:3_000_000] = rs.choice(np.frombuffer(b"AC", dtype=np.uint8), size=3_000_000)       # the sample sees two of the four symbols
+    st = _same(L, oracle, T, 300)
+    assert st["bits_per_char"] == 2
