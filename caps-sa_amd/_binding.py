@@ -89,6 +89,7 @@ class ShardInfo(ctypes.Structure):
         ("ms_merge_passes", ctypes.c_double),
         ("level_a_elems", ctypes.c_uint64),
         ("slot_splits", ctypes.c_uint32), ("slot_splits_redone", ctypes.c_uint32),
+        ("key_bytes", ctypes.c_uint32), ("reserved_", ctypes.c_uint32),
     ]
 
     def as_dict(self) -> dict:
@@ -97,7 +98,7 @@ class ShardInfo(ctypes.Structure):
 
 SHARD_EXPORTS = ["shard_create", "shard_destroy", "shard_info", "shard_phase1", "shard_pivots", "shard_collate",
                  "shard_phase2", "shard_last_sa", "shard_fix_first_lcp", "shard_scatter", "shard_plan", "shard_sort",
-                 "shard_phase1_arrays"]
+                 "shard_phase1_arrays", "shard_set_key_bits"]
 
 EXPORTS = ["device_count", "last_error", "version", "workspace_bytes", "release_cache", "host_alloc", "host_free"] + SHARD_EXPORTS + [
     f"{name}_{sfx}"
@@ -177,6 +178,8 @@ class CapsLib:
         f("shard_plan").argtypes = [_vp, _vp, _vp, _vp]
         f("shard_sort").restype = _ci
         f("shard_sort").argtypes = [_vp, _vp, _vp, _vp, _vp]
+        f("shard_set_key_bits").restype = _ci
+        f("shard_set_key_bits").argtypes = [_vp, _ci]
         f("shard_phase1_arrays").restype = _ci
         f("shard_phase1_arrays").argtypes = [_vp, _vp, _vp, ctypes.POINTER(_u64), ctypes.POINTER(_u64)]
         f("shard_last_sa").restype = _ci
@@ -396,8 +399,15 @@ class Shard:
             self.lib._check(code)
         return code, sc, rc
 
-    def sort_owned(self, d_recv_keys: int, d_recv_sa: int, dSA: int, dLCP: int):
-        self.lib._check(self.lib._f("shard_sort")(self.h, d_recv_keys or None, d_recv_sa or None, dSA or None, dLCP or None))
+    def sort_owned(self, d_recv_keys: int, d_recv_sa: int, dSA: int, dLCP: int) -> int:
+        """-> 0, or CAPS_SA_FB_KEY32 (6): a slot overflowed under 32-bit keys; all ranks set_key_bits(64) and start over."""
+        code = self.lib._f("shard_sort")(self.h, d_recv_keys or None, d_recv_sa or None, dSA or None, dLCP or None)
+        if code < 0:
+            self.lib._check(code)
+        return code
+
+    def set_key_bits(self, bits: int):
+        self.lib._check(self.lib._f("shard_set_key_bits")(self.h, bits))
 
     def phase1_arrays(self, d_keys_out: int = 0, d_sa_out: int = 0):
         """Copies the rank's sorted subarrays (after phase1()) into the given device buffers; -> (count, subarray length)."""

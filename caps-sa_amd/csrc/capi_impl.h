@@ -198,6 +198,7 @@ template <typename idx_t> struct MultiRank {
     idx_t *send_s = nullptr, *recv_s = nullptr, *dSA = nullptr, *dLCP = nullptr;
     caps_sa_shard_info info;
     std::vector<uint64_t> sc, rc;
+    int sort_code = 0;
     template <typename T> T* get(size_t count)
     {
         T* q = static_cast<T*>(be->alloc((count ? count : 1) * sizeof(T)));
@@ -283,6 +284,8 @@ int build_multi(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context,
             q->report = q->template get<uint64_t>(W);
         }
         const auto t1 = clock::now();
+        auto t2 = t1;
+        for (int attempt = 0;; ++attempt) {                       // second attempt: 64-bit keys after a slot overflow under 32
         // ---- level A on every device; the reports; the plan (identical on all ranks)
         for_each_rank(ranks, [&](MultiRank<idx_t>& q) { q.sh->scatter(q.send_k, q.send_s, q.report); });
         std::vector<uint64_t> all(W * world);
@@ -299,6 +302,7 @@ int build_multi(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context,
             if (code != CAPS_SA_FB_NONE) { fallback = code; return CAPS_SA_OK; }
         }
         // ---- the exchange: block d of rank r's send buffers -> slot r of rank d's receive buffers
+        for (auto& q : ranks) q->sh->info(&q->info);              // key_bytes of this attempt
         for (int r = 0; r < world; ++r) {
             MultiRank<idx_t>& src = *ranks[r];
             if (int e = set_device(src.dev)) return e;
@@ -309,15 +313,23 @@ int build_multi(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context,
                 if (cnt != dst.rc[r]) throw std::runtime_error("send / receive counts disagree");
                 uint64_t ro = 0;
                 for (int q = 0; q < r; ++q) ro += dst.rc[q];
-                src.be->peer_copy(dst.recv_k + ro, dst.dev, src.send_k + so, src.dev, cnt * sizeof(uint64_t));
+                const size_t kb = src.info.key_bytes;              // 4 under 32-bit keys: the key arrays are u32 then
+                src.be->peer_copy(reinterpret_cast<char*>(dst.recv_k) + ro * kb, dst.dev, reinterpret_cast<const char*>(src.send_k) + so * kb,
+                                  src.dev, cnt * kb);
                 src.be->peer_copy(dst.recv_s + ro, dst.dev, src.send_s + so, src.dev, cnt * sizeof(idx_t));
                 so += cnt;
             }
         }
         for (auto& q : ranks) { if (int e = set_device(q->dev)) return e; q->be->sync(); }
-        const auto t2 = clock::now();
+        t2 = clock::now();
         // ---- level B + tile sort of the owned groups; boundary LCPs between the slices
-        for_each_rank(ranks, [&](MultiRank<idx_t>& q) { q.sh->sort_owned(q.recv_k, q.recv_s, q.dSA, q.dLCP); });
+        for_each_rank(ranks, [&](MultiRank<idx_t>& q) { q.sort_code = q.sh->sort_owned(q.recv_k, q.recv_s, q.dSA, q.dLCP); });
+        int worst = 0;
+        for (auto& q : ranks) worst = q->sort_code > worst ? q->sort_code : worst;
+        if (worst == CAPS_SA_FB_NONE) break;
+        if (attempt > 0) throw std::runtime_error("the sharded direct path failed with 64-bit keys");
+        for (auto& q : ranks) q->sh->set_key_bits(64);            // a slot overflowed under 32-bit keys on some rank: all again with 64
+        }
         uint64_t prev = ~0ull;
         for (auto& q : ranks) {
             if (int e = set_device(q->dev)) return e;
@@ -790,7 +802,13 @@ int CAPS_API(shard_plan)(caps_sa_shard* s, const uint64_t* all_reports, uint64_t
 int CAPS_API(shard_sort)(caps_sa_shard* s, const void* k, const void* a, void* dSA, void* dLCP)
 {
     if (!s) return caps::fail(CAPS_SA_EINVAL, "null shard");
-    return caps::guarded([&]() -> int { s->impl->sort_owned(k, a, dSA, dLCP); return CAPS_SA_OK; });
+    return caps::guarded([&]() -> int { return s->impl->sort_owned(k, a, dSA, dLCP); });
+}
+int CAPS_API(shard_set_key_bits)(caps_sa_shard* s, int bits)
+{
+    if (!s || (bits != 32 && bits != 64)) return caps::fail(CAPS_SA_EINVAL, "bad argument");
+    s->impl->set_key_bits(bits);
+    return CAPS_SA_OK;
 }
 int CAPS_API(shard_phase1_arrays)(caps_sa_shard* s, void* d_keys_out, void* d_sa_out, uint64_t* count, uint64_t* subarray_len)
 {

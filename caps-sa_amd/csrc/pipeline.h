@@ -1016,7 +1016,7 @@ private:
         // 64-bit keys.  Measured at C3: level A 13.4 -> 11.1 ms, but level B 16.6 -> 18.1 and the tile sort 17.2 ->
         // 20.3 ms -- the group's shift + 32 bits are ~20 bases, about ten elements of a tile tie and every tile then waits for
         // text reads -- 52.3 against 49.8 ms per build: NOT the default.  (Its place is the exchange of a sharded build, where
-        // a third fewer bytes cross xGMI; not wired there yet.)
+        // a third fewer bytes cross xGMI: shard.h scatter() takes them whenever world > 1.)
         const char* keys_env = std::getenv("CAPS_SA_KEYS");
         const bool k32 = allow_k32 && !quantile && BITS == 2 && keys_env && std::string(keys_env) == "32";
         direct_k32_ = k32 ? 1u : 0u;

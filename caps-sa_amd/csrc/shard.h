@@ -55,7 +55,8 @@ struct ShardBase {
     // direct path (see Shard)
     virtual void scatter(void* d_send_keys, void* d_send_sa, void* d_report) = 0;
     virtual int plan(const uint64_t* all_reports, uint64_t* send_counts, uint64_t* recv_counts) = 0;
-    virtual void sort_owned(const void* d_recv_keys, const void* d_recv_sa, void* dSA, void* dLCP) = 0;
+    virtual int sort_owned(const void* d_recv_keys, const void* d_recv_sa, void* dSA, void* dLCP) = 0;
+    virtual void set_key_bits(int bits) = 0;
     virtual void phase1_arrays(void* d_keys_out, void* d_sa_out, uint64_t* count, uint64_t* subarray_len) = 0;
 };
 
@@ -116,6 +117,7 @@ public:
             gkey_ = get<uint64_t>(p_);
             glut_ = get<uint16_t>(SPLIT_LUT_CELLS + 2);
             dcur_ = get<idx_t>(gseg);
+            gshift_ = get<uint8_t>(gseg);
             dstat_ = get<uint64_t>(4);
             SA_ = elems(m_total_);
             SB_ = elems(m_total_);
@@ -150,6 +152,7 @@ public:
         o->n_streams = n_streams_; o->stream_cap = capA_;
         o->send_capacity = std::max<uint64_t>(local_n_, direct_fb_ == CAPS_SA_FB_NONE ? (uint64_t)n_streams_ * capA_ : 0);
         o->ms_scatter = ms_scatter_; o->ms_sort = ms_sort_;
+        o->key_bytes = key_bits_ / 8;
         o->ms_level_a = ms_level_a_; o->ms_level_b = ms_level_b_ + ms_count_; o->ms_tile_sort = ms_tile_sort_; o->ms_merge_passes = ms_merge_;
         o->level_a_elems = my_elems_;
         o->slot_splits = slot_stats_[0]; o->slot_splits_redone = slot_stats_[1];
@@ -361,8 +364,17 @@ public:
         if (be_.long_runs) {
             const uint32_t code = CAPS_SA_FB_LONG_RUNS;        // every rank sees the same text: all report the same
             be_.h2d(dflag, &code, sizeof code);
-        } else if (bits_ == 2) scatter_bits<2>(d_send_keys, d_send_sa, dflag);
-        else scatter_bits<8>(d_send_keys, d_send_sa, dflag);
+        } else {
+            // 32-bit keys (text.h key32_of) whenever the elements are going to cross xGMI: a third fewer bytes on the wire
+            // (8 + w -> 4 + w per suffix).  On one GPU they cost more than they save, so a world of one keeps 64
+            // bits unless CAPS_SA_KEYS=32 asks (tests); CAPS_SA_KEYS=64 and set_key_bits(64) (the retry after a slot overflow
+            // in level B) force 64.
+            const char* ke = std::getenv("CAPS_SA_KEYS");
+            const bool want32 = ke ? std::string(ke) == "32" : world_ > 1;
+            key_bits_ = want32 && !force64_ && bits_ == 2 ? 32u : 64u;
+            if (bits_ == 2) scatter_bits<2>(d_send_keys, d_send_sa, dflag);
+            else scatter_bits<8>(d_send_keys, d_send_sa, dflag);
+        }
         CAPS_LAUNCH((stream_report_kernel<idx_t>), (n_streams_ + 256) / 256, 256, be_, (const idx_t*)dcur_, n_streams_, capA_,
                     (const uint32_t*)dflag, report);
         BackendEvent e1 = be_.record();
@@ -429,14 +441,18 @@ public:
     }
 
     // d_recv_*: the blocks received from ranks 0 .. world-1, in rank order (world 1: the send buffers themselves)
-    void sort_owned(const void* d_recv_keys, const void* d_recv_sa, void* dSA, void* dLCP) override
+    // Returns 0, or CAPS_SA_FB_KEY32 when a slot of level B overflowed under 32-bit keys (nothing sorted): the caller makes
+    // ALL ranks agree (max over ranks), calls set_key_bits(64) and repeats scatter / exchange / sort.
+    int sort_owned(const void* d_recv_keys, const void* d_recv_sa, void* dSA, void* dLCP) override
     {
         if (!direct_planned_) throw std::invalid_argument("shard_plan has not accepted the direct path");
         BackendEvent e0 = be_.record();
+        int code = CAPS_SA_FB_NONE;
         if (recv_total_) {
             ::caps::prepare_segments(be_, seg2_, n_tiles2_ + 1, nullptr, nullptr, true);
-            if (bits_ == 2) sort_owned_bits<2>(d_recv_keys, d_recv_sa, dSA, dLCP);
-            else sort_owned_bits<8>(d_recv_keys, d_recv_sa, dSA, dLCP);
+            const bool ok = bits_ == 2 ? sort_owned_bits<2>(d_recv_keys, d_recv_sa, dSA, dLCP)
+                                       : sort_owned_bits<8>(d_recv_keys, d_recv_sa, dSA, dLCP);
+            if (!ok) code = CAPS_SA_FB_KEY32;
             dSA_ = static_cast<idx_t*>(dSA);
         }
         BackendEvent e1 = be_.record();
@@ -449,7 +465,10 @@ public:
         }
         clocks_.clear();
         be_.release_events();
+        return code;
     }
+
+    void set_key_bits(int bits) override { force64_ = bits == 64; }
 
     uint64_t last_sa() override
     {
@@ -502,6 +521,9 @@ private:
     bool direct_planned_ = false;
     uint32_t PG_ = 0, K1_ = 0, SUB_ = 1, n_streams_ = 0, my_tiles_ = 0;
     uint64_t capA_ = 0, my_elems_ = 0;
+    uint32_t key_bits_ = 64;             // width of the keys the last scatter() wrote (32: text.h key32_of)
+    bool force64_ = false;               // set_key_bits(64): after a slot overflow under 32-bit keys
+    uint8_t* gshift_ = nullptr;
     uint64_t *gkey_ = nullptr, *dstat_ = nullptr;
     uint16_t* glut_ = nullptr;
     idx_t* dcur_ = nullptr;
@@ -520,8 +542,14 @@ private:
         CAPS_LAUNCH(group_keys_kernel, (p_ + 255) / 256, 256, be_, (const uint64_t*)pkey_, p_, PG_, K1_, gkey_, dflag);
         CAPS_LAUNCH(split_lut_kernel, (SPLIT_LUT_CELLS + 256) / 256, 256, be_, (const uint64_t*)gkey_, K1_ - 1, glut_, dflag + 1);
         be_.memset(dcur_, 0, (size_t)n_streams_ * sizeof(idx_t));
+        if (key_bits_ == 32) CAPS_LAUNCH(group_shift_kernel, (K1_ + 255) / 256, 256, be_, (const uint64_t*)gkey_, K1_, gshift_);
         a0_ = be_.record();
-        if (my_tiles_)
+        if (my_tiles_ && key_bits_ == 32)
+            CAPS_LAUNCH((group_scatter_kernel<idx_t, BITS, uint32_t>), my_tiles_, TILE_NT, be_, (const uint32_t*)P_, packed_words(n_, BITS),
+                        (uint64_t)0, n_, (const uint64_t*)gkey_, K1_, (const uint16_t*)glut_, (const uint32_t*)(dflag + 1), SUB_, capA_, dcur_,
+                        static_cast<uint32_t*>(d_send_keys), static_cast<idx_t*>(d_send_sa), (uint32_t)rank_, (uint32_t)world_,
+                        (const uint64_t*)nullptr, (const uint64_t*)nullptr, (const uint8_t*)gshift_);
+        else if (my_tiles_)
             CAPS_LAUNCH((group_scatter_kernel<idx_t, BITS>), my_tiles_, TILE_NT, be_, (const uint32_t*)P_, packed_words(n_, BITS), (uint64_t)0,
                         n_, (const uint64_t*)gkey_, K1_, (const uint16_t*)glut_, (const uint32_t*)(dflag + 1), SUB_, capA_, dcur_,
                         static_cast<uint64_t*>(d_send_keys), static_cast<idx_t*>(d_send_sa), (uint32_t)rank_, (uint32_t)world_,
@@ -529,7 +557,7 @@ private:
         a1_ = be_.record();
     }
 
-    template <int BITS> void sort_owned_bits(const void* d_recv_keys, const void* d_recv_sa, void* dSA, void* dLCP)
+    template <int BITS> bool sort_owned_bits(const void* d_recv_keys, const void* d_recv_sa, void* dSA, void* dLCP)
     {
         SortOpts o;
         o.need_lcp = true;
@@ -551,6 +579,7 @@ private:
         o.bnd.last_sa = bk_.last_sa;
         o.slot_stats = slot_stats_;
         o.speculate = std::getenv("CAPS_SA_NO_SLOTS") == nullptr;
+        if (key_bits_ == 32) { o.k32 = true; o.range_mode = 2; o.gshift = gshift_; o.speculate = true; }
         KernelClock tile_clock, scatter_clock, count_clock, merge_clock;
         o.tile_clock = &tile_clock;
         o.scatter_clock = &scatter_clock;
@@ -558,7 +587,9 @@ private:
         o.merge_clock = &merge_clock;
         SortResult<idx_t> r = segmented_sort<idx_t, BITS>(be_, P_, n_, tdesc_, seg2_, n_tiles2_, max_len2_, A_, B_, recv_total_, o);
         clocks_ = {tile_clock, scatter_clock, count_clock, merge_clock};
+        if (r.failed) return false;
         finalize<idx_t, BITS>(be_, P_, n_, r, static_cast<idx_t*>(dSA), static_cast<idx_t*>(dLCP));
+        return true;
     }
 
     template <typename T> T* get(size_t count)

@@ -145,7 +145,8 @@ def build_sharded(lib, T: torch.Tensor, p: int = 0, idx_bits: int | None = None,
         P = inf["p"]
         B = bufs if bufs is not None else ShardBuffers(inf, dev, dt)
         # ---- direct path: same pivots on every rank, level A on the rank's tiles, ONE exchange, level B + tile sort
-        if inf["direct_fallback"] == 0:
+        attempt = 0
+        while inf["direct_fallback"] == 0:
             sh.scatter(B.send_k.data_ptr(), B.send_s.data_ptr(), B.report.data_ptr())
             lap("scatter")
             reports = torch.empty(world * B.report.numel(), dtype=torch.int64, device=dev)
@@ -153,32 +154,47 @@ def build_sharded(lib, T: torch.Tensor, p: int = 0, idx_bits: int | None = None,
             reports_h = reports.cpu().numpy().astype(np.uint64).reshape(world, B.report.numel())
             code, sc, rc = sh.plan(reports_h)
             lap("plan")
-            if code == 0:
-                sc = [int(x) for x in sc]
-                rc = [int(x) for x in rc]
-                t0 = time.perf_counter()
-                if world == 1:
-                    recv_k, recv_s = B.send_k, B.send_s               # nothing to exchange: level B reads the streams in place
-                else:
-                    recv_k, recv_s = B.recv_k, B.recv_s
-                    plan = exchange_plan(rc, sc, 8, dev)
-                    all_to_all_v(recv_k[:sum(rc)], B.send_k[:sum(sc)], rc, sc, plan)
-                    all_to_all_v(recv_s[:sum(rc)], B.send_s[:sum(sc)], rc, sc, plan)
-                if dev.type == "cuda":
-                    torch.cuda.synchronize(dev)
-                ms_exchange = 1e3 * (time.perf_counter() - t0)
-                lap("exchange")
-                sh.sort_owned(recv_k.data_ptr(), recv_s.data_ptr(), B.SA.data_ptr(), B.LCP.data_ptr())
-                lap("sort")
-                info = _finish(sh, B.LCP, dev, rank, world)
-                lap("boundary")
-                total = info["recv_total"]
-                info["ms_exchange"] = ms_exchange
-                info["path"] = "direct"
-                info["exchange_elems_sent"] = sum(sc) - sc[rank]
-                if prof is not None:
-                    info["host_profile_ms"] = prof
-                return B.SA[:total], B.LCP[:total], info["slice_off"], info
+            if code != 0:
+                break
+            sc = [int(x) for x in sc]
+            rc = [int(x) for x in rc]
+            kb = sh.info()["key_bytes"]                           # 4: 32-bit keys travel (2-bit texts, world > 1), else 8
+            send_k = B.send_k.view(torch.int32) if kb == 4 else B.send_k
+            recv_k = B.recv_k.view(torch.int32) if kb == 4 else B.recv_k
+            t0 = time.perf_counter()
+            if world == 1:
+                recv_k, recv_s = send_k, B.send_s                 # nothing to exchange: level B reads the streams in place
+            else:
+                recv_s = B.recv_s
+                plan = exchange_plan(rc, sc, max(kb, idx_bits // 8), dev)
+                all_to_all_v(recv_k[:sum(rc)], send_k[:sum(sc)], rc, sc, plan)
+                all_to_all_v(recv_s[:sum(rc)], B.send_s[:sum(sc)], rc, sc, plan)
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+            ms_exchange = 1e3 * (time.perf_counter() - t0)
+            lap("exchange")
+            mine = sh.sort_owned(recv_k.data_ptr(), recv_s.data_ptr(), B.SA.data_ptr(), B.LCP.data_ptr())
+            worst = torch.tensor([mine], dtype=torch.int64, device=dev)
+            if world > 1:
+                dist.all_reduce(worst, op=dist.ReduceOp.MAX)      # a slot overflow on ANY rank sends every rank round again
+            lap("sort")
+            if int(worst.item()) != 0:
+                if attempt:
+                    raise RuntimeError("the sharded direct path failed with 64-bit keys")
+                attempt += 1
+                sh.set_key_bits(64)
+                continue
+            info = _finish(sh, B.LCP, dev, rank, world)
+            lap("boundary")
+            total = info["recv_total"]
+            info["ms_exchange"] = ms_exchange
+            info["path"] = "direct"
+            info["key_retry"] = attempt
+            info["exchange_elems_sent"] = sum(sc) - sc[rank]
+            if prof is not None:
+                info["host_profile_ms"] = prof
+            return B.SA[:total], B.LCP[:total], info["slice_off"], info
+        if inf["direct_fallback"] == 0:
             inf = dict(inf, direct_fallback=code)
         # ---- samplesort path: phase 1 + samples
         sk, ss = B.sk, B.ss
@@ -309,7 +325,7 @@ def bench_main(args, rank: int, local_rank: int, world: int):
             if roof:
                 roof["scope"] = f"rank 0 of {world}: its kernels over its {mine} suffixes"
         ms_x = sum(i["ms_exchange"] for i in infos) / len(infos)
-        sent = info["exchange_elems_sent"] * (8 + w)
+        sent = info["exchange_elems_sent"] * ((info.get("key_bytes", 8) if direct else 8) + w)
         keys = ("ms_scatter", "ms_exchange", "ms_sort") if direct else ("ms_phase1", "ms_pivots", "ms_collate", "ms_exchange", "ms_phase2")
         out = {
             "metric": "suffixes/sec (SA+LCP build)", "value": n / (elapsed / args.steps), "unit": "suffixes/s",
@@ -326,7 +342,8 @@ def bench_main(args, rank: int, local_rank: int, world: int):
                                       "sharded, one RCCL all-to-all over xGMI"},
             "rank0_ms": {k_: info[k_] for k_ in keys},
             "exchange": {"ms": ms_x, "bytes_sent_per_rank": sent, "GBps_per_rank": (sent / 1e9) / (ms_x * 1e-3) if ms_x > 0 and sent else None,
-                         "note": "keys and indices in two all-to-all calls; region gaps (10 %) travel too"},
+                         "key_bytes": info.get("key_bytes", 8) if direct else 8, "key_retries": sum(i.get("key_retry", 0) for i in infos),
+                         "note": "keys and indices in two all-to-all calls; region gaps (10 %) travel too; 32-bit keys on 2-bit texts"},
             "rank0_host_profile_ms": info.get("host_profile_ms"),
             "roofline": roof,
             "verify_errors": errs,

@@ -85,6 +85,7 @@ typedef struct caps_sa_stats {
 #define CAPS_SA_FB_LONG_RUNS 3     /* the text holds a long periodic stretch: keys alone cannot split it */
 #define CAPS_SA_FB_PIVOT_TIES 4    /* two sampled pivots share their key */
 #define CAPS_SA_FB_GROUP_OVERFLOW 5 /* a group outgrew its region (a very frequent key) */
+#define CAPS_SA_FB_KEY32 6         /* sharded build: a bucket slot overflowed under 32-bit keys; repeat with caps_sa_hip_shard_set_key_bits(s, 64) */
 
 int caps_sa_hip_device_count(void);
 const char* caps_sa_hip_last_error(void);
@@ -244,6 +245,9 @@ typedef struct caps_sa_shard_info {
     double ms_level_a, ms_level_b, ms_tile_sort, ms_merge_passes;
     uint64_t level_a_elems;        /* text positions this rank distributed */
     uint32_t slot_splits, slot_splits_redone;
+    uint32_t key_bytes;            /* bytes per key in the send / receive buffers of the last shard_scatter: 8, or 4 (32-bit keys,
+                                      csrc/text.h key32_of: what travels when world > 1 on 2-bit texts) */
+    uint32_t reserved_;
 } caps_sa_shard_info;
 
 int caps_sa_hip_shard_create(const void* dT, uint64_t n, uint64_t subproblem_count, int idx_bytes, int rank, int world,
@@ -276,6 +280,11 @@ int caps_sa_hip_shard_phase2(caps_sa_shard* s, const void* d_recv_keys, const vo
 int caps_sa_hip_shard_scatter(caps_sa_shard* s, void* d_send_keys, void* d_send_sa, void* d_report);
 int caps_sa_hip_shard_plan(caps_sa_shard* s, const uint64_t* all_reports, uint64_t* send_counts, uint64_t* recv_counts);
 int caps_sa_hip_shard_sort(caps_sa_shard* s, const void* d_recv_keys, const void* d_recv_sa, void* dSA, void* dLCP);
+/* Key width: shard_scatter writes 32-bit keys (shard_info.key_bytes = 4: d_send_keys / d_recv_keys are then u32 arrays) when
+ * the world has more than one rank and the text packs to 2 bits -- a third fewer bytes cross xGMI.  shard_sort then returns
+ * CAPS_SA_FB_KEY32 (> 0) when a bucket slot overflowed (skewed keys the pivots did not reveal); the ranks take the maximum
+ * of their codes, and if it is not 0 every rank calls shard_set_key_bits(s, 64) and repeats scatter / exchange / sort. */
+int caps_sa_hip_shard_set_key_bits(caps_sa_shard* s, int bits);
 /* Differential tests: copies this rank's sorted subarrays after shard_phase1 into d_keys_out (u64[count]) / d_sa_out
  * (idx[count]) (either may be NULL: sizes only); subarray g of the rank = entries [g * subarray_len, (g + 1) * subarray_len),
  * the last one to the end. */

@@ -62,7 +62,8 @@ def main():
         SAo, LCPo = (O.naive_sa_lcp(T_np, idx_bits=bits) if T_np.size <= 200_000 else O.build_sa_lcp(T_np, p=p, idx_bits=bits)[:2])
         good = np.array_equal(SA_all.view(dt), SAo) and np.array_equal(LCP_all.view(dt), LCPo)
         if rank == 0:
-            print(f"case n={T_np.size} p={p} bits={bits} path={info['path']} fb={info.get('direct_fallback')} counts={counts} "
+            print(f"case n={T_np.size} p={p} bits={bits} path={info['path']} fb={info.get('direct_fallback')} keys={info.get('key_bytes')} "
+                  f"retry={info.get('key_retry')} counts={counts} "
                   f"{'OK' if good else 'MISMATCH'}", flush=True)
         ok = ok and good
     dist.destroy_process_group()

@@ -33,6 +33,8 @@ def test_sharded_build_matches_oracle(world, port, a2a_limit, small, path):
     else:
         assert r.stdout.count("path=direct") >= (4 if small else 3), r.stdout
         assert "fb=3" in r.stdout                      # the long run: CAPS_SA_FB_LONG_RUNS, agreed on by every rank
+        assert "keys=4 retry=0" in r.stdout            # 32-bit keys crossed the (gloo) wire ...
+        assert "keys=8 retry=1" in r.stdout            # ... and a slot overflow under them sent every rank round again with 64
 
 
 def test_imbalanced_ownership_fails_on_every_rank_together():

@@ -475,6 +475,31 @@ def test_shard_kernels_at_world_sizes_above_one_loopback(L, sa_path, world, n, p
     assert torch.equal(SA, SA1)
     assert torch.equal(LCP, LCP1)
     assert build_world.last_path == ("direct" if sa_path != "classic" and world != 3 else "samplesort")
+    if build_world.last_path == "direct":                     # random DNA: 32-bit keys cross the wire, no slot overflows
+        assert (build_world.last_key_bytes, build_world.last_key_retry) == (4, 0)
+
+
+def test_shard_key_width_retry_on_skewed_keys_loopback(L):
+    """Skewed base frequencies: level B's slots overflow under 32-bit keys, shard_sort says CAPS_SA_FB_KEY32 on some rank and
+    every rank goes round again with 64-bit keys (tests/loopback_world.py asserts the code and that it happens once)."""
+    import torch
+    from loopback_world import build_world
+    n, p, world = 24_000_000, 3000, 4
+    g = torch.Generator(device="cuda")
+    g.manual_seed(99)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda")
+    u = torch.rand(n, device="cuda", generator=g)
+    T = lut[(u > 0.6).long() + (u > 0.8).long() + (u > 0.9).long()]          # base frequencies 0.6 / 0.2 / 0.1 / 0.1
+    del u
+    SA1 = torch.empty(n, dtype=torch.int32, device="cuda")
+    LCP1 = torch.empty(n, dtype=torch.int32, device="cuda")
+    L.build_device(T.data_ptr(), n, SA1.data_ptr(), LCP1.data_ptr(), p=p)
+    assert L.verify_device(T.data_ptr(), n, SA1.data_ptr(), LCP1.data_ptr()) == 0
+    SA, LCP = build_world(L, T, p, world, 32)
+    assert torch.equal(SA, SA1) and torch.equal(LCP, LCP1)
+    if build_world.last_path == "direct":
+        print("key bytes", build_world.last_key_bytes, "retries", build_world.last_key_retry)
+        assert build_world.last_key_bytes == 8 and build_world.last_key_retry == 1
 
 
 @pytest.mark.parametrize("devices,n,p,bits", [([0, 0], 20_000_001, 8000, 32), ([0, 0, 0], 9_000_000, 0, 64), ([0], 5_000_000, 64, 32)])

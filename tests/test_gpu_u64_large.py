@@ -115,7 +115,9 @@ def test_c4_sharded_direct_path_for_the_last_rank(L, c4_text):
         assert rep[-2] == 0 and rep[-1] == 0, "pivot ties / overflow on random DNA"
         assert int(rep[:-2].sum()) == sh.info()["level_a_elems"]
         reports.append((r, rep))
-        recv_k[r * per_src:(r + 1) * per_src] = bufs.send_k[g_lo * block:g_hi * block]          # what the all-to-all delivers
+        kt = torch.int32 if sh.info()["key_bytes"] == 4 else torch.int64                        # world 8, 2-bit text: 32-bit keys
+        assert kt == torch.int32
+        recv_k.view(kt)[r * per_src:(r + 1) * per_src] = bufs.send_k.view(kt)[g_lo * block:g_hi * block]   # what the all-to-all delivers
         recv_s[r * per_src:(r + 1) * per_src] = bufs.send_s[g_lo * block:g_hi * block]
         if r == target:
             keep = sh
@@ -126,7 +128,7 @@ def test_c4_sharded_direct_path_for_the_last_rank(L, c4_text):
         assert int(all_rep[:, :-2].sum()) == n                    # level A distributed every suffix exactly once
         code, sc, rc = keep.plan(all_rep)
         assert code == 0 and int(rc[0]) == per_src and int(sc[target]) == per_src
-        keep.sort_owned(recv_k.data_ptr(), recv_s.data_ptr(), bufs.SA.data_ptr(), bufs.LCP.data_ptr())
+        assert keep.sort_owned(recv_k.data_ptr(), recv_s.data_ptr(), bufs.SA.data_ptr(), bufs.LCP.data_ptr()) == 0
         info = keep.info()
         cnt = info["recv_total"]
         assert info["slice_off"] + cnt == n and abs(cnt - n // world) < n // world // 20
