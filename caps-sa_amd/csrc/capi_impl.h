@@ -827,3 +827,15 @@ int CAPS_API(shard_fix_first_lcp)(caps_sa_shard* s, uint64_t prev_sa, void* dLCP
 }
 
 }  // extern "C"
+
+#if defined(CAPS_PHASE_CLOCK) && !defined(CAPS_EMUL)
+// measurement builds only (kernels.h PHASE_MARK): copies the 32 phase counters out and clears them
+extern "C" __attribute__((visibility("default"))) int caps_sa_hip_phase_clock(uint64_t* out32)
+{
+    unsigned long long h[32];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(caps::caps_phase_clock), sizeof(h)) != hipSuccess) return -1;
+    for (int i = 0; i < 32; ++i) out32[i] = h[i];
+    for (int i = 0; i < 32; ++i) h[i] = 0;
+    return hipMemcpyToSymbol(HIP_SYMBOL(caps::caps_phase_clock), h, sizeof(h)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -46,6 +46,7 @@ namespace caps { struct EmulCtx { uint32_t block_idx, grid_dim, block_dim; }; }
 #define TL(name, tid, k) name##_tlp_[(size_t)(tid) * name##_tlc_ + (k)]
 #define UNROLL
 #define ATOMIC_OR_U32(ptr, v) (*(ptr) |= (v))
+#define ATOMIC_MIN_U32(ptr, v) (*(ptr) = std::min<uint32_t>(*(ptr), (v)))
 #define ATOMIC_ADD_U64(ptr, v) (*(ptr) += (v))
 #define ATOMIC_ADD_LDS_U64(ptr, v) (*(ptr) += (v))
 #define ATOMIC_MAX_U64(ptr, v) (*(ptr) = std::max<uint64_t>(*(ptr), (v)))
@@ -93,6 +94,7 @@ static __device__ __forceinline__ void caps_lds_barrier()
 #define TL(name, tid, k) name##_reg_[k]
 #define UNROLL _Pragma("unroll")
 #define ATOMIC_OR_U32(ptr, v) atomicOr((ptr), (v))
+#define ATOMIC_MIN_U32(ptr, v) atomicMin((ptr), (v))
 #define ATOMIC_ADD_U64(ptr, v) atomicAdd((unsigned long long*)(ptr), (unsigned long long)(v))
 #define ATOMIC_ADD_LDS_U64(ptr, v) atomicAdd((unsigned long long*)(ptr), (unsigned long long)(v))
 #define ATOMIC_MAX_U64(ptr, v) atomicMax((unsigned long long*)(ptr), (unsigned long long)(v))

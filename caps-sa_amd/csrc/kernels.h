@@ -743,6 +743,18 @@ DEV_INLINE uint64_t tile_pair_lcp(const uint32_t* __restrict__ P, uint64_t n, ui
     return pair_lcp32<BITS, RUNS>(P, n, ka, a, kb, b, cs);
 }
 
+// Measurement only (make variant VARIANT_DEFS=-DCAPS_PHASE_CLOCK; never in the product build): thread 0 of every workgroup
+// adds the cycles between two marks to caps_phase_clock[slot] -- which barrier-separated phase of a tile sort takes the time
+// (tools/phase_clock.py reads the counters through caps_sa_hip_phase_clock()).  The results of the kernels are unchanged.
+#if defined(CAPS_PHASE_CLOCK) && !defined(CAPS_EMUL)
+__device__ unsigned long long caps_phase_clock[32];
+#define PHASE_T0() unsigned long long pc_t_ = clock64()
+#define PHASE_MARK(i) do { const unsigned long long t_ = clock64(); if (threadIdx.x == 0) atomicAdd(&caps_phase_clock[i], t_ - pc_t_); pc_t_ = clock64(); } while (0)
+#else
+#define PHASE_T0() ((void)0)
+#define PHASE_MARK(i) ((void)0)
+#endif
+
 // Shared pieces of the two tile sort kernels (macros: they use the kernels' TL registers).
 #define TILE_SORT_PROLOGUE                                                                                      \
     const uint32_t b = K_BLOCK_IDX;                                                                             \
@@ -826,7 +838,9 @@ DEV_INLINE uint64_t tile_pair_lcp(const uint32_t* __restrict__ P, uint64_t n, ui
     SYNC();
 
 // sorted tile in LDS -> HBM (+ LCPs from adjacent keys, + boundary records)
-#define TILE_SORT_EMIT                                                                                          \
+#define TILE_SORT_EMIT TILE_SORT_EMIT_(0u)
+/* OV: an lcp already known for slot e (0 = none: from the keys, the text on equal keys) */
+#define TILE_SORT_EMIT_(OV)                                                                                     \
     PAR(tid) {                                                                                                  \
         UNROLL                                                                                                  \
         for (uint32_t k = 0; k < TILE_EPT; ++k) {                                                               \
@@ -835,7 +849,10 @@ DEV_INLINE uint64_t tile_pair_lcp(const uint32_t* __restrict__ P, uint64_t n, ui
                 const uint64_t key = skey[e];                                                                   \
                 const idx_t sa = ssa[e];                                                                        \
                 uint64_t l = 0;                                                                                 \
-                if (with_lcp && e) l = tile_pair_lcp<BITS, TILE_RUNS>(P, n, skey[e - 1], (uint64_t)ssa[e - 1], skey[e], (uint64_t)sa, TILE_KEY_SHIFT); \
+                if (with_lcp && e) {                                                                            \
+                    const uint32_t ov_ = (OV);                                                                  \
+                    l = ov_ ? ov_ : tile_pair_lcp<BITS, TILE_RUNS>(P, n, skey[e - 1], (uint64_t)ssa[e - 1], skey[e], (uint64_t)sa, TILE_KEY_SHIFT); \
+                }                                                                                               \
                 if (direct) {                                                                                   \
                     fin.sa[start + e] = sa;                                                                     \
                     fin.lcp[start + e] = (idx_t)l;                                                              \
@@ -885,8 +902,10 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
     TL_DECL(uint32_t, rd, TILE_EPT);
     TL_DECL(uint32_t, rb, TILE_EPT);
 
+    PHASE_T0();
     TILE_SORT_LOAD
     TILE_SORT_RANGE
+    PHASE_MARK(0);                                             // load (+ range)
     bool fast = cnt > 1 && tb.range > 0;
     if (fast) {
         PAR(tid) {
@@ -904,6 +923,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
         }
         SYNC();
         fast = flag[0] == 0;
+        PHASE_MARK(1);                                         // histogram
     }
     if (cnt == 1) {                              // nothing to sort
         PAR(tid) { if (tid == 0) { skey[0] = TL(rk, tid, 0); ssa[0] = TL(rs, tid, 0); } }
@@ -911,6 +931,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
         fast = true;
     } else if (fast) {
         block_exclusive_scan_bins(KCTX_PASS hist);         // hist[b] = first slot of bin b, hist[TILE_BINS] = cnt
+        PHASE_MARK(2);                                         // scan
         PAR(tid) {
             UNROLL
             for (uint32_t k = 0; k < TILE_EPT; ++k) {
@@ -924,6 +945,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
             }
         }
         SYNC();
+        PHASE_MARK(3);                                         // place by bin
         PAR(tid) {
             UNROLL
             for (uint32_t k = 0; k < TILE_EPT; ++k) {
@@ -949,8 +971,10 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
         }
         SYNC();
         fast = flag[0] == 0;
+        PHASE_MARK(4);                                         // rank inside the bin
         if (fast) {
             TILE_SORT_PLACE_FINAL
+            PHASE_MARK(5);                                     // place final
         }
     }
 #ifdef CAPS_EMUL
@@ -962,6 +986,19 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
         return;
     }
     TILE_SORT_EMIT
+    PHASE_MARK(6);                                             // emit (+ LCPs); the stores themselves drain after the mark
+}
+
+// Every tile straight into tile_sort_kernel's queue of unfinished tiles (skewed keys, pipeline.h SortOpts::skewed_keys:
+// the linear bin map would crowd nearly every tile -- 97 % of a genome-like text's -- and its attempt is then pure cost).
+GLOBAL_FN LAUNCH_BOUNDS(256) queue_all_tiles_kernel(KCTX SegDesc sd, uint32_t* __restrict__ redo)
+{
+    PAR(tid) {
+        const uint32_t nt = sd.tile_off[sd.G];
+        const uint32_t i = K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (i < nt) redo[1 + i] = i;
+        if (i == 0) redo[0] = nt;
+    }
 }
 
 // ---- tile_sort_eq_kernel: second chance for the tiles tile_sort_kernel could not finish --------
@@ -979,6 +1016,8 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
 #define CAPS_EQ_ROUNDS 2          /* measured on skewed-Markov tiles (simulation): largest bin, median 243 (linear) -> 50 / 26 / 13 after 1 / 2 / 3 rounds */
 #endif
 constexpr uint32_t EQ_ROUNDS = CAPS_EQ_ROUNDS;
+constexpr uint32_t TIE_G = 16;                    // lanes (= windows per round) that settle one pair of equal keys together
+constexpr uint32_t TIE_PAIR_CAP = TILE_E / 8;     // pairs of equal keys per tile the list holds (more: the comparison sort's tile)
 constexpr uint32_t EQ_FRAC_BITS = 13;             // position inside a bin; a position is bin * 2^13 + fraction < 2^24 at 2048 bins
 static_assert((uint64_t)TILE_BINS_ << EQ_FRAC_BITS <= (1u << 24), "positions fit 24 bits");
 
@@ -1017,6 +1056,16 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_eq_kernel(KCTX 
     TL_DECL(idx_t, rs, TILE_EPT);
     TL_DECL(uint32_t, rd, TILE_EPT);
     TL_DECL(uint32_t, rb, TILE_EPT);
+    TL_DECL(uint32_t, rt, TILE_EPT);         // rank phase: rank inside the bin | ties << 28
+    TL_DECL(uint32_t, rl, TILE_EPT);         // lcp with the predecessor where a tie settled it
+    TL_DECL(uint64_t, twa, 1);               // tie rounds: the lane's pair of windows
+    TL_DECL(uint64_t, twb, 1);
+    SHARED_ARRAY(uint32_t, plist, TIE_PAIR_CAP);      // pairs of equal keys: first differing window << 24 | higher slot << 12 | lower slot
+    SHARED_ARRAY(uint32_t, pcnt, 1 + TIE_WINDOWS / TIE_G);   // [0] pairs listed, [1 + r] some pair is still equal after round r
+    static_assert((TILE_BINS + 1) * sizeof(uint32_t) >= TILE_E * sizeof(uint16_t) && TILE_E <= (1u << 12) && EQ_BIN_LIMIT <= 128 &&
+                  TILE_NT % TIE_G == 0 && TIE_WINDOWS % TIE_G == 0 && TIE_WINDOWS < 0xFFu,
+                  "tinfo fits hist; slots fit 12 bits; ranks inside a bin fit 8 bits; whole rounds of windows");
+    uint16_t* tinfo = reinterpret_cast<uint16_t*>(hist);
     const uint32_t n_redo = redo[0];
     for (uint32_t qi = K_BLOCK_IDX; qi < n_redo; qi += K_GRID_DIM) {
     const uint32_t b = redo[1 + qi];
@@ -1027,8 +1076,10 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_eq_kernel(KCTX 
     const bool with_lcp = lcp_mode != 0 && (t.s1 - t.s0) <= TILE_E;
     const bool direct = with_lcp && fin.sa != nullptr;
     const uint64_t in0 = slot_cap ? (uint64_t)g * slot_cap : start;
+    PHASE_T0();
     TILE_SORT_LOAD
     TILE_SORT_RANGE
+    PHASE_MARK(8);                                             // load
     bool fast = cnt > EQ_BIN_LIMIT && tb.range > 0 && tb.B == TILE_BINS;
     if (fast) {
         PAR(tid) {
@@ -1071,7 +1122,11 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_eq_kernel(KCTX 
             }
             SYNC();
         }
-        PAR(tid) { for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0; }
+        PHASE_MARK(9);                                         // equalisation rounds
+        PAR(tid) {
+            for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0;
+            if (tid <= TIE_WINDOWS / TIE_G) pcnt[tid] = 0;
+        }
         SYNC();
         PAR(tid) {
             UNROLL
@@ -1088,9 +1143,11 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_eq_kernel(KCTX 
         }
         SYNC();
         fast = flag[0] == 0;
+        PHASE_MARK(10);                                        // final histogram
     }
     if (fast) {                                                // from here on: as in tile_sort_kernel
         block_exclusive_scan_bins(KCTX_PASS hist);
+        PHASE_MARK(11);                                        // scan
         PAR(tid) {
             UNROLL
             for (uint32_t k = 0; k < TILE_EPT; ++k) {
@@ -1104,6 +1161,23 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_eq_kernel(KCTX 
             }
         }
         SYNC();
+        PHASE_MARK(12);                                        // place by bin
+        // ---- exact rank inside the bin.  Ties (equal keys: 2 % of a genome-like text's neighbours, repeats with a
+        // mutation every ~100 chars) need the text, several windows deep, every window a dependent HBM read of ~1 us.  Inside
+        // the ranking loop such a read stalls the whole wave once per tie and window, one after the other: measured with the
+        // phase clock (tools/phase_clock.py), 53 % of this kernel's time, and 24 % more in the emit phase, which read the same
+        // text again for the lcps.  So:
+        //  R1  rank by keys only and note the ties; the member with the higher slot of a PAIR of equal keys (the common case)
+        //      puts the pair on a list;
+        //  T   the workgroup settles the listed pairs together: TIE_G lanes per pair, one window each, all loads of a round
+        //      in flight at once -- TIE_G windows deep for ONE memory latency; the lane with the first difference (an LDS
+        //      atomic min on the list entry) derives order and lcp and leaves them for both members in tinfo; pairs that are
+        //      still equal go another round, up to TIE_WINDOWS windows (then the tile is the comparison sort's);
+        //  R3  the members pick their outcome up; an element with SEVERAL equal keys compares with each of them itself
+        //      (listing those as well was measured: slower, 185 against 172 ms on the genome-like 3e9 text).
+        // The lcp of an element with its predecessor in the final order is the largest lcp with a smaller member of its tie
+        // group; it travels with the element to its final slot (slcp) and the emit phase uses it instead of the text.
+        // tinfo / slcp: u16 per slot, in the memory of hist (free once R1 has read the bin bounds).
         PAR(tid) {
             UNROLL
             for (uint32_t k = 0; k < TILE_EPT; ++k) {
@@ -1112,25 +1186,136 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_eq_kernel(KCTX 
                     const uint32_t bin = TL(rb, tid, k), slot = TL(rd, tid, k);
                     const uint32_t bs = hist[bin], be = hist[bin + 1];
                     const uint64_t key = TL(rk, tid, k);
-                    const uint64_t sa = (uint64_t)TL(rs, tid, k);
-                    uint32_t less = 0;
-                    for (uint32_t j = bs; j < be; ++j) {
-                        const uint64_t kj = skey[j];
-                        less += kj < key ? 1u : 0u;
-                        if (kj == key && j != slot) {
-                            const uint32_t c = suffix_less_tie_bounded<BITS>(P, n, (uint64_t)ssa[j], sa);
-                            if (c == 2u) flag[0] = 1;
-                            less += c & 1u;
+                    uint32_t less = 0, ties = 0, tj = 0;
+                    for (uint32_t j = bs; j < be; j += 4) {                // four LDS reads in flight (crowded bins: up to 128)
+                        uint64_t kq[4];
+                        UNROLL
+                        for (uint32_t q = 0; q < 4; ++q) kq[q] = skey[j + q < TILE_E ? j + q : TILE_E - 1u];
+                        UNROLL
+                        for (uint32_t q = 0; q < 4; ++q) {
+                            if (j + q < be) {
+                                less += kq[q] < key ? 1u : 0u;
+                                if (kq[q] == key && j + q != slot) { ++ties; tj = j + q; }
+                            }
                         }
                     }
-                    TL(rd, tid, k) = bs + less;
+                    TL(rb, tid, k) = bs | (be << 16);                      // the bin id is not needed any more
+                    TL(rt, tid, k) = less | (ties > 3u ? 3u << 28 : ties << 28);   // less <= 127
+                    if (ties == 1u && slot > tj) {
+                        const uint32_t pi = FETCH_ADD_U32(&pcnt[0], 1u);
+                        if (pi < TIE_PAIR_CAP) plist[pi] = 0xFF000000u | (slot << 12) | tj;
+                        else flag[0] = 1;                                  // more pairs than the list holds: not here
+                    }
+                }
+            }
+        }
+        SYNC();                                                // hist is free: tinfo / slcp from here on
+        PHASE_MARK(16);                                        // R1: rank by keys
+        {
+            const uint32_t npairs = pcnt[0] < TIE_PAIR_CAP ? pcnt[0] : TIE_PAIR_CAP;        // block-uniform
+            constexpr uint32_t KCH_ = TextTraits<BITS>::KCH, ROUNDS = TIE_WINDOWS / TIE_G, PER = TILE_NT / TIE_G;
+            for (uint32_t round = 0; round < ROUNDS && npairs; ++round) {
+                for (uint32_t base = 0; base < npairs; base += PER) {
+                    PAR(tid) {
+                        const uint32_t pi = base + tid / TIE_G, W = round * TIE_G + tid % TIE_G;
+                        TL(twa, tid, 0) = 0;
+                        TL(twb, tid, 0) = 0;
+                        if (pi < npairs) {
+                            const uint32_t ent = plist[pi];
+                            if ((ent >> 24) == 0xFFu) {                   // not settled in an earlier round
+                                const uint64_t a = (uint64_t)ssa[ent & 0xFFFu], b2 = (uint64_t)ssa[(ent >> 12) & 0xFFFu];
+                                const uint64_t maxlen = a < n && b2 < n ? n - (a > b2 ? a : b2) : 0;   // corrupt index: settle at once
+                                const uint64_t l = (uint64_t)KCH_ * (1u + W);
+                                bool hit = l >= maxlen;                   // the shorter suffix ends before this window
+                                if (!hit) {
+                                    const uint64_t wa = window64<BITS>(P, a + l), wb = window64<BITS>(P, b2 + l);
+                                    TL(twa, tid, 0) = wa;
+                                    TL(twb, tid, 0) = wb;
+                                    hit = wa != wb;
+                                }
+                                if (hit) ATOMIC_MIN_U32(&plist[pi], (W << 24) | (ent & 0xFFFFFFu));
+                            }
+                        }
+                    }
+                    SYNC();
+                    PAR(tid) {
+                        const uint32_t pi = base + tid / TIE_G, W = round * TIE_G + tid % TIE_G;
+                        if (pi < npairs) {
+                            const uint32_t ent = plist[pi], lo = ent & 0xFFFu, hi = (ent >> 12) & 0xFFFu;
+                            if ((ent >> 24) == W) {                       // mine is the first window that differs (or ends)
+                                const uint64_t a = (uint64_t)ssa[lo], b2 = (uint64_t)ssa[hi];
+                                const uint64_t maxlen = a < n && b2 < n ? n - (a > b2 ? a : b2) : 0;
+                                const uint64_t l = (uint64_t)KCH_ * (1u + W);
+                                const uint64_t wa = TL(twa, tid, 0), wb = TL(twb, tid, 0);
+                                uint64_t d = maxlen;
+                                bool lo_first = a > b2;                   // one is a prefix of the other: the shorter first
+                                if (l < maxlen) {
+                                    d = l + (uint32_t)caps_clz64(wa ^ wb) / BITS;
+                                    d = d < maxlen ? d : maxlen;
+                                    lo_first = wa < wb;
+                                }
+                                tinfo[hi] = (uint16_t)(lo_first ? 0x8000u | (uint32_t)d : 0u);   // "your partner sorts before you" + lcp
+                                tinfo[lo] = (uint16_t)(lo_first ? 0u : 0x8000u | (uint32_t)d);
+                            } else if ((ent >> 24) == 0xFFu && tid % TIE_G == 0) {
+                                if (round + 1 == ROUNDS) flag[0] = 1;     // deeper than TIE_WINDOWS windows: not here
+                                else pcnt[1 + round] = 1;                 // another round
+                            }
+                        }
+                    }
+                }
+                SYNC();
+                if (round + 1 == ROUNDS || pcnt[1 + round] == 0) break;
+            }
+        }
+        PHASE_MARK(17);                                        // T: ties of pairs
+        PAR(tid) {
+            UNROLL
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                const uint32_t e = tid + k * TILE_NT;
+                TL(rl, tid, k) = 0;
+                if (e < cnt) {
+                    uint32_t info = TL(rt, tid, k);
+                    const uint32_t ties = info >> 28, slot = TL(rd, tid, k);
+                    const uint32_t bs = TL(rb, tid, k) & 0xFFFFu, be = TL(rb, tid, k) >> 16;
+                    if (ties == 1u) {
+                        const uint32_t v = tinfo[slot];
+                        if (v & 0x8000u) { ++info; TL(rl, tid, k) = v & 0x7FFFu; }
+                    } else if (ties > 1u) {
+                        const uint64_t key = TL(rk, tid, k);
+                        const uint64_t sa = (uint64_t)TL(rs, tid, k);
+                        uint32_t best = 0;
+                        for (uint32_t j = bs; j < be; ++j) {
+                            if (skey[j] == key && j != slot) {
+                                uint32_t l;
+                                const uint32_t c = tie_order_lcp_bounded<BITS>(P, n, (uint64_t)ssa[j], sa, l);   // 1: j sorts before me
+                                if (c == 2u) flag[0] = 1;
+                                if (c == 1u) { ++info; best = l > best ? l : best; }
+                            }
+                        }
+                        TL(rl, tid, k) = best;
+                    }
+                    TL(rd, tid, k) = bs + (info & 0xFFu);
                 }
             }
         }
         SYNC();
         fast = flag[0] == 0;
+        PHASE_MARK(13);                                        // rank inside the bin
         if (fast) {
-            TILE_SORT_PLACE_FINAL
+            PAR(tid) {
+                UNROLL
+                for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                    const uint32_t e = tid + k * TILE_NT;
+                    if (e < cnt) {
+                        const uint32_t d = TL(rd, tid, k);
+                        skey[d] = TL(rk, tid, k);
+                        ssa[d] = TL(rs, tid, k);
+                        tinfo[d] = (uint16_t)TL(rl, tid, k);   // = slcp: the lcp with the predecessor, where a tie settled it
+                    }
+                }
+            }
+            SYNC();
+            PHASE_MARK(14);                                    // place final
         }
     }
 #ifdef CAPS_EMUL
@@ -1139,9 +1324,10 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_eq_kernel(KCTX 
     if (!fast) {
         PAR(tid) { if (tid == 0) redo2[1 + FETCH_ADD_U32(&redo2[0], 1u)] = b; }
     } else {
-        TILE_SORT_EMIT
+        TILE_SORT_EMIT_((uint32_t)tinfo[e])
     }
     SYNC();                                                    // the staging arrays are free for the next tile
+    PHASE_MARK(15);                                            // emit (+ LCPs) and the barrier behind it
     }
 }
 

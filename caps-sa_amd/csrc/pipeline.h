@@ -427,6 +427,8 @@ struct SortOpts {
     const uint8_t* gshift = nullptr;    // non-null with range_mode 2: 32-bit keys (text.h key32_of), the parents' shifts
     bool k32 = false;                   // the elements (in_key, read as uint32_t) carry 32-bit keys; slots only: when a slot
                                         //   overflows the sort gives up (SortResult::failed) and the caller falls back to 64-bit keys
+    bool skewed_keys = false;           // the keys are far from uniform inside the buckets (skew probe): every tile goes to
+                                        //   tile_sort_eq_kernel straight away, tile_sort_kernel's linear map is not tried
     const uint64_t* knots = nullptr;    // non-null (quantile mode): parent q's buckets are (knots[q * KPG + i - 1], knots[q * KPG + i]],
     uint32_t knots_per_parent = 0;      //   i < KPG = knots_per_parent -- count pass + exact scatter, no slots, no equalising
     const void* runs = nullptr;   // RunSrc<idx_t>*: the segments are partitions still spread over the sorted subarrays in
@@ -681,7 +683,8 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         CAPS_LAUNCH_RUNS(tile_sort_general_kernel, (idx_t, BITS, false), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
                     (const uint64_t*)nullptr, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo2, 1u);
     } else {
-        CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
+        if (o.skewed_keys && eq_tiles) CAPS_LAUNCH(queue_all_tiles_kernel, (n_tiles + 255) / 256, 256, be, sd, redo);
+        else CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
                     in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, redo, no_shift);
         if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false>), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
                     in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo, redo2, 0u);
@@ -1116,6 +1119,7 @@ private:
         o2.sub = SUB;
         o2.seg_ends = true;
         if (quantile) { o2.knots = pl_.knots; o2.knots_per_parent = KPG; }
+        o2.skewed_keys = quantile && probe[2] != 0 && !std::getenv("CAPS_SA_TRY_LINEAR_TILES");   // (the variable: measurement)
         if (k32) { o2.k32 = true; o2.range_mode = 2; o2.gshift = pl_.gshift; }
         o2.in_key = a_key;
         o2.in_sa = a_sa;

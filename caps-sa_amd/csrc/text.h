@@ -256,6 +256,39 @@ HD uint32_t suffix_less_tie_bounded(const uint32_t* __restrict__ P, uint64_t n, 
     return 2u;
 }
 
+// Order AND lcp of two distinct suffixes with equal keys in one bounded scan (tile_sort_eq_kernel resolves every tie of a
+// tile once and hands the lcp on to the emit phase).  Two windows per step, loaded unconditionally: one memory latency per
+// 2 * KCH chars.  Returns 1 / 0 = a sorts before b / not, with lcp set (< 2^15: from + TIE_WINDOWS * KCH chars at most);
+// 2 = still equal after TIE_WINDOWS windows (lcp unset).
+template <int BITS>
+HD uint32_t tie_order_lcp_bounded(const uint32_t* __restrict__ P, uint64_t n, uint64_t a, uint64_t b, uint32_t& lcp)
+{
+    constexpr uint32_t KCH = TextTraits<BITS>::KCH;
+    lcp = 0;
+    if (a >= n || b >= n) return a > b ? 1u : 0u;
+    const uint64_t maxlen = n - (a > b ? a : b);
+    uint64_t l = KCH;
+    for (uint32_t k = 0; k < TIE_WINDOWS / 2 && l < maxlen; ++k, l += 2 * KCH) {
+        const bool more = l + KCH < maxlen;
+        const uint64_t l1 = more ? l + KCH : l;                  // no second window: the first one again (a safe address)
+        const uint64_t wa0 = window64<BITS>(P, a + l), wb0 = window64<BITS>(P, b + l);
+        const uint64_t wa1 = window64<BITS>(P, a + l1), wb1 = window64<BITS>(P, b + l1);
+        if (wa0 != wb0) {
+            const uint64_t d = l + (uint32_t)caps_clz64(wa0 ^ wb0) / BITS;
+            lcp = (uint32_t)(d < maxlen ? d : maxlen);
+            return wa0 < wb0 ? 1u : 0u;
+        }
+        if (wa1 != wb1) {
+            const uint64_t d = l1 + (uint32_t)caps_clz64(wa1 ^ wb1) / BITS;
+            lcp = (uint32_t)(d < maxlen ? d : maxlen);
+            return wa1 < wb1 ? 1u : 0u;
+        }
+    }
+    if (l >= maxlen) { lcp = (uint32_t)maxlen; return a > b ? 1u : 0u; }      // one is a prefix of the other: the shorter first
+    return 2u;
+}
+static_assert(64 / 2 + TIE_WINDOWS * (64 / 2) < (1u << 15) && 64 / 8 + TIE_WINDOWS * (64 / 8) < (1u << 15), "bounded tie lcps fit 15 bits");
+
 // Strict total order on suffixes: true iff suffix a sorts before suffix b.
 // (a == b -> false.)  Shorter suffix first when one is a prefix of the other.
 template <int BITS, bool RUNS = true>

@@ -372,3 +372,45 @@ def test_32_bit_keys_opt_in(oracle, monkeypatch):
             SA, LCP, st = emul().build(T, p=p, idx_bits=bits)
             assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), (T.size, keys)
             assert st["path_direct"] == 1 and st["direct_key_bits"] == expect, st
+
+
+def test_equalised_tile_sort_settles_ties_once(oracle):
+    """tile_sort_eq_kernel on skewed keys with planted repeats: pairs of equal keys (the common case: the member with the
+    higher slot compares, its partner picks the outcome up), groups of three and more (every member compares with each of
+    the others), ties deeper than the bounded scan (the tile goes on to the comparison sort), and the lcps that the tie
+    scans hand to the emit phase.  The counters say that the equalised kernel did finish tiles with such ties."""
+    import ctypes
+    from emul_util import emul_small
+    for E, n in ((emul(), 400_000), (emul_small(), 60_000)):
+        f = E.dll.caps_sa_emul_tile_stats8
+        f.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        a = (ctypes.c_uint64 * 8)()
+        rs = np.random.RandomState(n % 97)
+        # order-2 chain with skewed transitions: far from uniform inside every key range
+        trans = rs.dirichlet([0.4] * 4, size=16)
+        c = rs.randint(0, 4, size=2).tolist()
+        u = rs.rand(n)
+        cdf = np.cumsum(trans, axis=1)
+        for i in range(2, n):
+            c.append(int(min(3, np.searchsorted(cdf[c[-2] * 4 + c[-1]], u[i]))))
+        T = DNA[np.array(c)]
+        L = 90
+        for _ in range(n // 2000):                           # pairs: a copy with one mutation somewhere
+            s, d = rs.randint(0, n - L, size=2)
+            T[d:d + L] = T[s:s + L]
+            T[d + rs.randint(40, L)] = DNA[rs.randint(0, 4)]
+        for _ in range(n // 8000):                           # groups of three and four equal 32-mers
+            s = rs.randint(0, n - L)
+            for d in rs.randint(0, n - L, size=rs.randint(2, 4)):
+                T[d:d + L] = T[s:s + L]
+        s, d = n // 5, n // 2                                 # one tie far deeper than TIE_WINDOWS windows
+        T[d:d + 3000] = T[s:s + 3000]
+        f(a, 1)
+        SA, LCP, st = E.build(T, p=24)
+        f(a, 1)
+        SAo, LCPo = oracle.build_sa_lcp(T, p=24)
+        assert np.array_equal(SA, SAo), "SA"
+        assert np.array_equal(LCP, LCPo), "LCP"
+        gave_up, finished = a[6], a[7]
+        assert finished > 0, list(a)
+        assert int((LCP >= 40).sum()) > n // 100 and int(LCP.max()) >= 2999
