@@ -2205,6 +2205,7 @@ template <int BITS> HD uint64_t text_win_base(uint64_t pos0) { return pos0 / Tex
 //                scratch otherwise (level B in quantile mode: the knots of the segment's group).  Keys only: all
 //                suffixes with one key value land in one bucket, so buckets are consecutive slices of the suffix order.
 constexpr int MAP_LINEAR = 0, MAP_GROUPED = 1, MAP_SPLIT = 2;
+constexpr uint32_t COUNT_CHUNK = 8;            // tiles per chunk of bucket_count_kernel
 
 // Persistent workgroups (a tile is little work: launching one workgroup per tile is bound by
 // the wave launch rate).
@@ -2221,9 +2222,19 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_count_kernel(KCTX SegDesc sd, const uint
     SHARED_ARRAY(uint32_t, twin, FROM_TEXT ? TEXT_WIN : 1);
     SHARED_ARRAY(uint64_t, lsrc, FROM_RUNS ? TILE_E : 1);
     SHARED_ARRAY(idx_t, lrow, FROM_RUNS ? TILE_E : 1);
+    // A workgroup takes CHUNKS of consecutive tiles and keeps one LDS histogram across the tiles of a chunk that count into
+    // the same buckets (consecutive tiles of a long segment, or of the sub-streams of one parent): the histogram reaches the
+    // global counters once per chunk instead of once per tile -- at ~1000 buckets per segment and 4096 elements per tile
+    // that flush is one global atomic per 4 elements (genome-like 3e9, quantile mode: 20 of 162 ms were this kernel).
     const uint32_t n_tiles = sd.tile_off[sd.G];
-    for (uint32_t v = K_BLOCK_IDX; v < n_tiles; v += K_GRID_DIM) {
-        const uint32_t b = v;
+    const uint32_t want = n_tiles / (4u * K_GRID_DIM);
+    const uint32_t CH = want < 1u ? 1u : want > COUNT_CHUNK ? COUNT_CHUNK : want;          // short launches keep every workgroup busy
+    const uint32_t n_chunks = (n_tiles + CH - 1) / CH;
+    for (uint32_t v = K_BLOCK_IDX; v < n_chunks; v += K_GRID_DIM) {
+    uint64_t cur_b0 = ~0ull;                           // block-uniform: the buckets the LDS histogram counts for (~0: none)
+    uint32_t cur_B = 0;
+    const uint32_t b_end = (v + 1) * CH < n_tiles ? (v + 1) * CH : n_tiles;
+    for (uint32_t b = v * CH; b < b_end; ++b) {
         const uint32_t g = sd.tile_rec[b].g;
         const TileInfo t = tile_info(sd, b);
         const uint64_t start = t.s0 + (uint64_t)t.tl * TILE_E;
@@ -2239,13 +2250,20 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_count_kernel(KCTX SegDesc sd, const uint
         RUNS_TILE_SETUP
         const uint32_t n_split = MAP == MAP_SPLIT ? bp.B - 1 : 0u;
         const uint64_t* tab = MAP == MAP_SPLIT ? split + (uint64_t)(g / in_sub) * split_stride : nullptr;
+        // same buckets as the tile before (and, MAP_SPLIT, the same table: it belongs to the parent that owns the buckets)?
+        const bool fresh = !lds || b0 != cur_b0 || bp.B != cur_B;
         PAR(tid) {
-            if (lds) for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM) hist[i] = 0;
-            if (MAP == MAP_SPLIT && lds) for (uint32_t i = tid; i < n_split; i += K_BLOCK_DIM) stab[i] = tab[i];
+            if (fresh) {
+                for (uint32_t i = tid; i < cur_B; i += K_BLOCK_DIM)
+                    if (hist[i]) ATOMIC_ADD_U64(&count[cur_b0 + i], (uint64_t)hist[i]);
+                if (lds) for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM) hist[i] = 0;
+                if (MAP == MAP_SPLIT && lds) for (uint32_t i = tid; i < n_split; i += K_BLOCK_DIM) stab[i] = tab[i];
+            }
             if (FROM_TEXT)
                 for (uint32_t i = tid; i < TEXT_WIN; i += K_BLOCK_DIM) twin[i] = w0 + i < n_words ? P[w0 + i] : 0u;
             if (FROM_RUNS) { RUNS_STAGE(tid) }
         }
+        if (fresh) { cur_b0 = lds ? b0 : ~0ull; cur_B = lds ? bp.B : 0u; }
         SYNC();
         const uint32_t top = pow2_above(n_split);
         PAR(tid) {
@@ -2282,14 +2300,15 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_count_kernel(KCTX SegDesc sd, const uint
                 }
             }
         }
-        SYNC();
-        if (lds) {
-            PAR(tid) {
-                for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM)
-                    if (hist[i]) ATOMIC_ADD_U64(&count[b0 + i], (uint64_t)hist[i]);
-            }
-            SYNC();
+        SYNC();                                        // the histogram is complete; the staging arrays are free
+    }
+    if (cur_B) {
+        PAR(tid) {
+            for (uint32_t i = tid; i < cur_B; i += K_BLOCK_DIM)
+                if (hist[i]) ATOMIC_ADD_U64(&count[cur_b0 + i], (uint64_t)hist[i]);
         }
+        SYNC();
+    }
     }
 }
 
@@ -2559,7 +2578,10 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
 //                        bucket_scatter_kernel); ends as the stream's size -- larger than slot_cap = the stream overflowed,
 //                        its surplus was dropped and the caller must not use the result
 //   stream (g, sx) owns [(g * sub + sx) * slot_cap, +slot_cap) of out_key / out_sa
-constexpr uint32_t GA_TILES = 4;
+#ifndef CAPS_GA_TILES
+#define CAPS_GA_TILES 4
+#endif
+constexpr uint32_t GA_TILES = CAPS_GA_TILES;
 constexpr uint32_t GA_E = GA_TILES * TILE_E;
 constexpr uint32_t GA_EPT = GA_E / TILE_NT;
 static_assert(GA_E <= (1u << 14) && BUCKET_LDS <= (1u << 11), "group << 14 | position fits a register");
