@@ -1016,8 +1016,11 @@ GLOBAL_FN LAUNCH_BOUNDS(256) queue_all_tiles_kernel(KCTX SegDesc sd, uint32_t* _
 #define CAPS_EQ_ROUNDS 2          /* measured on skewed-Markov tiles (simulation): largest bin, median 243 (linear) -> 50 / 26 / 13 after 1 / 2 / 3 rounds */
 #endif
 constexpr uint32_t EQ_ROUNDS = CAPS_EQ_ROUNDS;
-constexpr uint32_t TIE_G = 16;                    // lanes (= windows per round) that settle one pair of equal keys together
-constexpr uint32_t TIE_PAIR_CAP = TILE_E / 8;     // pairs of equal keys per tile the list holds (more: the comparison sort's tile)
+constexpr uint32_t TIE_G1 = 8;                    // lanes (= windows) per listed tie in the first round,
+constexpr uint32_t TIE_G2 = 64;                   //   per tie that is still equal in the second
+constexpr uint32_t TIE_LIST_CAP = TILE_E / 8;     // list entries per tile (pairs from the bottom, elements' own entries from the top)
+constexpr uint32_t TIE_LIST_MAX = 6;              // an element lists up to this many equal keys (more: it scans them itself)
+constexpr uint32_t TIE_DEEP_CAP = 64;             // entries that may go to the second round
 constexpr uint32_t EQ_FRAC_BITS = 13;             // position inside a bin; a position is bin * 2^13 + fraction < 2^24 at 2048 bins
 static_assert((uint64_t)TILE_BINS_ << EQ_FRAC_BITS <= (1u << 24), "positions fit 24 bits");
 
@@ -1056,15 +1059,19 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_eq_kernel(KCTX 
     TL_DECL(idx_t, rs, TILE_EPT);
     TL_DECL(uint32_t, rd, TILE_EPT);
     TL_DECL(uint32_t, rb, TILE_EPT);
-    TL_DECL(uint32_t, rt, TILE_EPT);         // rank phase: rank inside the bin | ties << 28
+    TL_DECL(uint32_t, rt, TILE_EPT);         // rank phase: rank inside the bin | first own entry << 8 | ties << 28
     TL_DECL(uint32_t, rl, TILE_EPT);         // lcp with the predecessor where a tie settled it
-    TL_DECL(uint64_t, twa, 1);               // tie rounds: the lane's pair of windows
+    TL_DECL(uint64_t, twa, 1);               // tie rounds: the lane's pair of windows,
     TL_DECL(uint64_t, twb, 1);
-    SHARED_ARRAY(uint32_t, plist, TIE_PAIR_CAP);      // pairs of equal keys: first differing window << 24 | higher slot << 12 | lower slot
-    SHARED_ARRAY(uint32_t, pcnt, 1 + TIE_WINDOWS / TIE_G);   // [0] pairs listed, [1 + r] some pair is still equal after round r
+    TL_DECL(uint32_t, tpi, 1);               //   its entry (index | own-entry flag << 31 | virtual index << 16; ~0: none)
+    SHARED_ARRAY(uint32_t, plist, TIE_LIST_CAP);      // ties: first differing window << 24 | slot << 12 | the other's slot;
+                                                      //   an own entry once settled: 0x80 | the other sorts first, << 24 | lcp
+    SHARED_ARRAY(uint16_t, deep, TIE_DEEP_CAP);       // entries (virtual index) still equal after the first round
+    SHARED_ARRAY(uint32_t, pcnt, 4);                  // pairs listed, own entries listed, entries on `deep`
     static_assert((TILE_BINS + 1) * sizeof(uint32_t) >= TILE_E * sizeof(uint16_t) && TILE_E <= (1u << 12) && EQ_BIN_LIMIT <= 128 &&
-                  TILE_NT % TIE_G == 0 && TIE_WINDOWS % TIE_G == 0 && TIE_WINDOWS < 0xFFu,
-                  "tinfo fits hist; slots fit 12 bits; ranks inside a bin fit 8 bits; whole rounds of windows");
+                  TILE_NT % TIE_G1 == 0 && TILE_NT % TIE_G2 == 0 && TIE_G1 + TIE_G2 < 0x80u && TIE_LIST_CAP <= (1u << 12) &&
+                  TextTraits<BITS>::KCH * (1u + TIE_G1 + TIE_G2) < (1u << 15),
+                  "tinfo fits hist; slots and entries fit 12 bits; ranks inside a bin fit 8 bits; lcps of settled ties fit 15 bits");
     uint16_t* tinfo = reinterpret_cast<uint16_t*>(hist);
     const uint32_t n_redo = redo[0];
     for (uint32_t qi = K_BLOCK_IDX; qi < n_redo; qi += K_GRID_DIM) {
@@ -1125,7 +1132,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_eq_kernel(KCTX 
         PHASE_MARK(9);                                         // equalisation rounds
         PAR(tid) {
             for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0;
-            if (tid <= TIE_WINDOWS / TIE_G) pcnt[tid] = 0;
+            if (tid < 4) pcnt[tid] = 0;
         }
         SYNC();
         PAR(tid) {
@@ -1167,14 +1174,16 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_eq_kernel(KCTX 
         // the ranking loop such a read stalls the whole wave once per tie and window, one after the other: measured with the
         // phase clock (tools/phase_clock.py), 53 % of this kernel's time, and 24 % more in the emit phase, which read the same
         // text again for the lcps.  So:
-        //  R1  rank by keys only and note the ties; the member with the higher slot of a PAIR of equal keys (the common case)
-        //      puts the pair on a list;
-        //  T   the workgroup settles the listed pairs together: TIE_G lanes per pair, one window each, all loads of a round
-        //      in flight at once -- TIE_G windows deep for ONE memory latency; the lane with the first difference (an LDS
-        //      atomic min on the list entry) derives order and lcp and leaves them for both members in tinfo; pairs that are
-        //      still equal go another round, up to TIE_WINDOWS windows (then the tile is the comparison sort's);
-        //  R3  the members pick their outcome up; an element with SEVERAL equal keys compares with each of them itself
-        //      (listing those as well was measured: slower, 185 against 172 ms on the genome-like 3e9 text).
+        //  R1  rank by keys only and note the ties.  A PAIR of equal keys (91 % of the tied elements of a genome-like text) is
+        //      listed once, by its member with the higher slot; an element with 2 .. TIE_LIST_MAX equal keys lists (itself, the
+        //      other) for each of them -- its own entries, from the top of the same list;
+        //  T   the workgroup settles the listed entries together, several lanes per entry, one window each, all loads of a
+        //      round in flight at once: TIE_G1 windows deep for ONE memory latency.  The lane with the first difference (an
+        //      LDS atomic min on the entry) derives order and lcp: for a pair it leaves them for both members in tinfo, for
+        //      an own entry in the entry itself.  What is still equal (one tie in eight on such a text) goes on a short list
+        //      and gets TIE_G2 lanes per entry in a second round; still equal after that (TIE_G1 + TIE_G2 windows), or more
+        //      ties than the lists hold: the tile is the comparison sort's;
+        //  R3  the elements pick their outcomes up; one with more than TIE_LIST_MAX equal keys (rare) compares with each itself.
         // The lcp of an element with its predecessor in the final order is the largest lcp with a smaller member of its tie
         // group; it travels with the element to its final slot (slcp) and the emit phase uses it instead of the text.
         // tinfo / slcp: u16 per slot, in the memory of hist (free once R1 has read the bin bounds).
@@ -1187,114 +1196,144 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_eq_kernel(KCTX 
                     const uint32_t bs = hist[bin], be = hist[bin + 1];
                     const uint64_t key = TL(rk, tid, k);
                     uint32_t less = 0, ties = 0, tj = 0;
-                    for (uint32_t j = bs; j < be; j += 4) {                // four LDS reads in flight (crowded bins: up to 128)
-                        uint64_t kq[4];
-                        UNROLL
-                        for (uint32_t q = 0; q < 4; ++q) kq[q] = skey[j + q < TILE_E ? j + q : TILE_E - 1u];
-                        UNROLL
-                        for (uint32_t q = 0; q < 4; ++q) {
-                            if (j + q < be) {
-                                less += kq[q] < key ? 1u : 0u;
-                                if (kq[q] == key && j + q != slot) { ++ties; tj = j + q; }
-                            }
+                    for (uint32_t j = bs; j < be; ++j) {
+                        const uint64_t kj = skey[j];
+                        less += kj < key ? 1u : 0u;
+                        if (kj == key && j != slot) { ++ties; tj = j; }
+                    }
+                    uint32_t own = 0;                                      // my first entry, counted from the top of the list
+                    if (ties == 1u && slot > tj) {
+                        const uint32_t pi = FETCH_ADD_U32(&pcnt[0], 1u);
+                        if (pi < TIE_LIST_CAP) plist[pi] = 0xFF000000u | (slot << 12) | tj;
+                    } else if (ties >= 2u && ties <= TIE_LIST_MAX) {
+                        own = FETCH_ADD_U32(&pcnt[1], ties);
+                        if (own + ties <= TIE_LIST_CAP) {
+                            uint32_t q = own;
+                            for (uint32_t j = bs; j < be; ++j)
+                                if (skey[j] == key && j != slot) plist[TIE_LIST_CAP - 1u - q++] = 0xFF000000u | (slot << 12) | j;
+                        } else {
+                            own = 0;                                       // (the tile fails below: the list is full)
                         }
                     }
                     TL(rb, tid, k) = bs | (be << 16);                      // the bin id is not needed any more
-                    TL(rt, tid, k) = less | (ties > 3u ? 3u << 28 : ties << 28);   // less <= 127
-                    if (ties == 1u && slot > tj) {
-                        const uint32_t pi = FETCH_ADD_U32(&pcnt[0], 1u);
-                        if (pi < TIE_PAIR_CAP) plist[pi] = 0xFF000000u | (slot << 12) | tj;
-                        else flag[0] = 1;                                  // more pairs than the list holds: not here
-                    }
+                    TL(rt, tid, k) = less | (own << 8) | (ties > 15u ? 15u << 28 : ties << 28);   // less <= 127, own < 2^12
                 }
             }
         }
         SYNC();                                                // hist is free: tinfo / slcp from here on
         PHASE_MARK(16);                                        // R1: rank by keys
         {
-            const uint32_t npairs = pcnt[0] < TIE_PAIR_CAP ? pcnt[0] : TIE_PAIR_CAP;        // block-uniform
-            constexpr uint32_t KCH_ = TextTraits<BITS>::KCH, ROUNDS = TIE_WINDOWS / TIE_G, PER = TILE_NT / TIE_G;
-            for (uint32_t round = 0; round < ROUNDS && npairs; ++round) {
-                for (uint32_t base = 0; base < npairs; base += PER) {
-                    PAR(tid) {
-                        const uint32_t pi = base + tid / TIE_G, W = round * TIE_G + tid % TIE_G;
-                        TL(twa, tid, 0) = 0;
-                        TL(twb, tid, 0) = 0;
-                        if (pi < npairs) {
-                            const uint32_t ent = plist[pi];
-                            if ((ent >> 24) == 0xFFu) {                   // not settled in an earlier round
-                                const uint64_t a = (uint64_t)ssa[ent & 0xFFFu], b2 = (uint64_t)ssa[(ent >> 12) & 0xFFFu];
-                                const uint64_t maxlen = a < n && b2 < n ? n - (a > b2 ? a : b2) : 0;   // corrupt index: settle at once
-                                const uint64_t l = (uint64_t)KCH_ * (1u + W);
-                                bool hit = l >= maxlen;                   // the shorter suffix ends before this window
-                                if (!hit) {
-                                    const uint64_t wa = window64<BITS>(P, a + l), wb = window64<BITS>(P, b2 + l);
-                                    TL(twa, tid, 0) = wa;
-                                    TL(twb, tid, 0) = wb;
-                                    hit = wa != wb;
+            const uint32_t np = pcnt[0], nm = pcnt[1];                                     // block-uniform
+            constexpr uint32_t KCH_ = TextTraits<BITS>::KCH;
+            if (np + nm > TIE_LIST_CAP) {
+                PAR(tid) { if (tid == 0) flag[0] = 1; }                                    // more ties than the list holds: not here
+            } else if (np + nm) {
+                for (uint32_t round = 0; round < 2; ++round) {
+                    // round 0: every entry, TIE_G1 lanes each; round 1: the entries on the short list, TIE_G2 lanes each
+                    const uint32_t G = round ? TIE_G2 : TIE_G1, W0 = round ? TIE_G1 : 0u;
+                    const uint32_t n_ent = round ? (pcnt[2] < TIE_DEEP_CAP ? pcnt[2] : TIE_DEEP_CAP) : np + nm;
+                    if (round && pcnt[2] > TIE_DEEP_CAP) { PAR(tid) { if (tid == 0) flag[0] = 1; } }
+                    for (uint32_t base = 0; base < n_ent; base += TILE_NT / G) {
+                        PAR(tid) {
+                            const uint32_t vi = base + tid / G, W = W0 + tid % G;
+                            TL(twa, tid, 0) = 0;
+                            TL(twb, tid, 0) = 0;
+                            TL(tpi, tid, 0) = ~0u;
+                            if (vi < n_ent) {
+                                const uint32_t vj = round ? deep[vi] : vi;
+                                const uint32_t pi = vj < np ? vj : TIE_LIST_CAP - 1u - (vj - np);
+                                const uint32_t ent = plist[pi];
+                                TL(tpi, tid, 0) = pi | (vj < np ? 0u : 0x80000000u) | (vj << 16);
+                                if ((ent >> 24) == 0xFFu) {               // (always, in these two rounds)
+                                    const uint64_t a = (uint64_t)ssa[ent & 0xFFFu], b2 = (uint64_t)ssa[(ent >> 12) & 0xFFFu];
+                                    const uint64_t maxlen = a < n && b2 < n ? n - (a > b2 ? a : b2) : 0;   // corrupt index: settle at once
+                                    const uint64_t l = (uint64_t)KCH_ * (1u + W);
+                                    bool hit = l >= maxlen;               // the shorter suffix ends before this window
+                                    if (!hit) {
+                                        const uint64_t wa = window64<BITS>(P, a + l), wb = window64<BITS>(P, b2 + l);
+                                        TL(twa, tid, 0) = wa;
+                                        TL(twb, tid, 0) = wb;
+                                        hit = wa != wb;
+                                    }
+                                    if (hit) ATOMIC_MIN_U32(&plist[pi], (W << 24) | (ent & 0xFFFFFFu));
                                 }
-                                if (hit) ATOMIC_MIN_U32(&plist[pi], (W << 24) | (ent & 0xFFFFFFu));
                             }
                         }
-                    }
-                    SYNC();
-                    PAR(tid) {
-                        const uint32_t pi = base + tid / TIE_G, W = round * TIE_G + tid % TIE_G;
-                        if (pi < npairs) {
-                            const uint32_t ent = plist[pi], lo = ent & 0xFFFu, hi = (ent >> 12) & 0xFFFu;
-                            if ((ent >> 24) == W) {                       // mine is the first window that differs (or ends)
-                                const uint64_t a = (uint64_t)ssa[lo], b2 = (uint64_t)ssa[hi];
-                                const uint64_t maxlen = a < n && b2 < n ? n - (a > b2 ? a : b2) : 0;
-                                const uint64_t l = (uint64_t)KCH_ * (1u + W);
-                                const uint64_t wa = TL(twa, tid, 0), wb = TL(twb, tid, 0);
-                                uint64_t d = maxlen;
-                                bool lo_first = a > b2;                   // one is a prefix of the other: the shorter first
-                                if (l < maxlen) {
-                                    d = l + (uint32_t)caps_clz64(wa ^ wb) / BITS;
-                                    d = d < maxlen ? d : maxlen;
-                                    lo_first = wa < wb;
+                        SYNC();
+                        PAR(tid) {
+                            const uint32_t W = W0 + tid % G, tp = TL(tpi, tid, 0);
+                            if (tp != ~0u) {
+                                const uint32_t pi = tp & 0xFFFFu, vj = (tp >> 16) & 0x7FFFu;
+                                const uint32_t ent = plist[pi], lo = ent & 0xFFFu, hi = (ent >> 12) & 0xFFFu;
+                                if ((ent >> 24) == W) {                   // mine is the first window that differs (or ends)
+                                    const uint64_t a = (uint64_t)ssa[lo], b2 = (uint64_t)ssa[hi];
+                                    const uint64_t maxlen = a < n && b2 < n ? n - (a > b2 ? a : b2) : 0;
+                                    const uint64_t l = (uint64_t)KCH_ * (1u + W);
+                                    const uint64_t wa = TL(twa, tid, 0), wb = TL(twb, tid, 0);
+                                    uint64_t d = maxlen;
+                                    bool lo_first = a > b2;               // one is a prefix of the other: the shorter first
+                                    if (l < maxlen) {
+                                        d = l + (uint32_t)caps_clz64(wa ^ wb) / BITS;
+                                        d = d < maxlen ? d : maxlen;
+                                        lo_first = wa < wb;
+                                    }
+                                    if (tp & 0x80000000u) {               // an element's own entry: "the other sorts before you" + lcp
+                                        plist[pi] = (lo_first ? 0x81000000u : 0x80000000u) | (uint32_t)d;
+                                    } else {                              // a pair: the same for both members
+                                        tinfo[hi] = (uint16_t)(lo_first ? 0x8000u | (uint32_t)d : 0u);
+                                        tinfo[lo] = (uint16_t)(lo_first ? 0u : 0x8000u | (uint32_t)d);
+                                    }
+                                } else if ((ent >> 24) == 0xFFu && tid % G == 0) {
+                                    if (round) flag[0] = 1;               // deeper than TIE_G1 + TIE_G2 windows: not here
+                                    else {
+                                        const uint32_t q = FETCH_ADD_U32(&pcnt[2], 1u);
+                                        if (q < TIE_DEEP_CAP) deep[q] = (uint16_t)vj;
+                                    }
                                 }
-                                tinfo[hi] = (uint16_t)(lo_first ? 0x8000u | (uint32_t)d : 0u);   // "your partner sorts before you" + lcp
-                                tinfo[lo] = (uint16_t)(lo_first ? 0u : 0x8000u | (uint32_t)d);
-                            } else if ((ent >> 24) == 0xFFu && tid % TIE_G == 0) {
-                                if (round + 1 == ROUNDS) flag[0] = 1;     // deeper than TIE_WINDOWS windows: not here
-                                else pcnt[1 + round] = 1;                 // another round
                             }
                         }
+                        SYNC();
                     }
+                    if (round || pcnt[2] == 0) break;
                 }
-                SYNC();
-                if (round + 1 == ROUNDS || pcnt[1 + round] == 0) break;
             }
         }
-        PHASE_MARK(17);                                        // T: ties of pairs
+        SYNC();
+        PHASE_MARK(17);                                        // T: the listed ties
         PAR(tid) {
             UNROLL
             for (uint32_t k = 0; k < TILE_EPT; ++k) {
                 const uint32_t e = tid + k * TILE_NT;
                 TL(rl, tid, k) = 0;
                 if (e < cnt) {
-                    uint32_t info = TL(rt, tid, k);
-                    const uint32_t ties = info >> 28, slot = TL(rd, tid, k);
+                    const uint32_t info = TL(rt, tid, k);
+                    const uint32_t ties = info >> 28, slot = TL(rd, tid, k), own = (info >> 8) & 0xFFFu;
                     const uint32_t bs = TL(rb, tid, k) & 0xFFFFu, be = TL(rb, tid, k) >> 16;
+                    uint32_t more = 0, best = 0;
                     if (ties == 1u) {
                         const uint32_t v = tinfo[slot];
-                        if (v & 0x8000u) { ++info; TL(rl, tid, k) = v & 0x7FFFu; }
-                    } else if (ties > 1u) {
+                        if (v & 0x8000u) { more = 1; best = v & 0x7FFFu; }
+                    } else if (ties >= 2u && ties <= TIE_LIST_MAX) {
+                        for (uint32_t q = 0; q < ties; ++q) {
+                            const uint32_t r = plist[TIE_LIST_CAP - 1u - (own + q)];       // (anything when the tile has failed)
+                            if (r & 0x01000000u) { ++more; best = (r & 0xFFFFu) > best ? (r & 0xFFFFu) : best; }
+                        }
+                    } else if (ties > TIE_LIST_MAX) {
+                        // (fetching the first windows of four such suffixes at a time was measured: the extra registers cost
+                        // more than the latencies saved, genome-like 3e9 151 -> 162 ms)
                         const uint64_t key = TL(rk, tid, k);
                         const uint64_t sa = (uint64_t)TL(rs, tid, k);
-                        uint32_t best = 0;
                         for (uint32_t j = bs; j < be; ++j) {
                             if (skey[j] == key && j != slot) {
                                 uint32_t l;
                                 const uint32_t c = tie_order_lcp_bounded<BITS>(P, n, (uint64_t)ssa[j], sa, l);   // 1: j sorts before me
                                 if (c == 2u) flag[0] = 1;
-                                if (c == 1u) { ++info; best = l > best ? l : best; }
+                                if (c == 1u) { ++more; best = l > best ? l : best; }
                             }
                         }
-                        TL(rl, tid, k) = best;
                     }
-                    TL(rd, tid, k) = bs + (info & 0xFFu);
+                    TL(rl, tid, k) = best;
+                    TL(rd, tid, k) = bs + (((info & 0xFFu) + more) & 0xFFu);
                 }
             }
         }

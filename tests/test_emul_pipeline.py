@@ -403,6 +403,13 @@ def test_equalised_tile_sort_settles_ties_once(oracle):
             s = rs.randint(0, n - L)
             for d in rs.randint(0, n - L, size=rs.randint(2, 4)):
                 T[d:d + L] = T[s:s + L]
+        for _ in range(n // 20000):                          # frequent keys: 8 .. 13 copies of a 36-mer (the first window behind
+            s = rs.randint(0, n - L)                         # the key tells them apart) and of a 90-mer (it does not)
+            for d in rs.randint(0, n - L, size=rs.randint(8, 14)):
+                T[d:d + 36] = T[s:s + 36]
+            s = rs.randint(0, n - L)
+            for d in rs.randint(0, n - L, size=rs.randint(8, 14)):
+                T[d:d + L] = T[s:s + L]
         s, d = n // 5, n // 2                                 # one tie far deeper than TIE_WINDOWS windows
         T[d:d + 3000] = T[s:s + 3000]
         f(a, 1)
