@@ -1016,10 +1016,16 @@ GLOBAL_FN LAUNCH_BOUNDS(256) queue_all_tiles_kernel(KCTX SegDesc sd, uint32_t* _
 #define CAPS_EQ_ROUNDS 2          /* measured on skewed-Markov tiles (simulation): largest bin, median 243 (linear) -> 50 / 26 / 13 after 1 / 2 / 3 rounds */
 #endif
 constexpr uint32_t EQ_ROUNDS = CAPS_EQ_ROUNDS;
-constexpr uint32_t TIE_G1 = 8;                    // lanes (= windows) per listed tie in the first round,
+#ifndef CAPS_TIE_G1
+#define CAPS_TIE_G1 8
+#endif
+#ifndef CAPS_TIE_LIST_MAX
+#define CAPS_TIE_LIST_MAX 6
+#endif
+constexpr uint32_t TIE_G1 = CAPS_TIE_G1;          // lanes (= windows) per listed tie in the first round,
 constexpr uint32_t TIE_G2 = 64;                   //   per tie that is still equal in the second
 constexpr uint32_t TIE_LIST_CAP = TILE_E / 8;     // list entries per tile (pairs from the bottom, elements' own entries from the top)
-constexpr uint32_t TIE_LIST_MAX = 6;              // an element lists up to this many equal keys (more: it scans them itself)
+constexpr uint32_t TIE_LIST_MAX = CAPS_TIE_LIST_MAX;   // an element lists up to this many equal keys (more: it scans them itself)
 constexpr uint32_t TIE_DEEP_CAP = 64;             // entries that may go to the second round
 constexpr uint32_t EQ_FRAC_BITS = 13;             // position inside a bin; a position is bin * 2^13 + fraction < 2^24 at 2048 bins
 static_assert((uint64_t)TILE_BINS_ << EQ_FRAC_BITS <= (1u << 24), "positions fit 24 bits");
