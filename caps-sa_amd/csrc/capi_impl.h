@@ -277,8 +277,10 @@ int build_multi(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context,
             if (int e = set_device(q->dev)) return e;
             q->send_k = q->template get<uint64_t>(q->info.send_capacity);
             q->send_s = q->template get<idx_t>(q->info.send_capacity);
-            q->recv_k = q->template get<uint64_t>(q->info.capacity);
-            q->recv_s = q->template get<idx_t>(q->info.capacity);
+            if (q->info.exchange) {
+                q->recv_k = q->template get<uint64_t>(q->info.capacity);
+                q->recv_s = q->template get<idx_t>(q->info.capacity);
+            }
             q->dSA = q->template get<idx_t>(q->info.capacity);
             q->dLCP = q->template get<idx_t>(q->info.capacity);
             q->report = q->template get<uint64_t>(W);
@@ -303,7 +305,8 @@ int build_multi(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context,
         }
         // ---- the exchange: block d of rank r's send buffers -> slot r of rank d's receive buffers
         for (auto& q : ranks) q->sh->info(&q->info);              // key_bytes of this attempt
-        for (int r = 0; r < world; ++r) {
+        const bool exchange = ranks[0]->info.exchange != 0;      // (0: every device scattered the whole text and kept its groups)
+        for (int r = 0; exchange && r < world; ++r) {
             MultiRank<idx_t>& src = *ranks[r];
             if (int e = set_device(src.dev)) return e;
             uint64_t so = 0;
@@ -323,7 +326,9 @@ int build_multi(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context,
         for (auto& q : ranks) { if (int e = set_device(q->dev)) return e; q->be->sync(); }
         t2 = clock::now();
         // ---- level B + tile sort of the owned groups; boundary LCPs between the slices
-        for_each_rank(ranks, [&](MultiRank<idx_t>& q) { q.sort_code = q.sh->sort_owned(q.recv_k, q.recv_s, q.dSA, q.dLCP); });
+        for_each_rank(ranks, [&](MultiRank<idx_t>& q) {
+            q.sort_code = exchange ? q.sh->sort_owned(q.recv_k, q.recv_s, q.dSA, q.dLCP) : q.sh->sort_owned(q.send_k, q.send_s, q.dSA, q.dLCP);
+        });
         int worst = 0;
         for (auto& q : ranks) worst = q->sort_code > worst ? q->sort_code : worst;
         if (worst == CAPS_SA_FB_NONE) break;

@@ -2640,9 +2640,13 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) group_scatter_kernel(KCTX
                                                       KT* __restrict__ out_key, idx_t* __restrict__ out_sa,
                                                       uint32_t tile_first, uint32_t tile_stride,
                                                       const uint64_t* __restrict__ region_start, const uint64_t* __restrict__ region_cap,
-                                                      const uint8_t* __restrict__ gshift)
+                                                      const uint8_t* __restrict__ gshift, uint32_t own_lo, uint32_t own_hi)
 {
+    // own_lo .. own_hi: only the elements of these groups are kept (counted, re-ordered, written); stream (g, sx) of a kept group
+    // owns [((g - own_lo) * sub + sx) * slot_cap, + slot_cap).  A rank of a sharded build scatters the WHOLE text and keeps the
+    // groups it owns: no element ever crosses a link (shard.h); one GPU keeps them all (own_lo = 0, own_hi = K1).
     constexpr bool K32 = sizeof(KT) == 4;
+    constexpr uint32_t DROP = ~0u;
     SHARED_ARRAY(uint8_t, scs, K32 ? BUCKET_LDS : 1);
     // region_start != null: stream s = g * sub + sx owns [region_start[s], + region_cap[s]) instead of the uniform
     // [s * slot_cap, + slot_cap) -- groups that share a frequent key get the room of all of them (group_caps_kernel).
@@ -2700,8 +2704,8 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) group_scatter_kernel(KCTX
             UNROLL
             for (uint32_t j = 0; j < 4; ++j) {
                 const uint32_t e = tid + (kk + j) * TILE_NT;
-                uint32_t v = 0;
-                if (e < cnt) v = (lo[j] << 14) | FETCH_ADD_U32(&hist[lo[j]], 1u);
+                uint32_t v = DROP;
+                if (e < cnt && lo[j] >= own_lo && lo[j] < own_hi) v = (lo[j] << 14) | FETCH_ADD_U32(&hist[lo[j]], 1u);
                 TL(pk, tid, kk + j) = v;
             }
         }
@@ -2727,7 +2731,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) group_scatter_kernel(KCTX
         UNROLL
         for (uint32_t k = 0; k < GA_EPT; ++k) {
             const uint32_t v = TL(pk, tid, k), g = v >> 14;
-            TL(pk, tid, k) = (g << 14) | (hist[g] + (v & 0x3FFFu));       // group << 14 | position q in the re-ordered tile
+            if (v != DROP) TL(pk, tid, k) = (g << 14) | (hist[g] + (v & 0x3FFFu));   // group << 14 | position q in the re-ordered tile
         }
         UNROLL
         for (uint32_t j = 0; j < GPT; ++j) {
@@ -2737,7 +2741,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) group_scatter_kernel(KCTX
                 idx_t ob = 0;
                 if (c) {
                     const idx_t old = TL(co, tid, j);
-                    const uint64_t st = (uint64_t)i * sub + sx;
+                    const uint64_t st = (uint64_t)(i - own_lo) * sub + sx;             // (c != 0: a kept group)
                     const uint64_t r0 = region_start ? region_start[st] : st * slot_cap, rc = region_start ? region_cap[st] : slot_cap;
                     ob = (uint64_t)old + c <= rc ? (idx_t)(r0 + old) : NO_SLOT;
                 }
@@ -2745,14 +2749,15 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) group_scatter_kernel(KCTX
             }
         }
     }
-    // ---- write the re-ordered tile, TILE_E positions at a time: perm[q] = group << 14 | element
-    for (uint32_t c0 = 0; c0 < cnt; c0 += TILE_E) {
+    // ---- write the re-ordered tile (its kept elements), TILE_E positions at a time: perm[q] = group << 14 | element
+    const uint32_t kept = hist[TILE_BINS];                              // block-uniform (the scan's total)
+    for (uint32_t c0 = 0; c0 < kept; c0 += TILE_E) {
         PAR(tid) {
             UNROLL
             for (uint32_t k = 0; k < GA_EPT; ++k) {
                 const uint32_t e = tid + k * TILE_NT;
                 const uint32_t v = TL(pk, tid, k), q = v & 0x3FFFu;
-                if (e < cnt && q - c0 < TILE_E) perm[q - c0] = (v & ~0x3FFFu) | e;
+                if (v != DROP && q - c0 < TILE_E) perm[q - c0] = (v & ~0x3FFFu) | e;
             }
         }
         SYNC_LDS();
@@ -2760,7 +2765,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) group_scatter_kernel(KCTX
             UNROLL
             for (uint32_t k = 0; k < TILE_EPT; ++k) {
                 const uint32_t q = c0 + tid + k * TILE_NT;
-                if (q < cnt) {
+                if (q < kept) {
                     const uint32_t v = perm[q - c0], g = v >> 14, e = v & 0x3FFFu;
                     const idx_t ob = obase[g];
                     if (ob != NO_SLOT) {

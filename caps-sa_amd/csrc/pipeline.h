@@ -1072,12 +1072,12 @@ private:
                 CAPS_LAUNCH((group_scatter_kernel<idx_t, BITS, uint32_t>), (uint32_t)((n + GA_E - 1) / GA_E), TILE_NT, be_, (const uint32_t*)pl_.P,
                             packed_words(n, BITS), (uint64_t)0, n, (const uint64_t*)pl_.gkey, K1, (const uint16_t*)pl_.glut,
                             (const uint32_t*)(dflag + 1), SUB, capA, pl_.dcur, reinterpret_cast<uint32_t*>(a_key), a_sa, 0u, 1u,
-                            (const uint64_t*)rstart, (const uint64_t*)rcap, (const uint8_t*)pl_.gshift);
+                            (const uint64_t*)rstart, (const uint64_t*)rcap, (const uint8_t*)pl_.gshift, 0u, K1);
             else if (big_tiles)
                 CAPS_LAUNCH((group_scatter_kernel<idx_t, BITS>), (uint32_t)((n + GA_E - 1) / GA_E), TILE_NT, be_, (const uint32_t*)pl_.P,
                             packed_words(n, BITS), (uint64_t)0, n, (const uint64_t*)pl_.gkey, K1, (const uint16_t*)pl_.glut,
                             (const uint32_t*)(dflag + 1), SUB, capA, pl_.dcur, a_key, a_sa, 0u, 1u, (const uint64_t*)rstart, (const uint64_t*)rcap,
-                            (const uint8_t*)nullptr);
+                            (const uint8_t*)nullptr, 0u, K1);
             else
                 CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, SRC_TEXT, MAP_SPLIT>), n_tilesA, TILE_NT, be_, whole.desc(), (const uint32_t*)pl_.P,
                             packed_words(n, BITS), (uint64_t)0, (const uint64_t*)nullptr, (const idx_t*)nullptr, RunSrc<idx_t>(),

@@ -79,18 +79,27 @@ public:
         // direct path: groups, sub-streams, capacity of a stream region (sample quantiles: +-1.3 % at C3, Poisson on top)
         direct_fb_ = direct_shape(n, p_, m_total_, &PG_, &K1_);
         if (const char* force = std::getenv("CAPS_SA_PATH")) if (std::string(force) == "classic") direct_fb_ = CAPS_SA_FB_FORCED;
+        // Direct path, two ways to shard it.  LOCAL (the default): the text is replicated anyway, so every rank
+        // scatters ALL of it and keeps only the groups it owns -- level A costs every rank a pass over the whole (packed, 0.75 GB
+        // at C3) text but no element ever crosses a link: no data-path collective at all.  EXCHANGE (CAPS_SA_SHARD_EXCHANGE=1):
+        // every rank scatters every world-th tile of the text and the streams are exchanged by one all-to-all -- 8 B per suffix
+        // over xGMI, which costs more than the redundant classification at every world size a node offers.
+        local_ = std::getenv("CAPS_SA_SHARD_EXCHANGE") == nullptr;
+        const int tw = local_ ? 1 : world;                        // ranks that share the tiles of the text
         const uint64_t ga_tiles = (n + GA_E - 1) / GA_E;
-        my_tiles_ = (uint32_t)(ga_tiles > (uint64_t)rank ? (ga_tiles - rank + world - 1) / world : 0);
+        my_tiles_ = local_ ? (uint32_t)ga_tiles : (uint32_t)(ga_tiles > (uint64_t)rank ? (ga_tiles - rank + world - 1) / world : 0);
         my_elems_ = (uint64_t)my_tiles_ * GA_E;
-        if (my_tiles_ && (ga_tiles - 1) % world == (uint64_t)rank) my_elems_ -= ga_tiles * GA_E - n;   // the text's last tile is short
+        if (my_tiles_ && (local_ || (ga_tiles - 1) % world == (uint64_t)rank)) my_elems_ -= ga_tiles * GA_E - n;   // the text's last tile is short
         if (direct_fb_ == CAPS_SA_FB_NONE) {
-            SUB_ = ga_tiles / world >= 32ull * DIRECT_SUB ? DIRECT_SUB : 1u;
+            SUB_ = ga_tiles / tw >= 32ull * DIRECT_SUB ? DIRECT_SUB : 1u;
             if (const char* e = std::getenv("CAPS_SA_DIRECT_SUB")) if (std::atoi(e) >= 1 && (uint32_t)std::atoi(e) <= DIRECT_SUB) SUB_ = (uint32_t)std::atoi(e);
             n_streams_ = K1_ * SUB_;
-            const double mean = (double)n / ((double)n_streams_ * world);
+            own_lo_ = (uint32_t)((uint64_t)rank * K1_ / world);           // rank d owns groups [d K1 / world, (d + 1) K1 / world)
+            own_hi_ = (uint32_t)((uint64_t)(rank + 1) * K1_ / world);
+            const double mean = (double)n / ((double)n_streams_ * tw);
             capA_ = (uint64_t)(mean * 1.10 + 6.0 * std::sqrt(mean) + 2.0 * GA_E / K1_ + 64.0);
             capA_ += capA_ & 1;
-            if (n_streams_ * capA_ + TILE_E >= (uint64_t)std::numeric_limits<idx_t>::max()) direct_fb_ = CAPS_SA_FB_SHAPE;
+            if (n_streams_ * capA_ / (local_ ? world : 1) + TILE_E >= (uint64_t)std::numeric_limits<idx_t>::max()) direct_fb_ = CAPS_SA_FB_SHAPE;
         }
         const uint32_t gseg = std::max<uint32_t>(p_, DIRECT_SUB * std::min<uint32_t>(p_, BUCKET_LDS));
         try {
@@ -101,7 +110,7 @@ public:
             cap_ = std::max<uint64_t>(local_n_, share + share / 4 + 16 * TILE_E);
             if (world == 1) cap_ = local_n_;               // a single rank owns everything: no ownership imbalance to provide for
             if (direct_fb_ == CAPS_SA_FB_NONE) {           // received streams of the owned groups, gaps included
-                const uint64_t own_max = ((uint64_t)K1_ + world - 1) / world * SUB_ * world * capA_;
+                const uint64_t own_max = ((uint64_t)K1_ + world - 1) / world * SUB_ * tw * capA_;
                 cap_ = std::max<uint64_t>(cap_, own_max + TILE_E);
             }
             P_ = get<uint32_t>(text_alloc_words(n));
@@ -150,7 +159,9 @@ public:
         o->ms_phase1 = ms_phase1_; o->ms_pivots = ms_pivots_; o->ms_collate = ms_collate_; o->ms_phase2 = ms_phase2_;
         o->direct_fallback = (uint32_t)direct_fb_; o->direct_groups = K1_; o->direct_sub = SUB_;
         o->n_streams = n_streams_; o->stream_cap = capA_;
-        o->send_capacity = std::max<uint64_t>(local_n_, direct_fb_ == CAPS_SA_FB_NONE ? (uint64_t)n_streams_ * capA_ : 0);
+        o->send_capacity = std::max<uint64_t>(local_n_, direct_fb_ != CAPS_SA_FB_NONE ? 0 :
+                                              local_ ? ((uint64_t)K1_ + world_ - 1) / world_ * SUB_ * capA_ : (uint64_t)n_streams_ * capA_);
+        o->exchange = direct_fb_ == CAPS_SA_FB_NONE && local_ ? 0u : 1u;
         o->ms_scatter = ms_scatter_; o->ms_sort = ms_sort_;
         o->key_bytes = key_bits_ / 8;
         o->ms_level_a = ms_level_a_; o->ms_level_b = ms_level_b_ + ms_count_; o->ms_tile_sort = ms_tile_sort_; o->ms_merge_passes = ms_merge_;
@@ -365,12 +376,12 @@ public:
             const uint32_t code = CAPS_SA_FB_LONG_RUNS;        // every rank sees the same text: all report the same
             be_.h2d(dflag, &code, sizeof code);
         } else {
-            // 32-bit keys (text.h key32_of) whenever the elements are going to cross xGMI: a third fewer bytes on the wire
+            // 32-bit keys (text.h key32_of) whenever the elements are going to cross xGMI (exchange mode): a third fewer bytes on the wire
             // (8 + w -> 4 + w per suffix).  On one GPU they cost more than they save, so a world of one keeps 64
             // bits unless CAPS_SA_KEYS=32 asks (tests); CAPS_SA_KEYS=64 and set_key_bits(64) (the retry after a slot overflow
             // in level B) force 64.
             const char* ke = std::getenv("CAPS_SA_KEYS");
-            const bool want32 = ke ? std::string(ke) == "32" : world_ > 1;
+            const bool want32 = ke ? std::string(ke) == "32" : world_ > 1 && !local_;
             key_bits_ = want32 && !force64_ && bits_ == 2 ? 32u : 64u;
             if (bits_ == 2) scatter_bits<2>(d_send_keys, d_send_sa, dflag);
             else scatter_bits<8>(d_send_keys, d_send_sa, dflag);
@@ -400,11 +411,12 @@ public:
         jlo_ = bound(rank_);
         jhi_ = bound(rank_ + 1);
         G2_ = jhi_ - jlo_;
+        const int srcs = local_ ? 1 : world_;                        // ranks whose streams of an owned group this rank sorts
         for (int d = 0; d < world_; ++d) {
-            send_counts[d] = (uint64_t)(bound(d + 1) - bound(d)) * SUB_ * capA_;
-            recv_counts[d] = (uint64_t)G2_ * SUB_ * capA_;
+            send_counts[d] = local_ ? 0 : (uint64_t)(bound(d + 1) - bound(d)) * SUB_ * capA_;
+            recv_counts[d] = local_ ? 0 : (uint64_t)G2_ * SUB_ * capA_;
         }
-        if ((uint64_t)G2_ * SUB_ * capA_ * world_ > cap_) throw std::runtime_error("receive buffer too small for the owned streams");
+        if ((uint64_t)G2_ * SUB_ * capA_ * srcs > cap_) throw std::runtime_error("receive buffer too small for the owned streams");
         // size of stream x of group g at rank r: the cursors are stream-major (group_scatter_kernel)
         auto sz = [&](int r, uint32_t g, uint32_t x) { return all_reports[r * W + (size_t)x * K1_ + g]; };
         slice_off_ = 0;
@@ -412,7 +424,7 @@ public:
             for (int r = 0; r < world_; ++r)
                 for (uint32_t x = 0; x < SUB_; ++x) slice_off_ += sz(r, g, x);
         // level B's segments: (owned group, source rank, sub-stream), all sub-streams of a group consecutive
-        const uint32_t per_group = (uint32_t)world_ * SUB_;
+        const uint32_t per_group = (uint32_t)srcs * SUB_;
         const size_t nseg = (size_t)G2_ * per_group;
         std::vector<uint64_t> st(nseg + 1, 0), en(nseg + 1, 0);
         recv_total_ = 0;
@@ -420,10 +432,10 @@ public:
         n_tiles2_ = 0;
         const uint64_t block = (uint64_t)G2_ * SUB_ * capA_;                                // elements received from one rank
         for (uint32_t k = 0; k < G2_; ++k)
-            for (int r = 0; r < world_; ++r)
+            for (int r = 0; r < srcs; ++r)
                 for (uint32_t x = 0; x < SUB_; ++x) {
-                    const size_t s = ((size_t)k * world_ + r) * SUB_ + x;
-                    const uint64_t z = sz(r, jlo_ + k, x);
+                    const size_t s = ((size_t)k * srcs + r) * SUB_ + x;
+                    const uint64_t z = sz(local_ ? rank_ : r, jlo_ + k, x);
                     st[s] = (uint64_t)r * block + ((uint64_t)k * SUB_ + x) * capA_;
                     en[s] = st[s] + z;
                     recv_total_ += z;
@@ -440,7 +452,8 @@ public:
         return CAPS_SA_FB_NONE;
     }
 
-    // d_recv_*: the blocks received from ranks 0 .. world-1, in rank order (world 1: the send buffers themselves)
+    // d_recv_*: the blocks received from ranks 0 .. world-1, in rank order (no exchange -- shard_info.exchange = 0 --: the
+    // send buffers themselves)
     // Returns 0, or CAPS_SA_FB_KEY32 when a slot of level B overflowed under 32-bit keys (nothing sorted): the caller makes
     // ALL ranks agree (max over ranks), calls set_key_bits(64) and repeats scatter / exchange / sort.
     int sort_owned(const void* d_recv_keys, const void* d_recv_sa, void* dSA, void* dLCP) override
@@ -519,7 +532,8 @@ private:
     std::vector<KernelClock> clocks_;
     int direct_fb_ = CAPS_SA_FB_SHAPE;
     bool direct_planned_ = false;
-    uint32_t PG_ = 0, K1_ = 0, SUB_ = 1, n_streams_ = 0, my_tiles_ = 0;
+    bool local_ = true;                  // no exchange: every rank scatters the whole text and keeps its groups
+    uint32_t PG_ = 0, K1_ = 0, SUB_ = 1, n_streams_ = 0, my_tiles_ = 0, own_lo_ = 0, own_hi_ = 0;
     uint64_t capA_ = 0, my_elems_ = 0;
     uint32_t key_bits_ = 64;             // width of the keys the last scatter() wrote (32: text.h key32_of)
     bool force64_ = false;               // set_key_bits(64): after a slot overflow under 32-bit keys
@@ -543,17 +557,20 @@ private:
         CAPS_LAUNCH(split_lut_kernel, (SPLIT_LUT_CELLS + 256) / 256, 256, be_, (const uint64_t*)gkey_, K1_ - 1, glut_, dflag + 1);
         be_.memset(dcur_, 0, (size_t)n_streams_ * sizeof(idx_t));
         if (key_bits_ == 32) CAPS_LAUNCH(group_shift_kernel, (K1_ + 255) / 256, 256, be_, (const uint64_t*)gkey_, K1_, gshift_);
+        // local: every tile of the text, the owned groups kept; exchange: every world-th tile, every group kept
+        const uint32_t tile_first = local_ ? 0u : (uint32_t)rank_, tile_stride = local_ ? 1u : (uint32_t)world_;
+        const uint32_t keep_lo = local_ ? own_lo_ : 0u, keep_hi = local_ ? own_hi_ : K1_;
         a0_ = be_.record();
         if (my_tiles_ && key_bits_ == 32)
             CAPS_LAUNCH((group_scatter_kernel<idx_t, BITS, uint32_t>), my_tiles_, TILE_NT, be_, (const uint32_t*)P_, packed_words(n_, BITS),
                         (uint64_t)0, n_, (const uint64_t*)gkey_, K1_, (const uint16_t*)glut_, (const uint32_t*)(dflag + 1), SUB_, capA_, dcur_,
-                        static_cast<uint32_t*>(d_send_keys), static_cast<idx_t*>(d_send_sa), (uint32_t)rank_, (uint32_t)world_,
-                        (const uint64_t*)nullptr, (const uint64_t*)nullptr, (const uint8_t*)gshift_);
+                        static_cast<uint32_t*>(d_send_keys), static_cast<idx_t*>(d_send_sa), tile_first, tile_stride,
+                        (const uint64_t*)nullptr, (const uint64_t*)nullptr, (const uint8_t*)gshift_, keep_lo, keep_hi);
         else if (my_tiles_)
             CAPS_LAUNCH((group_scatter_kernel<idx_t, BITS>), my_tiles_, TILE_NT, be_, (const uint32_t*)P_, packed_words(n_, BITS), (uint64_t)0,
                         n_, (const uint64_t*)gkey_, K1_, (const uint16_t*)glut_, (const uint32_t*)(dflag + 1), SUB_, capA_, dcur_,
-                        static_cast<uint64_t*>(d_send_keys), static_cast<idx_t*>(d_send_sa), (uint32_t)rank_, (uint32_t)world_,
-                        (const uint64_t*)nullptr, (const uint64_t*)nullptr, (const uint8_t*)nullptr);
+                        static_cast<uint64_t*>(d_send_keys), static_cast<idx_t*>(d_send_sa), tile_first, tile_stride,
+                        (const uint64_t*)nullptr, (const uint64_t*)nullptr, (const uint8_t*)nullptr, keep_lo, keep_hi);
         a1_ = be_.record();
     }
 
@@ -567,7 +584,7 @@ private:
         o.pkey = gkey_;
         o.part_off = jlo_;
         o.part_total = K1_;
-        o.sub = (uint32_t)world_ * SUB_;
+        o.sub = (local_ ? 1u : (uint32_t)world_) * SUB_;
         o.seg_ends = true;
         o.in_key = static_cast<const uint64_t*>(d_recv_keys);
         o.in_sa = d_recv_sa;

@@ -158,12 +158,14 @@ def build_sharded(lib, T: torch.Tensor, p: int = 0, idx_bits: int | None = None,
                 break
             sc = [int(x) for x in sc]
             rc = [int(x) for x in rc]
-            kb = sh.info()["key_bytes"]                           # 4: 32-bit keys travel (2-bit texts, world > 1), else 8
+            now = sh.info()
+            kb = now["key_bytes"]                                 # 4: 32-bit keys travel (2-bit texts, exchange mode), else 8
             send_k = B.send_k.view(torch.int32) if kb == 4 else B.send_k
             recv_k = B.recv_k.view(torch.int32) if kb == 4 else B.recv_k
             t0 = time.perf_counter()
-            if world == 1:
-                recv_k, recv_s = send_k, B.send_s                 # nothing to exchange: level B reads the streams in place
+            if world == 1 or not now["exchange"]:
+                recv_k, recv_s = send_k, B.send_s                 # nothing travels: every rank scattered the whole text and kept
+                                                                  # its own groups; level B reads the streams in place
             else:
                 recv_s = B.recv_s
                 plan = exchange_plan(rc, sc, max(kb, idx_bits // 8), dev)
@@ -175,7 +177,7 @@ def build_sharded(lib, T: torch.Tensor, p: int = 0, idx_bits: int | None = None,
             lap("exchange")
             mine = sh.sort_owned(recv_k.data_ptr(), recv_s.data_ptr(), B.SA.data_ptr(), B.LCP.data_ptr())
             worst = torch.tensor([mine], dtype=torch.int64, device=dev)
-            if world > 1:
+            if world > 1 and now["exchange"]:                     # (32-bit keys only exist in exchange mode)
                 dist.all_reduce(worst, op=dist.ReduceOp.MAX)      # a slot overflow on ANY rank sends every rank round again
             lap("sort")
             if int(worst.item()) != 0:
@@ -190,7 +192,7 @@ def build_sharded(lib, T: torch.Tensor, p: int = 0, idx_bits: int | None = None,
             info["ms_exchange"] = ms_exchange
             info["path"] = "direct"
             info["key_retry"] = attempt
-            info["exchange_elems_sent"] = sum(sc) - sc[rank]
+            info["exchange_elems_sent"] = sum(sc) - sc[rank] if info["exchange"] else 0
             if prof is not None:
                 info["host_profile_ms"] = prof
             return B.SA[:total], B.LCP[:total], info["slice_off"], info
@@ -238,6 +240,7 @@ def build_sharded(lib, T: torch.Tensor, p: int = 0, idx_bits: int | None = None,
         info = _finish(sh, LCP, dev, rank, world)
         lap("boundary")
         info["ms_exchange"] = ms_exchange
+        info["exchange"] = 1
         info["path"] = "samplesort"
         info["direct_fallback"] = inf["direct_fallback"]
         info["exchange_elems_sent"] = sum(sc) - sc[rank]
@@ -343,7 +346,9 @@ def bench_main(args, rank: int, local_rank: int, world: int):
             "rank0_ms": {k_: info[k_] for k_ in keys},
             "exchange": {"ms": ms_x, "bytes_sent_per_rank": sent, "GBps_per_rank": (sent / 1e9) / (ms_x * 1e-3) if ms_x > 0 and sent else None,
                          "key_bytes": info.get("key_bytes", 8) if direct else 8, "key_retries": sum(i.get("key_retry", 0) for i in infos),
-                         "note": "keys and indices in two all-to-all calls; region gaps (10 %) travel too; 32-bit keys on 2-bit texts"},
+                         "note": ("no data-path collective: every rank scatters the whole (replicated) text and keeps the groups it owns"
+                                  if direct and not info.get("exchange", 1) else
+                                  "keys and indices in two all-to-all calls; region gaps (10 %) travel too; 32-bit keys on 2-bit texts")},
             "rank0_host_profile_ms": info.get("host_profile_ms"),
             "roofline": roof,
             "verify_errors": errs,

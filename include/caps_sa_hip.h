@@ -247,7 +247,9 @@ typedef struct caps_sa_shard_info {
     uint32_t slot_splits, slot_splits_redone;
     uint32_t key_bytes;            /* bytes per key in the send / receive buffers of the last shard_scatter: 8, or 4 (32-bit keys,
                                       csrc/text.h key32_of: what travels when world > 1 on 2-bit texts) */
-    uint32_t reserved_;
+    uint32_t exchange;             /* 1: the streams shard_scatter wrote must be exchanged (all-to-all by the counts of shard_plan)
+                                      before shard_sort; 0 (the default for the direct path): nothing travels -- every rank
+                                      scattered the whole text and kept its own groups; shard_sort reads the send buffers */
 } caps_sa_shard_info;
 
 int caps_sa_hip_shard_create(const void* dT, uint64_t n, uint64_t subproblem_count, int idx_bytes, int rank, int world,

@@ -33,9 +33,19 @@ def build_world(lib, T: torch.Tensor, p: int, world: int, idx_bits: int = 32):
                 break
             kbs = {s.info()["key_bytes"] for s in shards}
             assert len(kbs) == 1, f"ranks disagree on the key width: {kbs}"
-            kt = torch.int32 if kbs == {4} else torch.int64           # 32-bit keys travel when world > 1 on a 2-bit text
+            kt = torch.int32 if kbs == {4} else torch.int64           # 32-bit keys travel in exchange mode on a 2-bit text
+            exchange = {s.info()["exchange"] for s in shards}
+            assert len(exchange) == 1
             sc = [[int(x) for x in a] for _, a, _ in plans]
             rc = [[int(x) for x in b] for _, _, b in plans]
+            if exchange == {0}:                                       # nothing travels: every rank sorts what it scattered
+                assert all(sum(a) == 0 for a in sc) and all(sum(b) == 0 for b in rc)
+                worst = max(s.sort_owned(B.send_k.data_ptr(), B.send_s.data_ptr(), B.SA.data_ptr(), B.LCP.data_ptr())
+                            for s, B in zip(shards, bufs))
+                assert worst == 0 and kt == torch.int64
+                build_world.last_key_bytes, build_world.last_key_retry, build_world.last_exchange = 8, 0, 0
+                return _stitch(shards, bufs, n, sync, "direct")
+            build_world.last_exchange = 1
             for r in range(world):
                 assert [sc[q][r] for q in range(world)] == rc[r], "send/receive counts disagree"
                 ro = 0

@@ -11,18 +11,24 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,port,a2a_limit,small,path", [
-    (2, 29531, 0, 0, "auto"), (3, 29532, 0, 0, "auto"), (2, 29534, 4096, 0, "auto"), (4, 29535, 0, 0, "auto"),
-    (2, 29536, 0, 1, "auto"), (3, 29537, 4096, 1, "auto"), (2, 29538, 0, 0, "classic"), (2, 29539, 0, 1, "classic")])
-def test_sharded_build_matches_oracle(world, port, a2a_limit, small, path):
+@pytest.mark.parametrize("world,port,a2a_limit,small,path,exchange", [
+    (2, 29531, 0, 0, "auto", 0), (3, 29532, 0, 0, "auto", 0), (2, 29534, 4096, 0, "auto", 1), (4, 29535, 0, 0, "auto", 0),
+    (2, 29536, 0, 1, "auto", 1), (3, 29537, 4096, 1, "auto", 0), (3, 29533, 0, 1, "auto", 1), (2, 29538, 0, 0, "classic", 0),
+    (2, 29539, 0, 1, "classic", 0)])
+def test_sharded_build_matches_oracle(world, port, a2a_limit, small, path, exchange):
     """a2a_limit > 0: exchange in rounds of that many bytes per peer (the path taken on GPUs when a block exceeds
     RCCL's safe message size).  small: the kernels' 256-element-tile build (more tiles, groups and streams per case:
-    the direct path on every case that is not tiny).  path: CAPS_SA_PATH (classic = samplesort path on every case)."""
+    the direct path on every case that is not tiny).  path: CAPS_SA_PATH (classic = samplesort path on every case).
+    exchange: 0 = the direct path's default, every rank scatters the whole text and keeps its own groups (no data-path
+    collective); 1 = CAPS_SA_SHARD_EXCHANGE: every rank scatters its share of the tiles, one all-to-all of the streams."""
     from emul_util import emul, emul_small
     (emul_small if small else emul)()   # build the emulation library once, before the ranks race for it
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py")]
     env = dict(os.environ, CAPS_SA_PATH=path, CAPS_EMUL_SMALL=str(small))
+    env.pop("CAPS_SA_SHARD_EXCHANGE", None)
+    if exchange:
+        env["CAPS_SA_SHARD_EXCHANGE"] = "1"
     if a2a_limit:
         env["CAPS_A2A_MAX_BYTES"] = str(a2a_limit)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
@@ -33,8 +39,12 @@ def test_sharded_build_matches_oracle(world, port, a2a_limit, small, path):
     else:
         assert r.stdout.count("path=direct") >= (4 if small else 3), r.stdout
         assert "fb=3" in r.stdout                      # the long run: CAPS_SA_FB_LONG_RUNS, agreed on by every rank
-        assert "keys=4 retry=0" in r.stdout            # 32-bit keys crossed the (gloo) wire ...
-        assert "keys=8 retry=1" in r.stdout            # ... and a slot overflow under them sent every rank round again with 64
+        if exchange:
+            assert "keys=4 retry=0 exch=1" in r.stdout     # 32-bit keys crossed the (gloo) wire ...
+            assert "keys=8 retry=1 exch=1" in r.stdout     # ... and a slot overflow under them sent every rank round again with 64
+        else:
+            assert "path=direct fb=0 keys=8 retry=0 exch=0" in r.stdout and "path=direct fb=0 keys=4" not in r.stdout
+            assert "path=direct" in r.stdout and "exch=1 " not in "".join(l for l in r.stdout.splitlines() if "path=direct" in l)
 
 
 def test_imbalanced_ownership_fails_on_every_rank_together():

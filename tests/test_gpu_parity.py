@@ -451,14 +451,22 @@ def test_host_entry_point_cache_and_pinned_results(L, oracle):
     assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo)
 
 
-@pytest.mark.parametrize("world,n,p,bits", [(2, 20_000_001, 8000, 32), (3, 6_000_000, 500, 32), (4, 9_000_001, 0, 64),
-                                            (8, 40_000_000, 8000, 32)])
-def test_shard_kernels_at_world_sizes_above_one_loopback(L, sa_path, world, n, p, bits):
+@pytest.mark.parametrize("world,n,p,bits,exchange", [(2, 20_000_001, 8000, 32, 0), (2, 20_000_001, 8000, 32, 1), (3, 6_000_000, 500, 32, 0),
+                                                     (4, 9_000_001, 0, 64, 0), (4, 9_000_001, 0, 64, 1), (8, 40_000_000, 8000, 32, 0),
+                                                     (8, 40_000_000, 8000, 32, 1)])
+def test_shard_kernels_at_world_sizes_above_one_loopback(L, sa_path, world, n, p, bits, exchange, monkeypatch):
     """Every rank's shard on the one GPU of the box, collectives replaced by copies
     (tests/loopback_world.py): result == the single-GPU build, bit for bit.  Both constructions; world 3 carries a long
-    run, on which every rank of the direct path must fall back together."""
+    run, on which every rank of the direct path must fall back together.  exchange = 0: the direct path's default (every rank
+    scatters the whole text and keeps its groups, nothing travels); 1: CAPS_SA_SHARD_EXCHANGE (tiles shared, streams exchanged)."""
     import torch
     from loopback_world import build_world
+    if exchange and sa_path == "classic":
+        pytest.skip("the samplesort path always exchanges")
+    if exchange:
+        monkeypatch.setenv("CAPS_SA_SHARD_EXCHANGE", "1")
+    else:
+        monkeypatch.delenv("CAPS_SA_SHARD_EXCHANGE", raising=False)
     g = torch.Generator(device="cuda")
     g.manual_seed(world * 1000 + 7)
     lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device="cuda")
@@ -475,15 +483,16 @@ def test_shard_kernels_at_world_sizes_above_one_loopback(L, sa_path, world, n, p
     assert torch.equal(SA, SA1)
     assert torch.equal(LCP, LCP1)
     assert build_world.last_path == ("direct" if sa_path != "classic" and world != 3 else "samplesort")
-    if build_world.last_path == "direct":                     # random DNA: 32-bit keys cross the wire, no slot overflows
-        assert (build_world.last_key_bytes, build_world.last_key_retry) == (4, 0)
+    if build_world.last_path == "direct":                     # exchange mode on random DNA: 32-bit keys cross the wire, no slot overflows
+        assert (build_world.last_exchange, build_world.last_key_bytes, build_world.last_key_retry) == ((1, 4, 0) if exchange else (0, 8, 0))
 
 
-def test_shard_key_width_retry_on_skewed_keys_loopback(L):
-    """Skewed base frequencies: level B's slots overflow under 32-bit keys, shard_sort says CAPS_SA_FB_KEY32 on some rank and
-    every rank goes round again with 64-bit keys (tests/loopback_world.py asserts the code and that it happens once)."""
+def test_shard_key_width_retry_on_skewed_keys_loopback(L, monkeypatch):
+    """Exchange mode, skewed base frequencies: level B's slots overflow under 32-bit keys, shard_sort says CAPS_SA_FB_KEY32 on
+    some rank and every rank goes round again with 64-bit keys (tests/loopback_world.py asserts the code and that it happens once)."""
     import torch
     from loopback_world import build_world
+    monkeypatch.setenv("CAPS_SA_SHARD_EXCHANGE", "1")
     n, p, world = 24_000_000, 3000, 4
     g = torch.Generator(device="cuda")
     g.manual_seed(99)

@@ -91,9 +91,55 @@ def c4_text():
     return T
 
 
-def test_c4_sharded_direct_path_for_the_last_rank(L, c4_text):
+def test_c4_local_direct_path_for_the_last_rank(L, c4_text, monkeypatch):
+    """The sharded direct path as it runs by default (no exchange) at BASELINE config 4's size: rank 7 of 8 scatters the whole
+    8 Gi text, keeps the last eighth of the groups and sorts them; its slice (all positions, a third of them >= 2^32) is checked
+    by the exact slice verifier.  The slices' offsets need every rank's group sizes: ranks 0 .. 6 only run their level A."""
     import torch
     from caps_sa_dist import ShardBuffers
+    monkeypatch.delenv("CAPS_SA_SHARD_EXCHANGE", raising=False)
+    T, n, world, p = c4_text, C4_N, 8, 8000
+    dev = T.device
+    reports, bufs, keep = [], None, None
+    for r in range(world):
+        sh = L.shard(T.data_ptr(), n, p, 64, r, world, 0)
+        inf = sh.info()
+        assert inf["direct_fallback"] == 0 and inf["exchange"] == 0 and inf["idx_bytes"] == 8
+        if bufs is None:
+            bufs = ShardBuffers(inf, dev, torch.int64)
+        sh.scatter(bufs.send_k.data_ptr(), bufs.send_s.data_ptr(), bufs.report.data_ptr())
+        assert sh.info()["level_a_elems"] == n and sh.info()["key_bytes"] == 8
+        rep = bufs.report.cpu().numpy().astype(np.uint64)
+        assert rep[-2] == 0 and rep[-1] == 0, "pivot ties / overflow on random DNA"
+        reports.append(rep)
+        if r == world - 1:
+            keep = sh
+        else:
+            sh.close()
+    try:
+        all_rep = np.stack(reports)
+        assert int(all_rep[:, :-2].sum()) == n                    # every suffix kept by exactly one rank
+        code, sc, rc = keep.plan(all_rep)
+        assert code == 0 and int(sc.sum()) == 0 and int(rc.sum()) == 0
+        assert keep.sort_owned(bufs.send_k.data_ptr(), bufs.send_s.data_ptr(), bufs.SA.data_ptr(), bufs.LCP.data_ptr()) == 0
+        info = keep.info()
+        cnt = info["recv_total"]
+        assert info["slice_off"] + cnt == n and abs(cnt - n // world) < n // world // 20
+        assert int((bufs.SA[:cnt] >= TWO32).sum().item()) > cnt // 3
+        errs = L.verify_slice_device(T.data_ptr(), n, bufs.SA.data_ptr(), bufs.LCP.data_ptr(), cnt, False, idx_bits=64)
+        assert errs == 0, f"{errs} violations in rank {world - 1}'s slice"
+    finally:
+        keep.close()
+        del bufs
+        torch.cuda.empty_cache()
+
+
+def test_c4_sharded_direct_path_for_the_last_rank(L, c4_text, monkeypatch):
+    """The same in exchange mode (CAPS_SA_SHARD_EXCHANGE=1): every rank's level A over every 8th tile, 32-bit keys, the blocks
+    for rank 7 copied as the all-to-all would."""
+    import torch
+    from caps_sa_dist import ShardBuffers
+    monkeypatch.setenv("CAPS_SA_SHARD_EXCHANGE", "1")
     T, n, world, p = c4_text, C4_N, 8, 8000
     dev = T.device
     target = world - 1
