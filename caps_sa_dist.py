@@ -336,13 +336,18 @@ def bench_main(args, rank: int, local_rank: int, world: int):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": f"u{idx_bits}",
             "data": "synthetic",
             "config": {"workload": desc, "n": n, "subproblems": info["p"], "bits_per_char": info["bits_per_char"],
-                       "construction": "direct (same pivots on every rank, one scatter of every world-th tile into groups, ONE "
-                                       "all-to-all of (key, sa), per-group sort)" if direct
-                                       else f"samplesort (fallback reason {info.get('direct_fallback')})",
+                       "construction": ("direct, no exchange (same pivots on every rank; every rank scatters the whole replicated text "
+                                        "into groups and keeps the ones it owns; per-group sort)" if direct and not info.get("exchange", 1)
+                                        else "direct (same pivots on every rank, one scatter of every world-th tile into groups, ONE "
+                                        "all-to-all of (key, sa), per-group sort)" if direct
+                                        else f"samplesort (fallback reason {info.get('direct_fallback')})"),
                        "groups": info["direct_groups"], "streams_per_group": info["direct_sub"],
                        "workspace": "preallocated",
-                       "parallelism": f"{world} GPUs, one process each: text replicated, tiles of the text and groups of partitions "
-                                      "sharded, one RCCL all-to-all over xGMI"},
+                       "parallelism": (f"{world} GPUs, one process each: text replicated, groups of partitions (slices of the suffix "
+                                       "array) sharded; no data-path collective, only the ranks' reports, the agreement and the "
+                                       "boundary LCPs cross RCCL" if direct and not info.get("exchange", 1) else
+                                       f"{world} GPUs, one process each: text replicated, tiles of the text and groups of partitions "
+                                       "sharded, one RCCL all-to-all over xGMI")},
             "rank0_ms": {k_: info[k_] for k_ in keys},
             "exchange": {"ms": ms_x, "bytes_sent_per_rank": sent, "GBps_per_rank": (sent / 1e9) / (ms_x * 1e-3) if ms_x > 0 and sent else None,
                          "key_bytes": info.get("key_bytes", 8) if direct else 8, "key_retries": sum(i.get("key_retry", 0) for i in infos),

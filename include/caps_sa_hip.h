@@ -269,21 +269,26 @@ int caps_sa_hip_shard_phase2(caps_sa_shard* s, const void* d_recv_keys, const vo
  * Direct path of a sharded build (what Builder::run_direct does on one GPU; no sort_subarrays, no locate_pivots):
  *
  *   shard_create -> shard_scatter -> [all_gather of the reports] -> shard_plan
- *   -> [all-to-all of the (key, sa) blocks; world 1: none] -> shard_sort -> [all_gather last SA] -> shard_fix_first_lcp
+ *   -> [only if shard_info.exchange: all-to-all of the (key, sa) blocks] -> shard_sort -> [all_gather last SA] -> shard_fix_first_lcp
  *
  * shard_scatter: packs the text, derives the pivots (every rank the same ones, from the same samples of the text) and
- * distributes the suffixes of every world-th tile of the text into stream regions of d_send_keys (u64[send_capacity]) /
- * d_send_sa (idx[send_capacity]); the block for rank d is contiguous.  d_report: u64[n_streams + 2], this rank's stream
- * sizes and flags.  shard_plan: all_reports = HOST u64[world][n_streams + 2]; returns 0 and the elements to send to /
- * receive from every rank (gaps of the regions included), or a positive CAPS_SA_FB_* code -- the same on every rank --
- * when the text cannot be split by keys alone: the ranks then run the samplesort sequence above (shard_phase1 ...).
- * shard_sort: d_recv_* = the received blocks in rank order; dSA / dLCP: idx[capacity] out, recv_total entries valid.
+ * distributes suffixes into stream regions of d_send_keys (u64[send_capacity]) / d_send_sa (idx[send_capacity]).
+ *   Default (shard_info.exchange = 0): the suffixes of the WHOLE text that belong to the groups this rank owns -- the text is
+ *   replicated, so no element has to cross a link; shard_plan then returns all-zero counts and shard_sort reads the send
+ *   buffers (d_recv_* = d_send_*).
+ *   CAPS_SA_SHARD_EXCHANGE=1 (exchange = 1): the suffixes of every world-th tile of the text, all groups; the block for rank d
+ *   is contiguous, shard_plan returns the elements to send to / receive from every rank (gaps of the regions included) and
+ *   shard_sort takes the received blocks in rank order.
+ * d_report: u64[n_streams + 2], this rank's stream sizes and flags.  shard_plan: all_reports = HOST u64[world][n_streams + 2];
+ * returns 0, or a positive CAPS_SA_FB_* code -- the same on every rank -- when the text cannot be split by keys alone: the
+ * ranks then run the samplesort sequence above (shard_phase1 ...).  shard_sort: dSA / dLCP: idx[capacity] out, recv_total
+ * entries valid.
  */
 int caps_sa_hip_shard_scatter(caps_sa_shard* s, void* d_send_keys, void* d_send_sa, void* d_report);
 int caps_sa_hip_shard_plan(caps_sa_shard* s, const uint64_t* all_reports, uint64_t* send_counts, uint64_t* recv_counts);
 int caps_sa_hip_shard_sort(caps_sa_shard* s, const void* d_recv_keys, const void* d_recv_sa, void* dSA, void* dLCP);
-/* Key width: shard_scatter writes 32-bit keys (shard_info.key_bytes = 4: d_send_keys / d_recv_keys are then u32 arrays) when
- * the world has more than one rank and the text packs to 2 bits -- a third fewer bytes cross xGMI.  shard_sort then returns
+/* Key width (exchange = 1 only): shard_scatter writes 32-bit keys (shard_info.key_bytes = 4: d_send_keys / d_recv_keys are then u32
+ * arrays) when the world has more than one rank and the text packs to 2 bits -- a third fewer bytes cross xGMI.  shard_sort then returns
  * CAPS_SA_FB_KEY32 (> 0) when a bucket slot overflowed (skewed keys the pivots did not reveal); the ranks take the maximum
  * of their codes, and if it is not 0 every rank calls shard_set_key_bits(s, 64) and repeats scatter / exchange / sort. */
 int caps_sa_hip_shard_set_key_bits(caps_sa_shard* s, int bits);
