@@ -2680,15 +2680,28 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) group_scatter_kernel(KCTX
     }
     SYNC();
     // ---- classify: group = #{splitters < key} (LUT cell -> a few candidates -> branch-free search), rank inside (tile, group)
+    // 2-bit codes: a thread classifies GA_EPT CONSECUTIVE positions (when a tile starts on a word boundary: always, GA_E is a
+    // multiple of the 16 bases of a word) -- their keys are one 96-bit window of the staged text shifted along, three LDS reads
+    // for all of them instead of three each; byte codes keep one position per thread and round
+    const bool RUN_OF_POS = BITS == 2 && GA_EPT == CPW && pos0 % CPW == 0;      // block-uniform
     PAR(tid) {
+        uint64_t wA = 0;
+        uint32_t wC = 0;
+        if (RUN_OF_POS) {
+            const uint32_t wi = (uint32_t)(pos0 / CPW - w0) + tid;          // the word of my first position
+            wA = ((uint64_t)twin[wi] << 32) | twin[wi + 1];
+            wC = twin[wi + 2];
+        }
         UNROLL
         for (uint32_t kk = 0; kk < GA_EPT; kk += 4) {
             uint64_t key[4];
             uint32_t lo[4], hi[4];
             UNROLL
             for (uint32_t j = 0; j < 4; ++j) {
-                const uint32_t e = tid + (kk + j) * TILE_NT;
-                key[j] = e < cnt ? window64<BITS>(twin, pos0 + e - w0 * CPW) : 0;
+                const uint32_t e = RUN_OF_POS ? tid * GA_EPT + kk + j : tid + (kk + j) * TILE_NT;
+                const uint32_t sh = BITS * (kk + j);                        // < 32
+                key[j] = e >= cnt ? 0 : !RUN_OF_POS ? window64<BITS>(twin, pos0 + e - w0 * CPW)
+                                                    : sh ? (wA << sh) | (uint64_t)(wC >> (32u - sh)) : wA;
                 const uint32_t cell = (uint32_t)(key[j] >> (64 - SPLIT_LUT_BITS));
                 lo[j] = slut[cell];
                 hi[j] = slut[cell + 1];
@@ -2703,7 +2716,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) group_scatter_kernel(KCTX
             }
             UNROLL
             for (uint32_t j = 0; j < 4; ++j) {
-                const uint32_t e = tid + (kk + j) * TILE_NT;
+                const uint32_t e = RUN_OF_POS ? tid * GA_EPT + kk + j : tid + (kk + j) * TILE_NT;
                 uint32_t v = DROP;
                 if (e < cnt && lo[j] >= own_lo && lo[j] < own_hi) v = (lo[j] << 14) | FETCH_ADD_U32(&hist[lo[j]], 1u);
                 TL(pk, tid, kk + j) = v;
@@ -2755,7 +2768,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) group_scatter_kernel(KCTX
         PAR(tid) {
             UNROLL
             for (uint32_t k = 0; k < GA_EPT; ++k) {
-                const uint32_t e = tid + k * TILE_NT;
+                const uint32_t e = RUN_OF_POS ? tid * GA_EPT + k : tid + k * TILE_NT;
                 const uint32_t v = TL(pk, tid, k), q = v & 0x3FFFu;
                 if (v != DROP && q - c0 < TILE_E) perm[q - c0] = (v & ~0x3FFFu) | e;
             }
