@@ -120,9 +120,11 @@ template <int BITS> HD bool periodic128(uint64_t hi, uint64_t lo, uint32_t d)
 #define CAPS_RUN_ENTER 3
 #endif
 constexpr uint32_t RUN_ENTER = CAPS_RUN_ENTER;
+// in_run: the caller knows that the chars already seen equal are themselves periodic (an equal KEY with a period: G^32,
+// (AC)^16 -- the suffixes of an N-block, of a tandem array): the plain windows are skipped, the table is asked at once.
 template <int BITS, bool RUNS>
 HD uint64_t deep_scan(const uint32_t* __restrict__ P, uint64_t n, uint64_t a, uint64_t b, uint64_t l, uint64_t maxlen,
-                      uint64_t& wa, uint64_t& wb)
+                      uint64_t& wa, uint64_t& wb, bool in_run = false)
 {
     constexpr uint32_t KCH = TextTraits<BITS>::KCH;
 #ifdef CAPS_NO_RUN_TABLE       /* measurement variant: every comparator is the plain window loop */
@@ -138,7 +140,7 @@ HD uint64_t deep_scan(const uint32_t* __restrict__ P, uint64_t n, uint64_t a, ui
         }
         return maxlen;
     }
-    for (uint32_t k = 0; k < RUN_ENTER && l < maxlen; ++k, l += KCH) {
+    for (uint32_t k = 0; k < (in_run ? 0u : RUN_ENTER) && l < maxlen; ++k, l += KCH) {
         wa = window64<BITS>(P, a + l);
         wb = window64<BITS>(P, b + l);
         if (wa != wb) return l + (uint32_t)caps_clz64(wa ^ wb) / BITS;
@@ -146,18 +148,21 @@ HD uint64_t deep_scan(const uint32_t* __restrict__ P, uint64_t n, uint64_t a, ui
     if (l >= maxlen) return maxlen;
     const uint64_t* __restrict__ R = run_table(P, n);
     while (l < maxlen) {
+        // the four windows and the two table entries of a step are fetched TOGETHER: one memory latency per step instead of
+        // three (a merge over the suffixes of an N-block makes ~20 such comparisons per element and pass)
         const uint64_t x = a + l, y = b + l;
-        wa = window64<BITS>(P, x);
-        wb = window64<BITS>(P, y);
+        const uint64_t wa0 = window64<BITS>(P, x), wb0 = window64<BITS>(P, y);
+        const uint64_t wa1 = window64<BITS>(P, x + KCH), wb1 = window64<BITS>(P, y + KCH);
+        const uint64_t rx = R[(x + KCH - 1) / KCH], ry = R[(y + KCH - 1) / KCH];
+        wa = wa0;
+        wb = wb0;
         if (wa != wb) return l + (uint32_t)caps_clz64(wa ^ wb) / BITS;
         const uint64_t hi = wa;
-        wa = window64<BITS>(P, x + KCH);
-        wb = window64<BITS>(P, y + KCH);
+        wa = wa1;
+        wb = wb1;
         if (wa != wb) return l + KCH + (uint32_t)caps_clz64(wa ^ wb) / BITS;
         uint64_t step = 2 * KCH;
-        const uint64_t rx = R[(x + KCH - 1) / KCH];
         if (rx) {
-            const uint64_t ry = R[(y + KCH - 1) / KCH];
             const uint32_t d = (uint32_t)(rx >> 56);
             if ((uint32_t)(ry >> 56) == d && periodic128<BITS>(hi, wa, d)) {
                 const uint64_t ex = (rx & RUN_POS_MASK) - x, ey = (ry & RUN_POS_MASK) - y;
@@ -173,12 +178,12 @@ HD uint64_t deep_scan(const uint32_t* __restrict__ P, uint64_t n, uint64_t a, ui
 // (from is a multiple of KCH or anything <= the true lcp).  Exact, clamped to the
 // length of the shorter suffix.
 template <int BITS, bool RUNS = true>
-HD uint64_t deep_lcp(const uint32_t* __restrict__ P, uint64_t n, uint64_t a, uint64_t b, uint64_t from)
+HD uint64_t deep_lcp(const uint32_t* __restrict__ P, uint64_t n, uint64_t a, uint64_t b, uint64_t from, bool in_run = false)
 {
     if (a >= n || b >= n) return 0;              // corrupt index: do not scan
     const uint64_t maxlen = n - (a > b ? a : b);
     uint64_t wa, wb;
-    const uint64_t l = deep_scan<BITS, RUNS>(P, n, a, b, from, maxlen, wa, wb);
+    const uint64_t l = deep_scan<BITS, RUNS>(P, n, a, b, from, maxlen, wa, wb, in_run);
     return l < maxlen ? l : maxlen;
 }
 
@@ -193,7 +198,7 @@ HD uint64_t pair_lcp(const uint32_t* __restrict__ P, uint64_t n, uint64_t ka, ui
         const uint64_t l = (uint32_t)caps_clz64(x) / BITS;
         return l < maxlen ? l : maxlen;
     }
-    return deep_lcp<BITS, RUNS>(P, n, a, b, TextTraits<BITS>::KCH);
+    return deep_lcp<BITS, RUNS>(P, n, a, b, TextTraits<BITS>::KCH, RUNS && block_period<BITS>(ka) != 0);
 }
 
 // ---- 32-bit keys (direct path on 2-bit texts, pipeline.h) ---------------------------------------------------------
@@ -221,12 +226,12 @@ HD uint64_t pair_lcp32(const uint32_t* __restrict__ P, uint64_t n, uint32_t ka, 
 // inside the merge kernels would force the registers that hold the prefetched next tile to
 // be spilled for the whole rank phase.
 template <int BITS, bool RUNS = true>
-HD bool suffix_less_tie(const uint32_t* __restrict__ P, uint64_t n, uint64_t a, uint64_t b)
+HD bool suffix_less_tie(const uint32_t* __restrict__ P, uint64_t n, uint64_t a, uint64_t b, bool in_run = false)
 {
     if (a >= n || b >= n) return a > b;          // never loop on a corrupt index (keeps a bad input from hanging the GPU)
     const uint64_t maxlen = n - (a > b ? a : b);
     uint64_t wa = 0, wb = 0;
-    const uint64_t l = deep_scan<BITS, RUNS>(P, n, a, b, TextTraits<BITS>::KCH, maxlen, wa, wb);
+    const uint64_t l = deep_scan<BITS, RUNS>(P, n, a, b, TextTraits<BITS>::KCH, maxlen, wa, wb, in_run);
     if (l < maxlen) return wa < wb;              // the windows that hold the first differing char
     return a > b;                                // one is a prefix of the other: the shorter first
 }
@@ -296,7 +301,7 @@ HD bool suffix_less(const uint32_t* __restrict__ P, uint64_t n, uint64_t ka, uin
 {
     if (ka != kb) return ka < kb;
     if (a == b) return false;
-    return suffix_less_tie<BITS, RUNS>(P, n, a, b);
+    return suffix_less_tie<BITS, RUNS>(P, n, a, b, RUNS && block_period<BITS>(ka) != 0);
 }
 
 }  // namespace caps
