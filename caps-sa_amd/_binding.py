@@ -90,6 +90,7 @@ class ShardInfo(ctypes.Structure):
         ("level_a_elems", ctypes.c_uint64),
         ("slot_splits", ctypes.c_uint32), ("slot_splits_redone", ctypes.c_uint32),
         ("key_bytes", ctypes.c_uint32), ("exchange", ctypes.c_uint32),
+        ("direct_quantile", ctypes.c_uint32), ("reserved_", ctypes.c_uint32),
     ]
 
     def as_dict(self) -> dict:

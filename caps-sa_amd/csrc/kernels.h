@@ -2755,7 +2755,8 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) group_scatter_kernel(KCTX
                 if (c) {
                     const idx_t old = TL(co, tid, j);
                     const uint64_t st = (uint64_t)(i - own_lo) * sub + sx;             // (c != 0: a kept group)
-                    const uint64_t r0 = region_start ? region_start[st] : st * slot_cap, rc = region_start ? region_cap[st] : slot_cap;
+                    // (region_start / region_cap point at the first kept stream's entries; the output starts at its region)
+                    const uint64_t r0 = region_start ? region_start[st] - region_start[0] : st * slot_cap, rc = region_start ? region_cap[st] : slot_cap;
                     ob = (uint64_t)old + c <= rc ? (idx_t)(r0 + old) : NO_SLOT;
                 }
                 obase[i] = ob;
@@ -2796,16 +2797,25 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) group_scatter_kernel(KCTX
 
 // Report of a rank's level A for the other ranks (sharded direct path): out[0 .. n_streams) = stream sizes,
 // out[n_streams] = flag word (pivot-key ties), out[n_streams + 1] = size of the largest stream that outgrew its region (0: none).
+// region_cap != null (quantile mode): the room of stream (g, sx) is region_cap[(g - own_lo) * sub + sx] instead of cap (K1 = groups,
+// the cursors are stream-major: s = sx * K1 + g; streams of groups outside own_lo .. own_hi are empty).
 template <typename idx_t>
 GLOBAL_FN LAUNCH_BOUNDS(256) stream_report_kernel(KCTX const idx_t* __restrict__ cursor, uint32_t n_streams, uint64_t cap,
-                                                  const uint32_t* __restrict__ flag, uint64_t* __restrict__ out)
+                                                  const uint32_t* __restrict__ flag, uint64_t* __restrict__ out,
+                                                  const uint64_t* __restrict__ region_cap, uint32_t K1, uint32_t sub, uint32_t own_lo,
+                                                  uint32_t own_hi)
 {
     PAR(tid) {
         const uint32_t s = K_BLOCK_IDX * K_BLOCK_DIM + tid;
         if (s < n_streams) {
             const uint64_t z = (uint64_t)cursor[s];
             out[s] = z;
-            if (z > cap) ATOMIC_MAX_U64(&out[n_streams + 1], z);
+            uint64_t room = cap;
+            if (region_cap) {
+                const uint32_t g = s % K1, sx = s / K1;
+                room = g >= own_lo && g < own_hi ? region_cap[(uint64_t)(g - own_lo) * sub + sx] : 0;
+            }
+            if (z > room) ATOMIC_MAX_U64(&out[n_streams + 1], z);
         }
         if (s == n_streams) out[n_streams] = flag[0];
     }

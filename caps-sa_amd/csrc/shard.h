@@ -100,6 +100,12 @@ public:
             capA_ = (uint64_t)(mean * 1.10 + 6.0 * std::sqrt(mean) + 2.0 * GA_E / K1_ + 64.0);
             capA_ += capA_ & 1;
             if (n_streams_ * capA_ / (local_ ? world : 1) + TILE_E >= (uint64_t)std::numeric_limits<idx_t>::max()) direct_fb_ = CAPS_SA_FB_SHAPE;
+            // quantile mode (pipeline.h Builder::run_direct): NB buckets of BUCKET_Q suffixes, KPG per group, QUANTILE_SPB samples each
+            const uint64_t NBt = (n + BUCKET_Q - 1) / BUCKET_Q;
+            KPG_ = (uint32_t)((NBt + K1_ - 1) / K1_);
+            NB_ = (uint64_t)K1_ * KPG_;
+            m2_ = NB_ * QUANTILE_SPB;
+            if (m2_ > n / 4) m2_ = n / 4;
         }
         const uint32_t gseg = std::max<uint32_t>(p_, DIRECT_SUB * std::min<uint32_t>(p_, BUCKET_LDS));
         try {
@@ -127,6 +133,11 @@ public:
             glut_ = get<uint16_t>(SPLIT_LUT_CELLS + 2);
             dcur_ = get<idx_t>(gseg);
             gshift_ = get<uint8_t>(gseg);
+            rcap_ = get<uint64_t>((size_t)gseg + 1);
+            rstart_ = get<uint64_t>((size_t)gseg + 2);
+            quantile_ok_ = direct_fb_ == CAPS_SA_FB_NONE && local_ && KPG_ >= 2 && KPG_ <= BUCKET_LDS && m2_ >= 8 * NB_ && m2_ <= (1ull << 31) &&
+                           m2_ <= cap_ && n_streams_ <= gseg && (uint64_t)(own_hi_ - own_lo_) * KPG_ <= BucketBufs::bucket_bound(cap_, gseg);
+            knots_ = get<uint64_t>(quantile_ok_ ? NB_ : 1);
             dstat_ = get<uint64_t>(4);
             SA_ = elems(m_total_);
             SB_ = elems(m_total_);
@@ -162,6 +173,8 @@ public:
         o->send_capacity = std::max<uint64_t>(local_n_, direct_fb_ != CAPS_SA_FB_NONE ? 0 :
                                               local_ ? ((uint64_t)K1_ + world_ - 1) / world_ * SUB_ * capA_ : (uint64_t)n_streams_ * capA_);
         o->exchange = direct_fb_ == CAPS_SA_FB_NONE && local_ ? 0u : 1u;
+        o->direct_quantile = quantile_ ? 1u : 0u;
+        o->reserved_ = 0;
         o->ms_scatter = ms_scatter_; o->ms_sort = ms_sort_;
         o->key_bytes = key_bits_ / 8;
         o->ms_level_a = ms_level_a_; o->ms_level_b = ms_level_b_ + ms_count_; o->ms_tile_sort = ms_tile_sort_; o->ms_merge_passes = ms_merge_;
@@ -366,13 +379,15 @@ public:
     {
         if (direct_fb_ != CAPS_SA_FB_NONE) throw std::invalid_argument("this shard's shape does not allow the direct path");
         slot_stats_[0] = slot_stats_[1] = 0;
+        level_a_ran_ = false;
         BackendEvent e0 = be_.record();
         bits_ = prepare_text(be_, dT_, n_, P_, present_, lut_);
         uint64_t* report = static_cast<uint64_t*>(d_report);
         be_.memset(report, 0, ((size_t)n_streams_ + 2) * sizeof(uint64_t));
         be_.memset(dstat_, 0, 4 * sizeof(uint64_t));
         uint32_t* dflag = reinterpret_cast<uint32_t*>(dstat_ + 2);
-        if (be_.long_runs) {
+        quantile_ = false;
+        if (be_.long_runs && !quantile_ok_) {
             const uint32_t code = CAPS_SA_FB_LONG_RUNS;        // every rank sees the same text: all report the same
             be_.h2d(dflag, &code, sizeof code);
         } else {
@@ -387,11 +402,12 @@ public:
             else scatter_bits<8>(d_send_keys, d_send_sa, dflag);
         }
         CAPS_LAUNCH((stream_report_kernel<idx_t>), (n_streams_ + 256) / 256, 256, be_, (const idx_t*)dcur_, n_streams_, capA_,
-                    (const uint32_t*)dflag, report);
+                    (const uint32_t*)dflag, report, quantile_ ? (const uint64_t*)(rcap_ + (size_t)own_lo_ * SUB_) : (const uint64_t*)nullptr,
+                    K1_, SUB_, local_ ? own_lo_ : 0u, local_ ? own_hi_ : K1_);
         BackendEvent e1 = be_.record();
         be_.sync();
         ms_scatter_ = be_.elapsed_ms(e0, e1);
-        ms_level_a_ = be_.long_runs ? 0.0 : be_.elapsed_ms(a0_, a1_);
+        ms_level_a_ = level_a_ran_ ? be_.elapsed_ms(a0_, a1_) : 0.0;
         be_.release_events();
     }
 
@@ -436,7 +452,8 @@ public:
                 for (uint32_t x = 0; x < SUB_; ++x) {
                     const size_t s = ((size_t)k * srcs + r) * SUB_ + x;
                     const uint64_t z = sz(local_ ? rank_ : r, jlo_ + k, x);
-                    st[s] = (uint64_t)r * block + ((uint64_t)k * SUB_ + x) * capA_;
+                    st[s] = quantile_ ? h_rstart_[(size_t)k * SUB_ + x] - h_rstart_[0]      // (local mode only: r = 0)
+                                      : (uint64_t)r * block + ((uint64_t)k * SUB_ + x) * capA_;
                     en[s] = st[s] + z;
                     recv_total_ += z;
                     max_len2_ = z > max_len2_ ? z : max_len2_;
@@ -533,6 +550,11 @@ private:
     int direct_fb_ = CAPS_SA_FB_SHAPE;
     bool direct_planned_ = false;
     bool local_ = true;                  // no exchange: every rank scatters the whole text and keeps its groups
+    bool quantile_ok_ = false, quantile_ = false, skewed_ = false, level_a_ran_ = false;   // quantile level B (local mode only)
+    uint32_t KPG_ = 0;
+    uint64_t NB_ = 0, m2_ = 0;
+    uint64_t *knots_ = nullptr, *rcap_ = nullptr, *rstart_ = nullptr;
+    std::vector<uint64_t> h_rstart_, h_rcap_;       // regions of the owned streams (host copy for shard_plan)
     uint32_t PG_ = 0, K1_ = 0, SUB_ = 1, n_streams_ = 0, my_tiles_ = 0, own_lo_ = 0, own_hi_ = 0;
     uint64_t capA_ = 0, my_elems_ = 0;
     uint32_t key_bits_ = 64;             // width of the keys the last scatter() wrote (32: text.h key32_of)
@@ -554,6 +576,54 @@ private:
         CAPS_LAUNCH((pick_pivots_kernel<idx_t>), (p_ + 255) / 256, 256, be_, (const uint64_t*)smp.key, (const idx_t*)smp.sa, m, p_,
                     pkey_, psa_);
         CAPS_LAUNCH(group_keys_kernel, (p_ + 255) / 256, 256, be_, (const uint64_t*)pkey_, p_, PG_, K1_, gkey_, dflag);
+        // ---- linear or quantile level B (pipeline.h Builder::run_direct; every rank decides the same from the same pivots)
+        const uint64_t* rs = nullptr;
+        const uint64_t* rc = nullptr;
+        if (quantile_ok_) {
+            CAPS_LAUNCH(skew_probe_kernel, (p_ + 255) / 256, 256, be_, (const uint64_t*)pkey_, p_, PG_, K1_, dflag + 2);
+            uint32_t probe[4];
+            be_.d2h(probe, dflag, sizeof probe);
+            be_.sync();                               // {pivot-key ties, -, skewed, longest run of equal pivot keys}
+            quantile_ = probe[0] != 0 || probe[2] != 0 || be_.long_runs;
+            if (const char* mode = std::getenv("CAPS_SA_DIRECT_MODE")) {
+                if (std::string(mode) == "linear" && !be_.long_runs) quantile_ = false;
+                if (std::string(mode) == "quantile") quantile_ = true;
+            }
+            skewed_ = probe[2] != 0;
+            if (quantile_) key_bits_ = 64;            // (knot buckets carry 64-bit keys)
+            const uint64_t token = 2 * GA_E / K1_ + 16;
+            uint32_t code = 0;
+            if (quantile_ && probe[3] > p_ / 4) code = CAPS_SA_FB_PIVOT_TIES;        // one key over a quarter of the text: the samplesort path's
+            else if (quantile_ && capA_ <= 2 * token) code = CAPS_SA_FB_SHAPE;
+            if (quantile_ && code == 0) {
+                // more samples, sorted in the (still idle) element arrays; their quantiles are the bucket boundaries and, every
+                // KPG-th, the group keys; groups that share a frequent key share the room of all of them (group_caps_kernel)
+                CAPS_LAUNCH((sample_text_kernel<idx_t, BITS>), (uint32_t)((m2_ + 255) / 256), 256, be_, (const uint32_t*)P_, (uint64_t)0, n_, m2_,
+                            A_.key, A_.sa);
+                SegBufs sseg = seg1_;
+                sseg.G = 1;
+                CAPS_LAUNCH(uniform_segments_kernel, 1, 256, be_, sseg.seg_start, 1u, m2_, m2_);
+                prepare_segments(be_, sseg, tiles_of(m2_));
+                ElemBuf<idx_t> smp2 = sort<BITS>(sseg, tiles_of(m2_), m2_, false, A_, B_, m2_, 0, false, false, &bk_, true).uniform();
+                CAPS_LAUNCH(knots_kernel, (uint32_t)((NB_ + 255) / 256), 256, be_, (const uint64_t*)smp2.key, m2_, NB_, KPG_, K1_, knots_, gkey_);
+                CAPS_LAUNCH(group_caps_kernel, (K1_ + 255) / 256, 256, be_, (const uint64_t*)knots_, NB_, KPG_, K1_, SUB_, capA_ - token, token, rcap_);
+                CAPS_LAUNCH(scan_sizes_kernel, 1, 1024, be_, (const uint64_t*)rcap_, n_streams_, rstart_);
+                const size_t own_streams = (size_t)(own_hi_ - own_lo_) * SUB_;
+                h_rstart_.assign(own_streams + 1, 0);
+                h_rcap_.assign(own_streams + 1, 0);
+                be_.d2h(h_rstart_.data(), rstart_ + (size_t)own_lo_ * SUB_, (own_streams + 1) * sizeof(uint64_t));
+                be_.d2h(h_rcap_.data(), rcap_ + (size_t)own_lo_ * SUB_, own_streams * sizeof(uint64_t));
+                be_.sync();
+                // the regions of the owned streams must fit the send buffers (a rank that owns a frequent key's groups gets more room)
+                const uint64_t room = ((uint64_t)K1_ + world_ - 1) / world_ * SUB_ * capA_;
+                if (h_rstart_[own_streams] - h_rstart_[0] > room) code = CAPS_SA_FB_GROUP_OVERFLOW;
+                rs = rstart_ + (size_t)own_lo_ * SUB_;
+                rc = rcap_ + (size_t)own_lo_ * SUB_;
+            }
+            // the word the other ranks see: pivot ties are quantile mode's business, not a reason to fall back
+            if (quantile_ || code) be_.h2d(dflag, &code, sizeof code);
+            if (code) { quantile_ = false; return; }                                  // (every rank: the same text, the same code)
+        }
         CAPS_LAUNCH(split_lut_kernel, (SPLIT_LUT_CELLS + 256) / 256, 256, be_, (const uint64_t*)gkey_, K1_ - 1, glut_, dflag + 1);
         be_.memset(dcur_, 0, (size_t)n_streams_ * sizeof(idx_t));
         if (key_bits_ == 32) CAPS_LAUNCH(group_shift_kernel, (K1_ + 255) / 256, 256, be_, (const uint64_t*)gkey_, K1_, gshift_);
@@ -565,13 +635,14 @@ private:
             CAPS_LAUNCH((group_scatter_kernel<idx_t, BITS, uint32_t>), my_tiles_, TILE_NT, be_, (const uint32_t*)P_, packed_words(n_, BITS),
                         (uint64_t)0, n_, (const uint64_t*)gkey_, K1_, (const uint16_t*)glut_, (const uint32_t*)(dflag + 1), SUB_, capA_, dcur_,
                         static_cast<uint32_t*>(d_send_keys), static_cast<idx_t*>(d_send_sa), tile_first, tile_stride,
-                        (const uint64_t*)nullptr, (const uint64_t*)nullptr, (const uint8_t*)gshift_, keep_lo, keep_hi);
+                        rs, rc, (const uint8_t*)gshift_, keep_lo, keep_hi);
         else if (my_tiles_)
             CAPS_LAUNCH((group_scatter_kernel<idx_t, BITS>), my_tiles_, TILE_NT, be_, (const uint32_t*)P_, packed_words(n_, BITS), (uint64_t)0,
                         n_, (const uint64_t*)gkey_, K1_, (const uint16_t*)glut_, (const uint32_t*)(dflag + 1), SUB_, capA_, dcur_,
                         static_cast<uint64_t*>(d_send_keys), static_cast<idx_t*>(d_send_sa), tile_first, tile_stride,
-                        (const uint64_t*)nullptr, (const uint64_t*)nullptr, (const uint8_t*)nullptr, keep_lo, keep_hi);
+                        rs, rc, (const uint8_t*)nullptr, keep_lo, keep_hi);
         a1_ = be_.record();
+        level_a_ran_ = true;
     }
 
     template <int BITS> bool sort_owned_bits(const void* d_recv_keys, const void* d_recv_sa, void* dSA, void* dLCP)
@@ -597,6 +668,11 @@ private:
         o.slot_stats = slot_stats_;
         o.speculate = std::getenv("CAPS_SA_NO_SLOTS") == nullptr;
         if (key_bits_ == 32) { o.k32 = true; o.range_mode = 2; o.gshift = gshift_; o.speculate = true; }
+        if (quantile_) {                          // the owned groups' buckets are (knots[k - 1], knots[k]], KPG per group
+            o.knots = knots_ + (size_t)jlo_ * KPG_;
+            o.knots_per_parent = KPG_;
+            o.skewed_keys = skewed_ && !std::getenv("CAPS_SA_TRY_LINEAR_TILES");
+        }
         KernelClock tile_clock, scatter_clock, count_clock, merge_clock;
         o.tile_clock = &tile_clock;
         o.scatter_clock = &scatter_clock;

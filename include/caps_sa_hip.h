@@ -250,6 +250,9 @@ typedef struct caps_sa_shard_info {
     uint32_t exchange;             /* 1: the streams shard_scatter wrote must be exchanged (all-to-all by the counts of shard_plan)
                                       before shard_sort; 0 (the default for the direct path): nothing travels -- every rank
                                       scattered the whole text and kept its own groups; shard_sort reads the send buffers */
+    uint32_t direct_quantile;      /* 1: the last shard_scatter chose quantile buckets for level B (skewed keys, frequent keys, long
+                                      runs; csrc/pipeline.h Builder::run_direct) -- no-exchange mode only */
+    uint32_t reserved_;
 } caps_sa_shard_info;
 
 int caps_sa_hip_shard_create(const void* dT, uint64_t n, uint64_t subproblem_count, int idx_bytes, int rank, int world,

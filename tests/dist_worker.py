@@ -63,7 +63,7 @@ def main():
         good = np.array_equal(SA_all.view(dt), SAo) and np.array_equal(LCP_all.view(dt), LCPo)
         if rank == 0:
             print(f"case n={T_np.size} p={p} bits={bits} path={info['path']} fb={info.get('direct_fallback')} keys={info.get('key_bytes')} "
-                  f"retry={info.get('key_retry')} exch={info.get('exchange')} counts={counts} "
+                  f"retry={info.get('key_retry')} exch={info.get('exchange')} quant={info.get('direct_quantile')} counts={counts} "
                   f"{'OK' if good else 'MISMATCH'}", flush=True)
         ok = ok and good
     dist.destroy_process_group()

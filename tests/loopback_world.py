@@ -36,6 +36,9 @@ def build_world(lib, T: torch.Tensor, p: int, world: int, idx_bits: int = 32):
             kt = torch.int32 if kbs == {4} else torch.int64           # 32-bit keys travel in exchange mode on a 2-bit text
             exchange = {s.info()["exchange"] for s in shards}
             assert len(exchange) == 1
+            quant = {s.info()["direct_quantile"] for s in shards}
+            assert len(quant) == 1, f"ranks disagree on the bucket mode: {quant}"
+            build_world.last_quantile = quant.pop()
             sc = [[int(x) for x in a] for _, a, _ in plans]
             rc = [[int(x) for x in b] for _, _, b in plans]
             if exchange == {0}:                                       # nothing travels: every rank sorts what it scattered

@@ -38,12 +38,15 @@ def test_sharded_build_matches_oracle(world, port, a2a_limit, small, path, excha
         assert "path=direct" not in r.stdout
     else:
         assert r.stdout.count("path=direct") >= (4 if small else 3), r.stdout
-        assert "fb=3" in r.stdout                      # the long run: CAPS_SA_FB_LONG_RUNS, agreed on by every rank
         if exchange:
+            assert "fb=3" in r.stdout                  # the long run: CAPS_SA_FB_LONG_RUNS, agreed on by every rank
             assert "keys=4 retry=0 exch=1" in r.stdout     # 32-bit keys crossed the (gloo) wire ...
             assert "keys=8 retry=1 exch=1" in r.stdout     # ... and a slot overflow under them sent every rank round again with 64
         else:
             assert "path=direct fb=0 keys=8 retry=0 exch=0" in r.stdout and "path=direct fb=0 keys=4" not in r.stdout
+            if not small:                              # (256-element tiles: the shapes of these cases do not admit quantile buckets)
+                assert "path=direct fb=0 keys=8 retry=0 exch=0 quant=1" in r.stdout   # skewed base frequencies / the long run: quantile buckets
+                assert "n=180000 p=0 bits=32 path=direct" in r.stdout      # the long run no longer sends the ranks to the samplesort path
             assert "path=direct" in r.stdout and "exch=1 " not in "".join(l for l in r.stdout.splitlines() if "path=direct" in l)
 
 

@@ -487,6 +487,30 @@ def test_shard_kernels_at_world_sizes_above_one_loopback(L, sa_path, world, n, p
         assert (build_world.last_exchange, build_world.last_key_bytes, build_world.last_key_retry) == ((1, 4, 0) if exchange else (0, 8, 0))
 
 
+@pytest.mark.parametrize("world,kind", [(4, "genome"), (2, "genome+n"), (8, "genome+n")])
+def test_shard_quantile_mode_on_genome_like_text_loopback(L, world, kind, monkeypatch):
+    """The sharded direct path on skewed keys and N-block stand-ins (tools/genome_like.py, 96 Mi bases): every rank takes the
+    quantile buckets of Builder::run_direct for the groups it owns (no exchange) -- same arrays as the single-GPU build."""
+    import os
+    import sys
+    import torch
+    from loopback_world import build_world
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from bench import make_text
+    monkeypatch.delenv("CAPS_SA_SHARD_EXCHANGE", raising=False)
+    T = make_text(torch, 100_663_296, 42, torch.device("cuda", 0), kind)
+    n = T.numel()
+    SA1 = torch.empty(n, dtype=torch.int32, device="cuda")
+    LCP1 = torch.empty(n, dtype=torch.int32, device="cuda")
+    st = L.build_device(T.data_ptr(), n, SA1.data_ptr(), LCP1.data_ptr(), p=8000)
+    assert st["path_direct"] == 1 and st["direct_quantile"] == 1
+    assert L.verify_device(T.data_ptr(), n, SA1.data_ptr(), LCP1.data_ptr()) == 0
+    SA, LCP = build_world(L, T, 8000, world, 32)
+    assert torch.equal(SA, SA1) and torch.equal(LCP, LCP1)
+    assert build_world.last_path == "direct" and build_world.last_quantile == 1 and build_world.last_exchange == 0
+
+
 def test_shard_key_width_retry_on_skewed_keys_loopback(L, monkeypatch):
     """Exchange mode, skewed base frequencies: level B's slots overflow under 32-bit keys, shard_sort says CAPS_SA_FB_KEY32 on
     some rank and every rank goes round again with 64-bit keys (tests/loopback_world.py asserts the code and that it happens once)."""
