@@ -367,6 +367,7 @@ int build_multi(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context,
             stats->bits_per_char = ranks[0]->info.bits_per_char;
             stats->path_direct = 1;
             stats->direct_groups = ranks[0]->info.direct_groups;
+            stats->direct_quantile = ranks[0]->info.direct_quantile;
             stats->ms_h2d = ms(t0, t1);                       // device setup: allocations + the text to every device
             stats->ms_partition = ms(t1, t2);                 // level A + exchange (host wall clock, all devices)
             stats->ms_merge_partitions = ms(t2, t3);          // level B + tile sort + boundary LCPs

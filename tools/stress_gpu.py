@@ -94,7 +94,13 @@ while time.time() - t0 < budget:
     if os.environ.get("STRESS_ONLY_N") and n != int(os.environ["STRESS_ONLY_N"]):
         continue                                 # replaying one case of a sequence: same random draws, nothing built
     try:
-        SA, LCP, st = L.build(T, p=p, idx_bits=bits)
+        if os.environ.get("STRESS_MULTI"):       # the sharded build: 2 .. 8 ranks (all on device 0), with and without the exchange
+            world = int(rs.choice([2, 3, 4, 8]))
+            if rs.rand() < 0.3: os.environ["CAPS_SA_SHARD_EXCHANGE"] = "1"
+            else: os.environ.pop("CAPS_SA_SHARD_EXCHANGE", None)
+            SA, LCP, st = L.build_multi(T, [0] * world, p=p, idx_bits=bits)
+        else:
+            SA, LCP, st = L.build(T, p=p, idx_bits=bits)
     except caps_sa_amd.CapsSaError as e:         # p^2 matrices beyond the device memory (as in the reference: p^2 on the host)
         if e.code != -4:
             raise
@@ -106,6 +112,7 @@ while time.time() - t0 < budget:
         np.save(os.environ.get("STRESS_DUMP", "/tmp/stress_fail_T.npy"), T)
         print(json.dumps({"FAIL": True, "kind": kind, "n": n, "p": p, "bits": bits, "path": os.environ.get("CAPS_SA_PATH"),
                           "mode": os.environ.get("CAPS_SA_DIRECT_MODE"), "sub": os.environ.get("CAPS_SA_DIRECT_SUB"),
+                          "multi": os.environ.get("STRESS_MULTI"), "exchange": os.environ.get("CAPS_SA_SHARD_EXCHANGE"),
                           "stats": {k: st[k] for k in ("path_direct", "path_fallback", "direct_quantile", "direct_groups")}}))
         sys.exit(1)
     for k in stats: stats[k] += st[k]
