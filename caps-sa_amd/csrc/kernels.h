@@ -1044,8 +1044,11 @@ DEV_INLINE uint32_t eq_pos(const BucketParams& bp, uint64_t key)
     return x < top ? x : top;
 }
 
+#ifndef CAPS_EQ_WAVES
+#define CAPS_EQ_WAVES TILE_WAVES_PER_SIMD
+#endif
 template <typename idx_t, int BITS, bool FROM_TEXT>
-GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_eq_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
+GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
                                                   uint64_t text_base, uint32_t lcp_mode, uint32_t slot_cap, const uint64_t* in_key,
                                                   const idx_t* in_sa, uint64_t* out_key, idx_t* out_sa, idx_t* out_lcp,
                                                   FinalOut<idx_t> fin, const BucketParams* __restrict__ seg_map,
