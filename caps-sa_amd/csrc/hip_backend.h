@@ -18,6 +18,8 @@ struct OomError : std::runtime_error {
 inline void hip_check(hipError_t e, const char* what)
 {
     if (e != hipSuccess) {
+        (void)hipGetLastError();                 // HIP keeps a failed call's code until it is read: the next launch check of this
+                                                 // thread (check_launch) would report it as its own
         std::string m = std::string(what) + ": " + hipGetErrorString(e);
         if (e == hipErrorOutOfMemory) throw OomError(m);
         throw HipError(m);

@@ -107,7 +107,10 @@ public:
             m2_ = NB_ * QUANTILE_SPB;
             if (m2_ > n / 4) m2_ = n / 4;
         }
-        const uint32_t gseg = std::max<uint32_t>(p_, DIRECT_SUB * std::min<uint32_t>(p_, BUCKET_LDS));
+        // segments of level B: (owned group, sub-stream), in exchange mode (owned group, source rank, sub-stream) -- a rank owns
+        // ceil(K1 / world) groups at most, i.e. up to K1 * SUB + world * SUB segments when the groups do not divide evenly (found
+        // by tools/stress_gpu.py STRESS_MULTI: p = 3 on 8 ranks overran the tables by 40 entries; HIP refused the copy)
+        const uint32_t gseg = std::max<uint32_t>(p_, DIRECT_SUB * std::min<uint32_t>(p_, BUCKET_LDS)) + (uint32_t)world * DIRECT_SUB;
         try {
             // Everything is allocated ONCE here (hipMalloc / hipFree of tens of GB cost seconds): the
             // element arrays serve phase 1 (this rank's subarrays) and phase 2 (its partitions), sized
@@ -127,6 +130,7 @@ public:
             seg1_ = segs(G_ ? G_ : 1, cap_ / TILE_E + p_ + 2);
             seg1_.G = G_;
             seg2_ = segs(gseg, cap_ / TILE_E + gseg + 2);
+            seg_cap_ = gseg;
             seg2_.G = p_;
             seg2_.seg_end = get<uint64_t>((size_t)gseg + 1);
             gkey_ = get<uint64_t>(p_);
@@ -442,6 +446,7 @@ public:
         // level B's segments: (owned group, source rank, sub-stream), all sub-streams of a group consecutive
         const uint32_t per_group = (uint32_t)srcs * SUB_;
         const size_t nseg = (size_t)G2_ * per_group;
+        if (nseg > seg_cap_) throw std::runtime_error("more level-B segments than the shard's tables hold");
         std::vector<uint64_t> st(nseg + 1, 0), en(nseg + 1, 0);
         recv_total_ = 0;
         max_len2_ = 0;
@@ -549,6 +554,7 @@ private:
     std::vector<KernelClock> clocks_;
     int direct_fb_ = CAPS_SA_FB_SHAPE;
     bool direct_planned_ = false;
+    uint32_t seg_cap_ = 0;               // entries of seg2_ (level B's segments)
     bool local_ = true;                  // no exchange: every rank scatters the whole text and keeps its groups
     bool quantile_ok_ = false, quantile_ = false, skewed_ = false, level_a_ran_ = false;   // quantile level B (local mode only)
     uint32_t KPG_ = 0;

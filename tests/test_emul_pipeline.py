@@ -245,12 +245,31 @@ def test_equalised_split_never_needs_more_passes_than_the_plain_one(oracle, monk
                 assert st["merge_passes_phase2"] <= st0["merge_passes_phase2"]
 
 
-def test_one_process_several_devices(oracle):
+def test_one_process_several_devices(oracle, monkeypatch):
     """caps_sa_*_build_multi_* (capi_impl.h build_multi): one Shard per listed device, blocks copied device to device,
     slices copied into the caller's arrays; here every "device" is the emulation's host memory."""
     from emul_util import emul_small
     E = emul_small()
     rs = np.random.RandomState(19)
+    # groups that do not divide evenly among the ranks (3 or 7 groups on 8, 4 or 2 ranks: some ranks own none), with and
+    # without the exchange -- the exchange layout has up to world * SUB more segments than K1 * SUB (tools/stress_gpu.py found
+    # the tables one rank short of that)
+    for exchange in ("1", None):
+        if exchange:
+            monkeypatch.setenv("CAPS_SA_SHARD_EXCHANGE", exchange)
+        else:
+            monkeypatch.delenv("CAPS_SA_SHARD_EXCHANGE", raising=False)
+        for sub in ("8", None):
+            if sub:
+                monkeypatch.setenv("CAPS_SA_DIRECT_SUB", sub)
+            else:
+                monkeypatch.delenv("CAPS_SA_DIRECT_SUB", raising=False)
+            for devs, n, p, bits in [([0] * 8, 60_000, 3, 32), ([0] * 4, 50_000, 7, 64), ([0] * 2, 40_000, 3, 32)]:
+                T = rs.choice(DNA, size=n)
+                SA, LCP, st = E.build_multi(T, devs, p=p, idx_bits=bits)
+                SAo, LCPo = oracle.naive_sa_lcp(T, idx_bits=bits)
+                assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), (exchange, sub, devs, n, p)
+    monkeypatch.delenv("CAPS_SA_DIRECT_SUB", raising=False)
     for devs, n, p, bits in [([0, 0], 60_000, 0, 32), ([0, 0, 0], 90_001, 700, 32), ([0] * 8, 150_000, 0, 64), ([0], 40_000, 0, 32),
                              ([0, 0], 3_000, 0, 32)]:
         T = rs.choice(DNA, size=n)

@@ -549,6 +549,27 @@ def test_one_process_several_ranks_on_this_gpu(L, oracle, devices, n, p, bits):
     L.release_cache()
 
 
+@pytest.mark.parametrize("exchange", [0, 1])
+def test_ranks_with_groups_that_do_not_divide_evenly(L, oracle, exchange, monkeypatch):
+    """3 or 7 groups on 8, 4, 3, 2 ranks (some own none), forced sub-streams, u64: with the exchange a rank's level B then has
+    up to world * SUB more segments than K1 * SUB -- tools/stress_gpu.py (STRESS_MULTI) found the segment tables short of that
+    (HIP refused the copy; the entry points also left HIP's sticky error for the next build to trip over)."""
+    if exchange:
+        monkeypatch.setenv("CAPS_SA_SHARD_EXCHANGE", "1")
+    else:
+        monkeypatch.delenv("CAPS_SA_SHARD_EXCHANGE", raising=False)
+    monkeypatch.setenv("CAPS_SA_DIRECT_SUB", "8")
+    rs = np.random.RandomState(5)
+    T = rs.choice(np.frombuffer(b"AT", dtype=np.uint8), size=996_385, p=[0.8, 0.2])
+    SAo, LCPo = oracle.build_sa_lcp(T, p=16, idx_bits=64)
+    for world in (8, 4, 3, 2):
+        for p in (3, 7, 16):
+            SA, LCP, st = L.build_multi(T, [0] * world, p=p, idx_bits=64)
+            assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), (world, p)
+            assert st["path_direct"] == 1
+    L.release_cache()
+
+
 def test_genome_like_256mi_with_n_blocks_device(L):
     """the genome-like workload at BASELINE config 1's size (tools/genome_like.py, seeded: order-5 Markov
     chain with skewed transitions + planted mutated repeats) with N-block stand-ins on top -- the direct path in quantile

@@ -93,11 +93,16 @@ while time.time() - t0 < budget:
     else: os.environ.pop("CAPS_SA_DIRECT_SUB", None)
     if os.environ.get("STRESS_ONLY_N") and n != int(os.environ["STRESS_ONLY_N"]):
         continue                                 # replaying one case of a sequence: same random draws, nothing built
+    if os.environ.get("STRESS_TRACE"):           # the parameters of every build, before it runs (finding the one that faults)
+        print(json.dumps({"next": done, "kind": kind, "n": n, "p": p, "bits": bits, "path": os.environ.get("CAPS_SA_PATH"),
+                          "mode": os.environ.get("CAPS_SA_DIRECT_MODE"), "sub": os.environ.get("CAPS_SA_DIRECT_SUB")}), flush=True)
     try:
         if os.environ.get("STRESS_MULTI"):       # the sharded build: 2 .. 8 ranks (all on device 0), with and without the exchange
             world = int(rs.choice([2, 3, 4, 8]))
             if rs.rand() < 0.3: os.environ["CAPS_SA_SHARD_EXCHANGE"] = "1"
             else: os.environ.pop("CAPS_SA_SHARD_EXCHANGE", None)
+            if os.environ.get("STRESS_TRACE"):
+                print(json.dumps({"world": world, "exchange": os.environ.get("CAPS_SA_SHARD_EXCHANGE")}), flush=True)
             SA, LCP, st = L.build_multi(T, [0] * world, p=p, idx_bits=bits)
         else:
             SA, LCP, st = L.build(T, p=p, idx_bits=bits)
