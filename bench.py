@@ -34,6 +34,8 @@ WORKLOADS = {
     "g3": (3_000_000_000, "genome", "genome-like (tools/genome_like.py seed 7): 3e9 bases, u32 indices, p=8000"),
     "g2": (268_435_456, "genome", "genome-like (tools/genome_like.py seed 7): 256 Mi bases, u32 indices, p=8000"),
     "g3n": (3_000_000_000, "genome+n", "genome-like + single-letter blocks (1 x 2e6, 5 x 5e5, 100 x 5e4): 3e9 bases, u32, p=8000"),
+    # BASELINE config 4's shape: needs --gpus 8 (one GPU cannot hold a whole build of it; tools/shard_probe.py c4 times one rank)
+    "c4": (8 << 30, "uniform", "C4: 8 Gi random DNA bases + remapped trailing newline, u64 indices, p=8000 (multi-GPU only)"),
 }
 
 
@@ -157,6 +159,9 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if args.workload == "c4" and world < 8 and not args.bases:
+        raise SystemExit("--workload c4 (8 Gi + 1 bases, 64-bit indices) needs --gpus 8: one GPU cannot hold a whole build of it "
+                         "(tools/shard_probe.py c4 times one rank of eight on one GPU)")
     if world > 1 or os.environ.get("CAPS_SA_FORCE_SHARDED") == "1":
         # sharded path (one process per GPU, RCCL exchange); CAPS_SA_FORCE_SHARDED=1 runs it at world
         # size 1 too (smoke test of the multi-GPU driver on a 1-GPU box)

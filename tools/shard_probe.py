@@ -19,7 +19,7 @@ from caps_sa_dist import ShardBuffers, _idx_dtype  # noqa: E402
 wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
 # "c4": BASELINE config 4's shape (8 Gi random bases + the remapped newline, 64-bit indices), ranks of a world of 8 only (the
 # buffers of a rank of fewer do not fit one GPU next to the text)
-n_bases, kind, _ = (8 << 30, "uniform", None) if wl == "c4" else WORKLOADS[wl]
+n_bases, kind, _ = WORKLOADS[wl]
 L = caps_sa_amd.lib()
 T = make_text(torch, n_bases, 42, torch.device("cuda", 0), kind)
 n = T.numel()
