@@ -37,7 +37,13 @@ namespace caps { struct EmulCtx { uint32_t block_idx, grid_dim, block_dim; }; }
 #define K_BLOCK_IDX (kctx_.block_idx)
 #define K_GRID_DIM (kctx_.grid_dim)
 #define K_BLOCK_DIM (kctx_.block_dim)
+#ifdef CAPS_EMUL_REVERSE   /* the threads of every phase in descending order: a phase that depends on the order of its threads
+                              (a missing barrier between a write and a read of two threads) gives a different result than with
+                              the ascending build, or a wrong one (tests/test_emul_pipeline.py, reversed-order cases) */
+#define PAR(tid) for (uint32_t tid##_i_ = 0, tid = kctx_.block_dim - 1; tid##_i_ < kctx_.block_dim; ++tid##_i_, --tid)
+#else
 #define PAR(tid) for (uint32_t tid = 0; tid < kctx_.block_dim; ++tid)
+#endif
 #define SYNC() ((void)0)
 #define SYNC_LDS() ((void)0)
 #define SHARED_ARRAY(type, name, count) std::vector<type> name##_vec_(count); type* name = name##_vec_.data()

@@ -1253,7 +1253,12 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                                 const uint32_t pi = vj < np ? vj : TIE_LIST_CAP - 1u - (vj - np);
                                 const uint32_t ent = plist[pi];
                                 TL(tpi, tid, 0) = pi | (vj < np ? 0u : 0x80000000u) | (vj << 16);
-                                if ((ent >> 24) == 0xFFu) {               // (always, in these two rounds)
+                                // open: untouched (0xFF) or touched by another lane of THIS round (its window number) -- not
+                                // "untouched" alone: the lanes of an entry would then depend on each other's timing (they do run
+                                // in lockstep, one wave holds them all, but nothing here should need that; the reversed-order
+                                // emulation, tests/test_emul_pipeline.py, found it)
+                                const uint32_t tb = ent >> 24;
+                                if (tb == 0xFFu || (tb >= W0 && tb < W0 + G)) {
                                     const uint64_t a = (uint64_t)ssa[ent & 0xFFFu], b2 = (uint64_t)ssa[(ent >> 12) & 0xFFFu];
                                     const uint64_t maxlen = a < n && b2 < n ? n - (a > b2 ? a : b2) : 0;   // corrupt index: settle at once
                                     const uint64_t l = (uint64_t)KCH_ * (1u + W);

@@ -10,6 +10,8 @@ _emul = None
 
 def emul():
     global _emul
+    if os.environ.get("CAPS_EMUL_REV") == "1":      # the whole suite through the reversed-order builds (a one-off check)
+        return emul_rev(False)
     if _emul is None:
         subprocess.check_call(["make", "-s", "-C", EMUL_DIR, "libcaps_sa_emul.so"])
         if ROOT not in sys.path:
@@ -25,6 +27,8 @@ _small = None
 def emul_small():
     """The same kernel sources compiled with 256-element tiles (64-thread workgroups)."""
     global _small
+    if os.environ.get("CAPS_EMUL_REV") == "1":
+        return emul_rev(True)
     if _small is None:
         subprocess.check_call(["make", "-s", "-C", EMUL_DIR, "libcaps_sa_emul_small.so"])
         if ROOT not in sys.path:
@@ -32,3 +36,19 @@ def emul_small():
         import caps_sa_amd
         _small = caps_sa_amd.CapsLib(os.path.join(EMUL_DIR, "libcaps_sa_emul_small.so"), "caps_sa_emul_")
     return _small
+
+
+_rev = {}
+
+
+def emul_rev(small: bool = True):
+    """The emulation with the threads of every phase run in DESCENDING order (kernel_lang.h CAPS_EMUL_REVERSE): results must
+    not depend on it."""
+    name = "libcaps_sa_emul_small_rev.so" if small else "libcaps_sa_emul_rev.so"
+    if name not in _rev:
+        subprocess.check_call(["make", "-s", "-C", EMUL_DIR, name])
+        if ROOT not in sys.path:
+            sys.path.insert(0, ROOT)
+        import caps_sa_amd
+        _rev[name] = caps_sa_amd.CapsLib(os.path.join(EMUL_DIR, name), "caps_sa_emul_")
+    return _rev[name]

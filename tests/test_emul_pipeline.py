@@ -440,3 +440,58 @@ def test_equalised_tile_sort_settles_ties_once(oracle):
         gave_up, finished = a[6], a[7]
         assert finished > 0, list(a)
         assert int((LCP >= 40).sum()) > n // 100 and int(LCP.max()) >= 2999
+
+
+def test_phases_do_not_depend_on_the_order_of_their_threads(oracle, monkeypatch):
+    """the emulation runs the threads of a phase one after the other, so it cannot see a missing barrier -- unless
+    the order changes the outcome.  The same sources compiled with the threads of every phase in DESCENDING order
+    (kernel_lang.h CAPS_EMUL_REVERSE; both tile geometries) must still produce THE suffix and LCP arrays: uniform and skewed
+    keys, key ties settled by the workgroup (pairs, groups, deep ones), long runs, byte alphabets, both constructions, the
+    one-process multi-rank build with and without the exchange."""
+    from emul_util import emul_rev
+    rs = np.random.RandomState(3)
+
+    def ties(n):
+        trans = rs.dirichlet([0.4] * 4, size=16)
+        cdf = np.cumsum(trans, axis=1)
+        c = rs.randint(0, 4, size=2).tolist()
+        u = rs.rand(n)
+        for i in range(2, n):
+            c.append(int(min(3, np.searchsorted(cdf[c[-2] * 4 + c[-1]], u[i]))))
+        T = DNA[np.array(c)]
+        for _ in range(n // 1500):
+            s, d = rs.randint(0, n - 90, size=2)
+            T[d:d + 90] = T[s:s + 90]
+            T[d + rs.randint(40, 90)] = DNA[rs.randint(0, 4)]
+        for _ in range(n // 6000):
+            s = rs.randint(0, n - 90)
+            for d in rs.randint(0, n - 90, size=rs.randint(2, 9)):
+                T[d:d + 40] = T[s:s + 40]
+        T[n // 2:n // 2 + 2500] = T[n // 5:n // 5 + 2500]
+        return T
+
+    for small in (True, False):
+        E = emul_rev(small)
+        n_big = 60_000 if small else 300_000
+        cases = [(rs.choice(DNA, size=n_big), 0, 32), (rs.choice(DNA, size=n_big // 2 + 1), 12, 64),
+                 (rs.choice(DNA, size=n_big, p=[0.6, 0.2, 0.1, 0.1]), 7, 32), (ties(n_big), 24, 32),
+                 (rs.choice(np.frombuffer(b"abcdefgh\xf0", dtype=np.uint8), size=n_big // 2), 16, 32), (rs.choice(DNA, size=300), 0, 32)]
+        runs = rs.choice(DNA, size=n_big // 2)
+        runs[1000:7000] = ord("G")
+        cases.append((runs, 0, 32))
+        for T, p, bits in cases:
+            SAo, LCPo = oracle.build_sa_lcp(T, p=p, idx_bits=bits)
+            for path in ("auto", "classic"):
+                monkeypatch.setenv("CAPS_SA_PATH", path)
+                SA, LCP, st = E.build(T, p=p, idx_bits=bits)
+                assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), (small, T.size, p, bits, path)
+        monkeypatch.setenv("CAPS_SA_PATH", "auto")
+        for exchange in ("1", None):
+            if exchange:
+                monkeypatch.setenv("CAPS_SA_SHARD_EXCHANGE", exchange)
+            else:
+                monkeypatch.delenv("CAPS_SA_SHARD_EXCHANGE", raising=False)
+            T = rs.choice(DNA, size=n_big)
+            SAo, LCPo = oracle.build_sa_lcp(T, p=16)
+            SA, LCP, st = E.build_multi(T, [0, 0, 0], p=16)
+            assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), (small, exchange)
