@@ -37,7 +37,10 @@ namespace caps { struct EmulCtx { uint32_t block_idx, grid_dim, block_dim; }; }
 #define K_BLOCK_IDX (kctx_.block_idx)
 #define K_GRID_DIM (kctx_.grid_dim)
 #define K_BLOCK_DIM (kctx_.block_dim)
-#ifdef CAPS_EMUL_REVERSE   /* the threads of every phase in descending order: a phase that depends on the order of its threads
+#if defined(CAPS_EMUL_SCATTER)   /* ... or in a scattered order: start anywhere, step by an odd stride (block sizes are powers of two) */
+static inline uint32_t caps_emul_phase_start() { static uint32_t c = 12345u; c = c * 1664525u + 1013904223u; return c >> 8; }
+#define PAR(tid) for (uint32_t tid##_i_ = 0, tid##_s_ = (kctx_.block_dim / 2u + 1u) | 1u, tid = caps_emul_phase_start() % kctx_.block_dim;                       tid##_i_ < kctx_.block_dim; ++tid##_i_, tid = (tid + tid##_s_) % kctx_.block_dim)
+#elif defined(CAPS_EMUL_REVERSE)   /* the threads of every phase in descending order: a phase that depends on the order of its threads
                               (a missing barrier between a write and a read of two threads) gives a different result than with
                               the ascending build, or a wrong one (tests/test_emul_pipeline.py, reversed-order cases) */
 #define PAR(tid) for (uint32_t tid##_i_ = 0, tid = kctx_.block_dim - 1; tid##_i_ < kctx_.block_dim; ++tid##_i_, --tid)
