@@ -34,6 +34,10 @@ WORKLOADS = {
     "g3": (3_000_000_000, "genome", "genome-like (tools/genome_like.py seed 7): 3e9 bases, u32 indices, p=8000"),
     "g2": (268_435_456, "genome", "genome-like (tools/genome_like.py seed 7): 256 Mi bases, u32 indices, p=8000"),
     "g3n": (3_000_000_000, "genome+n", "genome-like + single-letter blocks (1 x 2e6, 5 x 5e5, 100 x 5e4): 3e9 bases, u32, p=8000"),
+    # ... and with GRCh38-shaped repeats: satellite tandem arrays (period 171 / 2052), a 300-base family in 1e5 copies,
+    # segmental duplications incl. an exact 50-kb one (tools/genome_like.py plant_genome_repeats)
+    "g3r": (3_000_000_000, "genome+r", "genome-like + satellite arrays, 1e5-copy 300-base family, segmental duplications: 3e9 bases, u32, p=8000"),
+    "g2r": (268_435_456, "genome+r", "genome-like + satellite arrays, repeat family, segmental duplications: 256 Mi bases, u32, p=8000"),
     # BASELINE config 4's shape: needs --gpus 8 (one GPU cannot hold a whole build of it; tools/shard_probe.py c4 times one rank)
     "c4": (8 << 30, "uniform", "C4: 8 Gi random DNA bases + remapped trailing newline, u64 indices, p=8000 (multi-GPU only)"),
 }
@@ -53,6 +57,9 @@ def make_text(torch, n_bases, seed, device, kind="uniform"):
                 if ln * 4 < n_bases:
                     for a in torch.randint(0, n_bases - ln, (cnt,), device=device, generator=g).tolist():
                         T[a:a + ln] = ord("G")
+        if kind == "genome+r":
+            from genome_like import plant_genome_repeats
+            plant_genome_repeats(T, n_bases)
         T[n - 1] = ord("C")
         return T
     g = torch.Generator(device=device)

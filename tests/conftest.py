@@ -29,6 +29,17 @@ def golden_cases():
         return json.load(f)["cases"]
 
 
+LARGE_GOLDEN = ["dna_cli_140k", "two_letters_skewed_150k", "planted_repeat_145k", "latin1_signed_136k", "dna_cli_200k",
+                "markov_skewed_250k"]
+
+
+def large_golden(name: str):
+    """(text, sa, lcp) of one large reference-made fixture (tests/golden/large_<name>.npz: outputs of the reference's
+    chatgpt_baseline.py, recorded by tests/golden/make_golden.py).  Long enough for the DEFAULT construction (direct path)."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", f"large_{name}.npz"))
+    return np.ascontiguousarray(z["text"]), z["sa"], z["lcp"]
+
+
 def text_bytes(s: str) -> np.ndarray:
     return np.frombuffer(s.encode("latin-1"), dtype=np.uint8)
 

@@ -77,3 +77,59 @@ with open(os.path.join(HERE, "cases.json"), "w") as f:
     json.dump({"generator": "tests/golden/make_golden.py", "source": "chatgpt_baseline.py (reference)",
                "cases": cases}, f, separators=(",", ":"))
 print(f"wrote {len(cases)} cases")
+
+# ---------------------------------------------------------------------------------------------------------------
+# Large cases (round 3): long enough (>= 32 tiles of 4096 suffixes) for the library's DEFAULT construction -- the
+# direct path, csrc/pipeline.h Builder::run_direct -- so that reference-made vectors drive it, not only the chain
+# fixtures -> oracle -> HIP.  chatgpt_baseline.suffix_array materialises every suffix (n^2 / 2 bytes: 10 GB at
+# n = 140,000), so the sizes stay just above that threshold and the cases are made one at a time.  Stored as
+# tests/golden/large_<name>.npz (text, sa, lcp as arrays; data only).
+#
+# latin1_signed: the reference compares `char`s, which are SIGNED on its platform (src/Suffix_Array.cpp:75-77,289), while
+# Python orders str by code point.  The text handed to chatgpt_baseline is therefore the order-isomorphic string
+# chr(byte ^ 0x80) (signed order of the bytes = code point order of that string); SA and LCP are position-based, so they
+# are the expected arrays of the byte text itself.
+# ---------------------------------------------------------------------------------------------------------------
+import gc
+import numpy as np
+
+
+def add_large(name, raw: bytes, note, signed_order=False):
+    text = "".join(chr(b ^ 0x80) for b in raw) if signed_order else raw.decode("latin-1")
+    sa = ref.suffix_array(text)
+    gc.collect()
+    lcp = ref.lcp_array(text, sa)
+    np.savez_compressed(os.path.join(HERE, f"large_{name}.npz"), text=np.frombuffer(raw, dtype=np.uint8),
+                        sa=np.asarray(sa, dtype=np.uint32), lcp=np.asarray(lcp, dtype=np.uint32),
+                        note=np.asarray(note), signed_order=np.asarray(signed_order))
+    print(f"wrote large_{name}.npz  n={len(raw)}  max lcp {max(lcp)}")
+    del sa, lcp, text
+    gc.collect()
+
+
+if os.environ.get("CAPS_GOLDEN_LARGE", "1") != "0":
+    add_large("dna_cli_140k", cli_remap(gen_rand_seq(21, 140_000).encode()).encode(),
+              "utils/gen_rand_seq.py 21 140000 through the CLI remap (2-bit path, uniform keys)")
+    add_large("two_letters_skewed_150k", "".join(random.Random(22).choices("AT", weights=[0.85, 0.15], k=150_000)).encode(),
+              "two letters, 85 % / 15 % (skewed keys: quantile buckets)")
+    rs = random.Random(23)
+    body = [rs.choice("ACGT") for _ in range(145_000)]
+    rep = body[10_000:15_000]
+    body[70_000:75_000] = rep                                            # an exact 5-kb duplicate
+    mut = list(rep)
+    for i in rs.sample(range(5000), 50):
+        mut[i] = rs.choice("ACGT")
+    body[120_000:125_000] = mut                                          # and a copy with 1 % point mutations
+    body[40_000:40_600] = "G" * 600                                      # an N-block stand-in (src/main.cpp:61-68 maps N to G)
+    add_large("planted_repeat_145k", "".join(body).encode(), "random DNA + exact and mutated 5-kb repeat + a 600-long G run (deep LCPs)")
+    rs = random.Random(24)
+    add_large("latin1_signed_136k", bytes(rs.choice([0x00, 0x41, 0x61, 0x7F, 0x80, 0x81, 0xC3, 0xE9, 0xFF]) for _ in range(136_000)),
+              "bytes on both sides of 0x80: signed-char order (8-bit path); see the comment in make_golden.py", signed_order=True)
+    rs = random.Random(26)
+    trans = {a + b: [rs.random() ** 3 + 0.01 for _ in range(4)] for a in "ACGT" for b in "ACGT"}     # order-2 chain, skewed rows
+    out = ["A", "C"]
+    for _ in range(250_000 - 2):
+        out.append(rs.choices("ACGT", weights=trans[out[-2] + out[-1]])[0])
+    add_large("markov_skewed_250k", "".join(out).encode(), "order-2 Markov chain with skewed transitions (genome-like k-mer skew; 61 tiles)")
+    add_large("dna_cli_200k", cli_remap(gen_rand_seq(25, 200_000).encode()).encode(),
+              "utils/gen_rand_seq.py 25 200000 through the CLI remap (48 tiles)")

@@ -4,7 +4,7 @@ are the -m gpu tests in test_gpu_parity.py, which run the real kernels."""
 import numpy as np
 import pytest
 
-from conftest import text_bytes
+from conftest import LARGE_GOLDEN, large_golden, text_bytes
 from emul_util import emul
 
 DNA = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -26,6 +26,18 @@ def test_golden_cases(oracle, golden_cases):
             SA, LCP, _ = E.build(T, p=p)
             assert SA.tolist() == c["sa"], (c["name"], p)
             assert LCP.tolist() == c["lcp"], (c["name"], p)
+
+
+@pytest.mark.parametrize("name", LARGE_GOLDEN)
+def test_large_golden_cases_take_the_direct_path(name, monkeypatch):
+    """Reference-made vectors long enough for the default construction: the direct path (and, separately, the samplesort
+    path) of the emulated kernels against them."""
+    T, sa, lcp = large_golden(name)
+    for path in ("auto", "classic"):
+        monkeypatch.setenv("CAPS_SA_PATH", path)
+        SA, LCP, st = emul().build(T, p=0)
+        assert np.array_equal(SA, sa) and np.array_equal(LCP, lcp), (name, path)
+        assert st["path_direct"] == (1 if path == "auto" else 0), (name, path, st["path_fallback"])
 
 
 @pytest.mark.parametrize("n,p", [(200000, 7), (200001, 0), (300007, 16), (100000, 1), (4096, 2), (4097, 2),

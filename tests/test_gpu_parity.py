@@ -7,7 +7,7 @@ the device: permutation + adjacent-pair order + exact LCP) plus closed forms."""
 import numpy as np
 import pytest
 
-from conftest import text_bytes
+from conftest import LARGE_GOLDEN, large_golden, text_bytes
 
 pytestmark = pytest.mark.gpu
 DNA = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -41,6 +41,23 @@ def test_golden_cases(L, golden_cases):
             SA, LCP, _ = L.build(T, p=p)
             assert SA.tolist() == c["sa"], (c["name"], p)
             assert LCP.tolist() == c["lcp"], (c["name"], p)
+
+
+@pytest.mark.parametrize("name", LARGE_GOLDEN)
+def test_large_golden_cases_drive_the_direct_path(L, name, monkeypatch):
+    """Reference-made vectors (chatgpt_baseline.py, tests/golden/make_golden.py) of 136k .. 250k chars: long enough for the
+    DEFAULT construction, so the direct path is compared with reference output itself, not only through the oracle; the
+    latin-1 case pins the signed-char order (src/Suffix_Array.cpp:75-77) the same way."""
+    T, sa, lcp = large_golden(name)
+    for path in ("auto", "classic"):
+        monkeypatch.setenv("CAPS_SA_PATH", path)
+        for p in (0, 8000):
+            SA, LCP, st = L.build(T, p=p)
+            assert np.array_equal(SA, sa) and np.array_equal(LCP, lcp), (name, path, p)
+            if path == "classic":
+                assert st["path_direct"] == 0
+            elif p == 0:
+                assert st["path_direct"] == 1, (name, st["path_fallback"])
 
 
 def test_reference_dump_digest_pins(L, oracle):
@@ -196,6 +213,56 @@ def test_c3_3g_device_resident(L, sa_path):
     assert st["path_direct"] == (0 if sa_path == "classic" else 1), st
     if sa_path != "classic":
         assert st["path_fallback"] == 0 and st["slot_splits_redone"] == 0 and st["direct_groups"] == 1000, st
+
+
+@pytest.mark.parametrize("kind", ["genome", "genome+n", "genome+r"])
+def test_c3_genome_like_3g_device_resident(L, kind):
+    """BASELINE config 3 is GRCh38; its stand-ins at full size (bench.py --workload g3 / g3n / g3r: skewed order-5 Markov
+    text with planted mutated repeats; + N-block stand-ins; + satellite arrays, a 1e5-copy repeat family and segmental
+    duplications) take kernels the uniform 3e9 text never reaches -- quantile level B, tile_sort_eq_kernel, the run-table
+    merge passes -- with counts near 2^32.  Exact device verifier; the default construction must be the direct path in
+    quantile mode."""
+    import os
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from bench import make_text
+    T = make_text(torch, 3_000_000_000, 42, torch.device("cuda", 0), kind)
+    n = T.numel()
+    SA = torch.empty(n, dtype=torch.int32, device="cuda")
+    LCP = torch.empty(n, dtype=torch.int32, device="cuda")
+    st = L.build_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr(), p=8000)
+    errs = L.verify_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr())
+    brief = {k: st[k] for k in ("path_direct", "path_fallback", "direct_quantile", "long_runs", "direct_groups", "direct_max_group", "ms_total")}
+    assert errs == 0, (errs, brief)
+    assert st["p_eff"] == 8000 and st["path_direct"] == 1 and st["direct_quantile"] == 1, brief
+    if kind == "genome+n":
+        assert st["long_runs"] == 1 and int(LCP.max().item()) >= 1_999_000, brief
+    if kind == "genome+r":
+        assert int(LCP.max().item()) >= 49_999, brief            # the exact 50-kb duplicate
+    del T, SA, LCP
+    torch.cuda.empty_cache()
+
+
+def test_genome_like_256mi_with_grch38_shaped_repeats_device(L, sa_path):
+    """tools/genome_like.py plant_genome_repeats at BASELINE config 1's size: a satellite array of period 171 and its
+    higher-order repeat of period 2052 (thousands of suffixes share a 32-base key and differ ~200 chars on), a 300-base
+    family in 6,250 copies, 100-kb duplications at 1 % and an exact 50-kb duplicate.  Both constructions, exact verifier."""
+    import os
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from bench import make_text
+    T = make_text(torch, 268_435_456, 42, torch.device("cuda", 0), "genome+r")
+    n = T.numel()
+    SA = torch.empty(n, dtype=torch.int32, device="cuda")
+    LCP = torch.empty(n, dtype=torch.int32, device="cuda")
+    st = L.build_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr(), p=8000)
+    assert L.verify_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr()) == 0
+    assert st["path_direct"] == (0 if sa_path == "classic" else 1), st
+    assert int(LCP.max().item()) >= 49_999
 
 
 def test_sharded_driver_single_rank_rccl(L, sa_path):

@@ -3,7 +3,7 @@ recorded from the reference's own chatgpt_baseline.py (tests/golden/make_golden.
 import numpy as np
 import pytest
 
-from conftest import text_bytes
+from conftest import LARGE_GOLDEN, large_golden, text_bytes
 
 
 def _cases(golden_cases):
@@ -31,6 +31,17 @@ def test_oracle_matches_golden(oracle, golden_cases, p):
         assert LCP.tolist() == c["lcp"], c["name"]
         ran += 1
     assert ran >= 15
+
+
+@pytest.mark.parametrize("name", LARGE_GOLDEN)
+def test_oracle_matches_large_golden(oracle, name):
+    """The 136k .. 250k-char reference-made vectors (incl. bytes >= 0x80: the signed-char order of src/Suffix_Array.cpp:75-77
+    now has a reference-held pin, see make_golden.py): oracle, default p and p = 8000-style small subarrays."""
+    T, sa, lcp = large_golden(name)
+    for p in (0, 37):
+        SA, LCP = oracle.build_sa_lcp(T, p=p)
+        assert np.array_equal(SA, sa), (name, p)
+        assert np.array_equal(LCP, lcp), (name, p)
 
 
 def test_naive_matches_golden_everywhere(oracle, golden_cases):

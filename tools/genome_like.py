@@ -41,6 +41,55 @@ def markov_dna(n, order=5, seed=7, device="cuda", skew=0.5, repeats=0.02, repeat
     return out_t
 
 
+def plant_genome_repeats(T, n_bases, seed=5):
+    """GRCh38-shaped repeat content on top of a text of ACGT letters (in place).  Sizes are those of
+    the 3e9-base workload, scaled down with the text (factor n_bases / 3e9, at least 1/16):
+      * a 20 Mb tandem array of a 171-base monomer, every copy 1.5 % diverged (alpha satellite) -- half of it as a
+        higher-order repeat: a unit of 12 monomers 20 % apart from each other, the units 0.5 % apart (period 2052:
+        far beyond the run table's 16), so thousands of suffixes share their first 32 bases and differ ~200 chars on;
+      * 100,000 copies of a 300-base family, each 12 % from the consensus (Alu-like), at disjoint places;
+      * five 100-kb duplications at 1 % divergence and ONE exact 50-kb duplicate (segmental duplications).
+    Deterministic for a given (n_bases, seed): no two planted pieces overlap."""
+    dev = T.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=dev)
+    f = max(1.0 / 16, min(1.0, n_bases / 3e9))
+
+    def rnd(m):
+        return lut[torch.randint(0, 4, (m,), device=dev, generator=g, dtype=torch.int64)]
+
+    def mutate(seg, rate):
+        seg = seg.clone()
+        m = torch.rand(seg.numel(), device=dev, generator=g) < rate
+        seg[m] = rnd(int(m.sum()))
+        return seg
+
+    mono = rnd(171)
+    half = int(10_000_000 * f)
+    a0 = n_bases // 10                                               # [0.10 n, 0.10 n + 2 * half): the satellite
+    assert a0 + 2 * half < n_bases // 4
+    T[a0:a0 + half] = mutate(mono.repeat(half // 171 + 1)[:half], 0.015)
+    unit = torch.cat([mutate(mono, 0.2) for _ in range(12)])
+    T[a0 + half:a0 + 2 * half] = mutate(unit.repeat(half // unit.numel() + 1)[:half], 0.005)
+    copies = int(100_000 * f)                                        # [0.30 n, 0.90 n): the 300-base family, one copy per stride
+    stride = (6 * n_bases // 10) // copies
+    assert stride >= 1000
+    cons = rnd(300)
+    pos = (n_bases * 3 // 10) + torch.arange(copies, device=dev, dtype=torch.int64) * stride \
+        + torch.randint(0, stride - 300, (copies,), device=dev, generator=g)
+    fam = mutate(cons.repeat(copies), 0.12).view(copies, 300)
+    T[(pos[:, None] + torch.arange(300, device=dev)).view(-1)] = fam.view(-1)
+    dl = int(100_000 * max(f, 0.5))                                  # duplications: sources in [0.02 n, 0.08 n), copies in [0.92 n, 0.99 n)
+    for k in range(5):
+        s0 = n_bases * 2 // 100 + k * (n_bases // 100)
+        d0 = n_bases * 92 // 100 + k * (n_bases // 100)
+        T[d0:d0 + dl] = mutate(T[s0:s0 + dl], 0.01)
+    s0, d0 = n_bases * 8 // 100, n_bases * 98 // 100
+    T[d0:d0 + 50_000] = T[s0:s0 + 50_000]
+    return T
+
+
 if __name__ == "__main__":
     import os, sys, time, json
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
