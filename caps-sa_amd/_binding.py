@@ -59,7 +59,7 @@ class Stats(ctypes.Structure):
         ("direct_max_group", ctypes.c_uint64),
         ("level_a_ms", ctypes.c_double),
         ("direct_key_bits", ctypes.c_uint32),
-        ("reserved_", ctypes.c_uint32),
+        ("run_buckets", ctypes.c_uint32),
     ]
 
     def as_dict(self) -> dict:
@@ -90,7 +90,7 @@ class ShardInfo(ctypes.Structure):
         ("level_a_elems", ctypes.c_uint64),
         ("slot_splits", ctypes.c_uint32), ("slot_splits_redone", ctypes.c_uint32),
         ("key_bytes", ctypes.c_uint32), ("exchange", ctypes.c_uint32),
-        ("direct_quantile", ctypes.c_uint32), ("reserved_", ctypes.c_uint32),
+        ("direct_quantile", ctypes.c_uint32), ("run_buckets", ctypes.c_uint32),
     ]
 
     def as_dict(self) -> dict:

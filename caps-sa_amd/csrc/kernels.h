@@ -380,6 +380,12 @@ GLOBAL_FN LAUNCH_BOUNDS(256) uniform_segments_kernel(KCTX uint64_t* __restrict__
     }
 }
 
+// seg_start[0 .. 1] = {s0, s1}: ONE segment anywhere in the arrays (a letter-run bucket, pipeline.h sort_run_buckets)
+GLOBAL_FN LAUNCH_BOUNDS(64) segment_range_kernel(KCTX uint64_t* __restrict__ seg_start, uint64_t s0, uint64_t s1)
+{
+    PAR(tid) { if (tid == 0 && K_BLOCK_IDX == 0) { seg_start[0] = s0; seg_start[1] = s1; } }
+}
+
 // Exclusive scan of sizes[G] into seg_start[G+1] (single workgroup).
 // Partition offsets of the reference's serial scan (src/Suffix_Array.cpp:319-330).
 // gfx950: per-wave inclusive scan with wave64 shuffles, wave totals combined through LDS.
@@ -420,8 +426,11 @@ GLOBAL_FN LAUNCH_BOUNDS(1024) scan_sizes_kernel(KCTX const uint64_t* __restrict_
 // tile_off[G+1] = exclusive scan of ceil(len/TILE_E); out2[0] = #tiles, out2[1] = max segment
 // length (out2 must be zeroed before the launch).  Single workgroup; LDS Hillis-Steele scan
 // per chunk of 1024 segments.
+// skip (optional): segments with skip[g] != 0 get no tiles and do not count for the maximum (they are sorted elsewhere:
+// the letter-run buckets of run_bucket_mark_kernel)
 GLOBAL_FN LAUNCH_BOUNDS(1024) seg_prepare_kernel(KCTX const uint64_t* __restrict__ seg_start, const uint64_t* __restrict__ seg_end,
-                                                 uint32_t G, uint32_t* __restrict__ tile_off, uint64_t* __restrict__ out2)
+                                                 uint32_t G, uint32_t* __restrict__ tile_off, uint64_t* __restrict__ out2,
+                                                 const uint8_t* __restrict__ skip)
 {
     SHARED_ARRAY(uint32_t, buf, 2048);
     uint32_t carry = 0;
@@ -429,7 +438,7 @@ GLOBAL_FN LAUNCH_BOUNDS(1024) seg_prepare_kernel(KCTX const uint64_t* __restrict
         PAR(tid) {
             const uint32_t g = base + tid;
             uint64_t len = 0;
-            if (g < G) len = seg_end_of(seg_start, seg_end, g) - seg_start[g];
+            if (g < G && !(skip && skip[g])) len = seg_end_of(seg_start, seg_end, g) - seg_start[g];
             buf[tid] = (uint32_t)((len + TILE_E - 1) / TILE_E);
             if (len) ATOMIC_MAX_U64(&out2[1], len);
         }
@@ -445,7 +454,7 @@ GLOBAL_FN LAUNCH_BOUNDS(1024) seg_prepare_kernel(KCTX const uint64_t* __restrict
         PAR(tid) {
             const uint32_t g = base + tid;
             if (g < G) {
-                const uint64_t len = seg_end_of(seg_start, seg_end, g) - seg_start[g];
+                const uint64_t len = skip && skip[g] ? 0 : seg_end_of(seg_start, seg_end, g) - seg_start[g];
                 tile_off[g] = carry + buf[src * 1024 + tid] - (uint32_t)((len + TILE_E - 1) / TILE_E);
             }
         }
@@ -518,7 +527,8 @@ GLOBAL_FN LAUNCH_BOUNDS(1024) add_offsets_kernel(KCTX OutT* __restrict__ out, ui
 
 // cnt[g] = ceil(len_g / TILE_E); out2[1] = max len (out2 zeroed before the launch).
 GLOBAL_FN LAUNCH_BOUNDS(256) tile_count_kernel(KCTX const uint64_t* __restrict__ seg_start, const uint64_t* __restrict__ seg_end,
-                                               uint32_t G, uint64_t* __restrict__ cnt, uint64_t* __restrict__ out2)
+                                               uint32_t G, uint64_t* __restrict__ cnt, uint64_t* __restrict__ out2,
+                                               const uint8_t* __restrict__ skip)
 {
     SHARED_ARRAY(uint64_t, mx, 1);
     PAR(tid) { if (tid == 0) mx[0] = 0; }
@@ -526,7 +536,7 @@ GLOBAL_FN LAUNCH_BOUNDS(256) tile_count_kernel(KCTX const uint64_t* __restrict__
     PAR(tid) {
         const uint64_t g = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
         if (g < G) {
-            const uint64_t len = seg_end_of(seg_start, seg_end, g) - seg_start[g];
+            const uint64_t len = skip && skip[g] ? 0 : seg_end_of(seg_start, seg_end, g) - seg_start[g];
             cnt[g] = (len + TILE_E - 1) / TILE_E;
             if (len) ATOMIC_MAX_LDS_U64(&mx[0], len);
         }
@@ -801,10 +811,14 @@ __device__ unsigned long long caps_phase_clock[32];
 // Bin map of the tile: prepared in advance when the tile belongs to a key-range bucket (seg_map, from
 // bucket_ranges_kernel: its 64-bit division would otherwise be repeated by every thread of every
 // tile), otherwise from the min / max over the tile.
+/* TILE_SYNC: the barrier of the tile kernels' shared pieces.  Everything the threads of a tile hand each other goes through  */
+/* LDS, so tile_sort_eq_kernel (which keeps spilled registers in scratch and emits straight before its next tile) uses the  */
+/* LDS-scope barrier: __syncthreads() would also wait for every scratch store and every result store of the wave.           */
+#define TILE_SYNC() SYNC()
 #define TILE_SORT_RANGE                                                                                         \
     const bool known_range = seg_map != nullptr;                                                                \
     if (!known_range) {                                                                                         \
-        SYNC(); /* kmm initialised */                                                                           \
+        TILE_SYNC(); /* kmm initialised */                                                                      \
         PAR(tid) {                                                                                              \
             uint64_t mn = ~0ull, mx = 0;                                                                        \
             UNROLL                                                                                              \
@@ -819,7 +833,7 @@ __device__ unsigned long long caps_phase_clock[32];
             BLOCK_MINMAX_U64(&kmm[0], &kmm[1], mn, mx);                                                         \
         }                                                                                                       \
     }                                                                                                           \
-    SYNC();                                                                                                     \
+    TILE_SYNC();                                                                                                \
     const BucketParams tb = known_range ? seg_map[g] : make_bucket_params(kmm[0], kmm[1], TILE_BINS); /* block-uniform */
 
 // registers -> final slots TL(rd) in LDS
@@ -835,7 +849,7 @@ __device__ unsigned long long caps_phase_clock[32];
             }                                                                                                   \
         }                                                                                                       \
     }                                                                                                           \
-    SYNC();
+    TILE_SYNC();
 
 // sorted tile in LDS -> HBM (+ LCPs from adjacent keys, + boundary records)
 #define TILE_SORT_EMIT TILE_SORT_EMIT_(0u)
@@ -1047,6 +1061,10 @@ DEV_INLINE uint32_t eq_pos(const BucketParams& bp, uint64_t key)
 #ifndef CAPS_EQ_WAVES
 #define CAPS_EQ_WAVES TILE_WAVES_PER_SIMD
 #endif
+#ifndef CAPS_EQ_FULL_SYNC          /* measurement: -DCAPS_EQ_FULL_SYNC keeps __syncthreads() in this kernel */
+#undef TILE_SYNC
+#define TILE_SYNC() SYNC_LDS()
+#endif
 template <typename idx_t, int BITS, bool FROM_TEXT>
 GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
                                                   uint64_t text_base, uint32_t lcp_mode, uint32_t slot_cap, const uint64_t* in_key,
@@ -1083,10 +1101,18 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                   "tinfo fits hist; slots and entries fit 12 bits; ranks inside a bin fit 8 bits; lcps of settled ties fit 15 bits");
     uint16_t* tinfo = reinterpret_cast<uint16_t*>(hist);
     const uint32_t n_redo = redo[0];
+    // the queue entry and the record of the NEXT tile are fetched while this one is sorted (two dependent loads off the
+    // head of every tile: the load phase was 13 % of this kernel's time, most of it these latencies)
+    uint32_t b_next = K_BLOCK_IDX < n_redo ? redo[1 + K_BLOCK_IDX] : 0u;
+    TileInfo t_next = tile_info(sd, b_next);
     for (uint32_t qi = K_BLOCK_IDX; qi < n_redo; qi += K_GRID_DIM) {
-    const uint32_t b = redo[1 + qi];
-    const uint32_t g = sd.tile_rec[b].g;
-    const TileInfo t = tile_info(sd, b);
+    const uint32_t b = b_next;
+    const TileInfo t = t_next;
+    const uint32_t g = t.g;
+    if (qi + K_GRID_DIM < n_redo) {
+        b_next = redo[1 + qi + K_GRID_DIM];
+        t_next = tile_info(sd, b_next);
+    }
     const uint64_t start = t.s0 + (uint64_t)t.tl * TILE_E;
     const uint32_t cnt = (uint32_t)(t.s1 - start < TILE_E ? t.s1 - start : TILE_E);
     const bool with_lcp = lcp_mode != 0 && (t.s1 - t.s0) <= TILE_E;
@@ -1111,7 +1137,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
         for (uint32_t round = 0; round < EQ_ROUNDS; ++round) {
             if (round) {
                 PAR(tid) { for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0; }
-                SYNC();
+                TILE_SYNC();
             }
             PAR(tid) {
                 UNROLL
@@ -1120,7 +1146,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                     if (e < cnt) FETCH_ADD_U32(&hist[TL(rb, tid, k) >> EQ_FRAC_BITS], 1u);
                 }
             }
-            SYNC();
+            TILE_SYNC();
             block_exclusive_scan_bins(KCTX_PASS hist);
             PAR(tid) {
                 UNROLL
@@ -1136,14 +1162,14 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                     }
                 }
             }
-            SYNC();
+            TILE_SYNC();
         }
         PHASE_MARK(9);                                         // equalisation rounds
         PAR(tid) {
             for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0;
             if (tid < 4) pcnt[tid] = 0;
         }
-        SYNC();
+        TILE_SYNC();
         PAR(tid) {
             UNROLL
             for (uint32_t k = 0; k < TILE_EPT; ++k) {
@@ -1157,7 +1183,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                 }
             }
         }
-        SYNC();
+        TILE_SYNC();
         fast = flag[0] == 0;
         PHASE_MARK(10);                                        // final histogram
     }
@@ -1176,7 +1202,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                 }
             }
         }
-        SYNC();
+        TILE_SYNC();
         PHASE_MARK(12);                                        // place by bin
         // ---- exact rank inside the bin.  Ties (equal keys: 2 % of a genome-like text's neighbours, repeats with a
         // mutation every ~100 chars) need the text, several windows deep, every window a dependent HBM read of ~1 us.  Inside
@@ -1229,7 +1255,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                 }
             }
         }
-        SYNC();                                                // hist is free: tinfo / slcp from here on
+        TILE_SYNC();                                                // hist is free: tinfo / slcp from here on
         PHASE_MARK(16);                                        // R1: rank by keys
         {
             const uint32_t np = pcnt[0], nm = pcnt[1];                                     // block-uniform
@@ -1273,7 +1299,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                                 }
                             }
                         }
-                        SYNC();
+                        TILE_SYNC();
                         PAR(tid) {
                             const uint32_t W = W0 + tid % G, tp = TL(tpi, tid, 0);
                             if (tp != ~0u) {
@@ -1306,13 +1332,13 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                                 }
                             }
                         }
-                        SYNC();
+                        TILE_SYNC();
                     }
                     if (round || pcnt[2] == 0) break;
                 }
             }
         }
-        SYNC();
+        TILE_SYNC();
         PHASE_MARK(17);                                        // T: the listed ties
         PAR(tid) {
             UNROLL
@@ -1351,7 +1377,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                 }
             }
         }
-        SYNC();
+        TILE_SYNC();
         fast = flag[0] == 0;
         PHASE_MARK(13);                                        // rank inside the bin
         if (fast) {
@@ -1367,7 +1393,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                     }
                 }
             }
-            SYNC();
+            TILE_SYNC();
             PHASE_MARK(14);                                    // place final
         }
     }
@@ -1379,10 +1405,13 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
     } else {
         TILE_SORT_EMIT_((uint32_t)tinfo[e])
     }
-    SYNC();                                                    // the staging arrays are free for the next tile
+    TILE_SYNC();                                                    // the staging arrays are free for the next tile
     PHASE_MARK(15);                                            // emit (+ LCPs) and the barrier behind it
     }
 }
+
+#undef TILE_SYNC
+#define TILE_SYNC() SYNC()
 
 // ---- tile_sort_general_kernel: the tiles tile_sort_kernel could not finish ------------------
 // (keys far from uniform inside the tile, or equal keys: repeats), taken from its queue
@@ -3052,6 +3081,9 @@ GLOBAL_FN LAUNCH_BOUNDS(256) skew_probe_kernel(KCTX const uint64_t* __restrict__
 
 // knots[k] (k < NB - 1) = the sample at quantile (k + 1) / NB of the sorted samples: bucket k holds the keys in
 // (knots[k-1], knots[k]]; the groups are runs of KPG consecutive buckets, gkey[g] = knots[(g + 1) * KPG - 1].
+// A FREQUENT key K -- the quantile of two or more consecutive knots: a long repeat, an N-block -- gets a bucket of its own:
+// the first knot of its run becomes K - 1, so bucket (K - 1, K] = {K} holds nothing else (run_bucket_mark_kernel finds such
+// buckets by knots[k - 1] + 1 == knots[k]) and the keys between the previous knot and K have theirs.
 GLOBAL_FN LAUNCH_BOUNDS(256) knots_kernel(KCTX const uint64_t* __restrict__ skey, uint64_t m, uint64_t NB, uint32_t KPG, uint32_t K1,
                                           uint64_t* __restrict__ knots, uint64_t* __restrict__ gkey)
 {
@@ -3059,7 +3091,12 @@ GLOBAL_FN LAUNCH_BOUNDS(256) knots_kernel(KCTX const uint64_t* __restrict__ skey
         const uint64_t k = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
         if (k < NB) {
             // the last bucket of the last group ends at the top of the key range
-            const uint64_t v = k + 1 < NB ? skey[((k + 1) * m) / NB] : ~0ull;
+            uint64_t v = k + 1 < NB ? skey[((k + 1) * m) / NB] : ~0ull;
+            if (k + 2 < NB) {
+                const uint64_t nx = skey[((k + 2) * m) / NB];
+                const uint64_t pv = k ? skey[(k * m) / NB] : 0;
+                if (nx == v && (k == 0 ? v > 0 : pv + 1 < v)) --v;        // head of a run of equal knots, with room below
+            }
             knots[k] = v;
             if ((k + 1) % KPG == 0 && (k + 1) / KPG < K1) gkey[(k + 1) / KPG - 1] = v;
         }
@@ -3104,13 +3141,85 @@ GLOBAL_FN LAUNCH_BOUNDS(256) knot_plan_kernel(KCTX uint32_t G, uint32_t sub, uin
 }
 
 // The tile sort's bin map of every bucket in quantile mode: linear over (knots[i-1], knots[i]].
-GLOBAL_FN LAUNCH_BOUNDS(256) knot_ranges_kernel(KCTX const uint64_t* __restrict__ knots, uint64_t NB, BucketParams* __restrict__ tile_map)
+// has_prev: knots[-1] exists (a shard's slice of the knots that does not start at bucket 0): the lower end of bucket 0.
+GLOBAL_FN LAUNCH_BOUNDS(256) knot_ranges_kernel(KCTX const uint64_t* __restrict__ knots, uint64_t NB, BucketParams* __restrict__ tile_map,
+                                                uint32_t has_prev)
 {
     PAR(tid) {
         const uint64_t i = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
         if (i < NB) {
-            const uint64_t lo = i ? knots[i - 1] : 0, hi = knots[i];
-            tile_map[i] = make_bucket_params(lo < hi ? lo + (i ? 1 : 0) : hi, hi, TILE_BINS);
+            const bool below = i > 0 || has_prev != 0;
+            const uint64_t lo = below ? knots[(int64_t)i - 1] : 0, hi = knots[i];
+            tile_map[i] = make_bucket_params(lo < hi ? lo + (below ? 1 : 0) : hi, hi, TILE_BINS);
+        }
+    }
+}
+
+// ---- letter-run buckets (text.h "letter runs") ------------------------------------------------------------------
+// run_bucket_mark_kernel: bucket i of a quantile split is a LETTER-RUN BUCKET when it holds one key only (knots[i - 1] + 1 ==
+// knots[i]: knots_kernel gives every frequent key such a bucket), that key is one letter repeated, and it is larger than a
+// tile -- all the suffixes deep inside the N-blocks of a genome (the CLI maps N to G, src/main.cpp:61-68).  Such a bucket
+// sits out the tile sort and the LCP-merge passes (skip[i] = 1: no tiles) and is listed ({bucket, start, end, key} in
+// list[1 + 4 j ..], list[0] = how many) for run_rekey_kernel / run_emit_kernel, which order it by (terminator class,
+// what is left of the run, text behind the run) -- no suffix of it is compared with another through the run.
+constexpr uint32_t RUN_BUCKET_MAX = 64;        // listed buckets (4 letters at 2 bits per char; any more stay ordinary)
+GLOBAL_FN LAUNCH_BOUNDS(256) run_bucket_mark_kernel(KCTX const uint64_t* __restrict__ knots, uint64_t NB, uint32_t has_prev, uint32_t bits,
+                                                    const uint64_t* __restrict__ seg_start, uint8_t* __restrict__ skip,
+                                                    uint64_t* __restrict__ list)
+{
+    PAR(tid) {
+        const uint64_t i = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (i < NB) {
+            const uint64_t hi = knots[i], len = seg_start[i + 1] - seg_start[i];
+            const bool pure = (i > 0 || has_prev != 0) ? knots[(int64_t)i - 1] + 1 == hi : hi == 0;
+            const bool letter = bits == 2 ? is_letter_key<2>(hi) : is_letter_key<8>(hi);
+            uint8_t s = 0;
+            if (pure && letter && len > TILE_E) {
+                const uint64_t j = FETCH_ADD_U64(&list[0], 1);
+                if (j < RUN_BUCKET_MAX) {
+                    list[1 + 4 * j] = i;
+                    list[2 + 4 * j] = seg_start[i];
+                    list[3 + 4 * j] = seg_start[i + 1];
+                    list[4 + 4 * j] = hi;
+                    s = 1;
+                }
+            }
+            skip[i] = s;
+        }
+    }
+}
+
+// key[x] = run_key(sa[x]) for the elements [s0, s1) of a letter-run bucket of key K (in place: the bucket's keys are all K).
+template <typename idx_t, int BITS>
+GLOBAL_FN LAUNCH_BOUNDS(256) run_rekey_kernel(KCTX const uint32_t* __restrict__ P, uint64_t n, uint64_t s0, uint64_t s1, uint64_t K,
+                                              uint64_t* __restrict__ key, const idx_t* __restrict__ sa)
+{
+    PAR(tid) {
+        for (uint64_t x = s0 + (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid; x < s1; x += (uint64_t)K_GRID_DIM * K_BLOCK_DIM)
+            key[x] = run_key<(int)sizeof(idx_t), BITS>(P, n, (uint64_t)sa[x], K);
+    }
+}
+
+// The sorted letter-run bucket [s0, s1) (run keys + positions) -> SA and LCP.  LCPs from the run keys (text.h run_pair_lcp);
+// the bucket's head and the head of what follows it in the suffix array (at `total`: the end of the array) are compared with
+// their neighbours in dSA through the text -- the segment records of a bucket that sat out the sort hold nothing.
+template <typename idx_t, int BITS>
+GLOBAL_FN LAUNCH_BOUNDS(256) run_emit_kernel(KCTX const uint32_t* __restrict__ P, uint64_t n, uint64_t s0, uint64_t s1, uint64_t total,
+                                             const uint64_t* __restrict__ key, const idx_t* __restrict__ sa,
+                                             idx_t* __restrict__ dSA, idx_t* __restrict__ dLCP)
+{
+    PAR(tid) {
+        for (uint64_t x = s0 + (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid; x <= s1; x += (uint64_t)K_GRID_DIM * K_BLOCK_DIM) {
+            if (x == s1) {                                       // the element behind the bucket: its LCP with the bucket's last
+                if (s1 < total) dLCP[s1] = (idx_t)deep_lcp<BITS, true>(P, n, (uint64_t)sa[s1 - 1], (uint64_t)dSA[s1], 0);
+                continue;
+            }
+            const uint64_t b = (uint64_t)sa[x];
+            uint64_t l = 0;
+            if (x > s0) l = run_pair_lcp<(int)sizeof(idx_t), BITS>(P, n, key[x - 1], (uint64_t)sa[x - 1], key[x], b);
+            else if (s0 > 0) l = deep_lcp<BITS, true>(P, n, (uint64_t)dSA[s0 - 1], b, 0);
+            dSA[x] = (idx_t)b;
+            dLCP[x] = (idx_t)l;
         }
     }
 }

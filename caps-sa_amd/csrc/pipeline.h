@@ -14,6 +14,7 @@
 // Written against a tiny backend interface (alloc / copies / launch) so that the same
 // sequence can be driven by the host emulation used in tests/emul (kernel_lang.h).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstdio>
@@ -102,6 +103,8 @@ struct BucketBufs {
     uint64_t* fcount = nullptr;       // [EQ_FINE * nb_cap]
     uint32_t* gfirst = nullptr;       // [nb_cap] first fine bucket of every slot's group
     uint8_t* kshift = nullptr;        // [nb_cap] 32-bit keys: the shift of every bucket's parent group
+    uint8_t* skip = nullptr;          // [nb_cap] buckets that sit out the tile sort and the merge passes (letter-run buckets)
+    uint64_t* run_list = nullptr;     // [1 + 4 * RUN_BUCKET_MAX] the letter-run buckets of a quantile split (run_bucket_mark_kernel)
     uint32_t nb_cap = 0;
     uint64_t tile_cap = 0;
     // buckets of a sort: mean size BUCKET_TARGET (linear maps) or BUCKET_Q (quantile mode), at least two per segment
@@ -234,6 +237,8 @@ Plan<idx_t> make_plan(uint64_t n, uint64_t p_arg, char* base)
     pl.bk.fcount = ar.take<uint64_t>((size_t)EQ_FINE * pl.bk.nb_cap);
     pl.bk.gfirst = ar.take<uint32_t>(pl.bk.nb_cap);
     pl.bk.kshift = ar.take<uint8_t>(pl.bk.nb_cap);
+    pl.bk.skip = ar.take<uint8_t>(pl.bk.nb_cap);
+    pl.bk.run_list = ar.take<uint64_t>(1 + 4 * RUN_BUCKET_MAX);
     pl.pass_elems = ar.take<uint64_t>(kMaxPasses);
     pl.present = ar.take<uint32_t>(16);
     pl.lut = ar.take<uint8_t>(256);
@@ -368,15 +373,16 @@ constexpr uint32_t kSmallScan = 32768;
 #endif
 
 // use_end: the segments sit in fixed-capacity regions (s.seg_end holds their ends)
+// skip: segments that get no tiles (seg_prepare_kernel)
 inline void prepare_segments(Backend& be, const SegBufs& s, uint64_t tile_bound, uint64_t* big_tmp = nullptr,
-                             uint64_t* big_cnt = nullptr, bool use_end = false)
+                             uint64_t* big_cnt = nullptr, bool use_end = false, const uint8_t* skip = nullptr)
 {
     be.memset(s.out2, 0, 2 * sizeof(uint64_t));
     const uint64_t* send = use_end ? s.seg_end : nullptr;
     if (s.G <= kSmallScan || !big_tmp) {
-        CAPS_LAUNCH(seg_prepare_kernel, 1, 1024, be, (const uint64_t*)s.seg_start, send, s.G, s.tile_off, s.out2);
+        CAPS_LAUNCH(seg_prepare_kernel, 1, 1024, be, (const uint64_t*)s.seg_start, send, s.G, s.tile_off, s.out2, skip);
     } else {
-        CAPS_LAUNCH(tile_count_kernel, (s.G + 255) / 256, 256, be, (const uint64_t*)s.seg_start, send, s.G, big_cnt, s.out2);
+        CAPS_LAUNCH(tile_count_kernel, (s.G + 255) / 256, 256, be, (const uint64_t*)s.seg_start, send, s.G, big_cnt, s.out2, skip);
         device_exclusive_scan<uint32_t>(be, big_cnt, s.G, s.tile_off, big_tmp);
         CAPS_LAUNCH(tile_total_kernel, 1, 64, be, (const uint32_t*)s.tile_off, s.G, s.out2);
     }
@@ -396,6 +402,13 @@ template <typename idx_t> struct SortResult {
     bool k32 = false;                                                 // sorted with 32-bit keys (boundary LCPs come from the text)
     bool failed = false;                                              // k32 only: a slot overflowed, nothing was sorted
     SegBufs segs;                                                     // the segments that were sorted (buckets, if bucketed)
+    // letter-run buckets (text.h "letter runs"): they sat out the sort; finalize() orders them by their run keys
+    struct RunBucket { uint64_t s0, s1, key; };
+    std::vector<RunBucket> run_buckets;
+    SegBufs run_tables;                                               // segment tables for their sort (the parents': idle by then)
+    const BucketBufs* run_bk = nullptr;
+    TileDesc* run_desc = nullptr;
+    uint64_t total = 0;                                               // elements of the whole sort (= end of the result arrays)
     uint32_t n_tiles = 0;
     FinalOut<idx_t> fin;                                              // direct final output (may be empty)
     ElemBuf<idx_t> uniform() const { return unified ? buf[0] : buf[passes & 1]; }   // valid when unified or !skip_finished
@@ -431,6 +444,7 @@ struct SortOpts {
                                         //   tile_sort_eq_kernel straight away, tile_sort_kernel's linear map is not tried
     const uint64_t* knots = nullptr;    // non-null (quantile mode): parent q's buckets are (knots[q * KPG + i - 1], knots[q * KPG + i]],
     uint32_t knots_per_parent = 0;      //   i < KPG = knots_per_parent -- count pass + exact scatter, no slots, no equalising
+    bool knots_have_prev = false;       // knots[-1] exists: the slice of a shard that does not own the first group
     const void* runs = nullptr;   // RunSrc<idx_t>*: the segments are partitions still spread over the sorted subarrays in
                                   //   `cur` (requires the bucket split: bk != null and max_len > TILE_E)
     bool unify = false;           // gather the result into buf[0] (consumers that index whole segments)
@@ -482,7 +496,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
             if (NB > bk.nb_cap) throw std::invalid_argument("more knot buckets than the bucket tables hold");
             CAPS_LAUNCH(knot_plan_kernel, (s.G + 255) / 256, 256, be, s.G, o.sub, o.knots_per_parent, bk.params, bk.segB);
             CAPS_LAUNCH(scan_sizes_kernel, 1, 1024, be, (const uint64_t*)bk.segB, s.G, bk.bstart);
-            CAPS_LAUNCH(knot_ranges_kernel, (uint32_t)((NB + 255) / 256), 256, be, o.knots, NB, bk.tile_map);
+            CAPS_LAUNCH(knot_ranges_kernel, (uint32_t)((NB + 255) / 256), 256, be, o.knots, NB, bk.tile_map, o.knots_have_prev ? 1u : 0u);
         } else {
         CAPS_LAUNCH(bucket_plan_kernel, (s.G + 255) / 256, 256, be, (const uint64_t*)s.seg_start, s_end, s.G, o.range_mode, o.pkey, o.part_off,
                     o.part_total ? o.part_total : s.G, 1u, 1u, o.sub,
@@ -527,12 +541,35 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         auto adopt_buckets = [&]() {
             device_exclusive_scan<uint64_t>(be, bk.count, bk.nb_cap, bk.sub.seg_start, bk.scan_tmp);
         };
+        // letter-run buckets (quantile splits of a final sort only): marked on the device, they get no tiles -- the tile sort
+        // and the merge passes never see them -- and finalize() orders them by their run keys (text.h "letter runs")
+        const bool run_buckets = by_knots && o.need_lcp && o.final_sa && bk.skip && !std::getenv("CAPS_SA_NO_RUN_BUCKETS") &&
+                                 n < (1ull << RunKey<(int)sizeof(idx_t)>::RB);
         auto bucket_tiles = [&]() {
             segs = bk.sub;
             segs.G = bk.nb_cap;
-            prepare_segments(be, segs, bk.tile_cap, bk.scan_tmp, bk.count);    // count[] is free again: reuse as scratch
+            uint64_t rl[1 + 4 * RUN_BUCKET_MAX];
+            if (run_buckets) {
+                const uint64_t NB = (uint64_t)(s.G / o.sub) * o.knots_per_parent;
+                be.memset(bk.skip, 0, bk.nb_cap);
+                be.memset(bk.run_list, 0, sizeof(uint64_t));
+                CAPS_LAUNCH(run_bucket_mark_kernel, (uint32_t)((NB + 255) / 256), 256, be, o.knots, NB, o.knots_have_prev ? 1u : 0u, (uint32_t)BITS,
+                            (const uint64_t*)bk.sub.seg_start, bk.skip, bk.run_list);
+            }
+            prepare_segments(be, segs, bk.tile_cap, bk.scan_tmp, bk.count, false, run_buckets ? bk.skip : nullptr);   // count[] is free again: scratch
             be.d2h(out2, segs.out2, sizeof out2);
+            if (run_buckets) be.d2h(rl, bk.run_list, sizeof rl);
             be.sync();
+            if (run_buckets) {
+                const uint64_t cnt = rl[0] < RUN_BUCKET_MAX ? rl[0] : RUN_BUCKET_MAX;
+                for (uint64_t j = 0; j < cnt; ++j) r.run_buckets.push_back({rl[2 + 4 * j], rl[3 + 4 * j], rl[4 + 4 * j]});
+                std::sort(r.run_buckets.begin(), r.run_buckets.end(),
+                          [](const typename SortResult<idx_t>::RunBucket& a, const typename SortResult<idx_t>::RunBucket& b) { return a.s0 < b.s0; });
+                r.run_tables = s;
+                r.run_bk = &bk;
+                r.run_desc = desc;
+                r.total = n_elems;
+            }
         };
         // ---- speculative split: no count pass.  Bucket i gets the fixed slot [i * TILE_E, (i + 1) * TILE_E) of a
         // slot buffer viewed over `oth`; the scatter's cursors end as the exact bucket sizes.  If every bucket fits
@@ -719,6 +756,32 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
     return r;
 }
 
+// The letter-run buckets of a sort (SortResult::run_buckets; text.h "letter runs"): every element gets its run key -- (class of
+// the run's terminator, what is left of the run, the text behind it) -- in place of the key all of them share; an ordinary
+// sort by those keys (tile sort + merge passes whose comparisons are register compares: the text is read only where two
+// runs of one length are followed by the same chars) orders the bucket, run_emit_kernel writes SA and derives the LCPs from
+// the run keys.  Called from finalize(), after the rest of the result is in dSA / dLCP (the buckets' neighbours are read
+// from there) and the bucket tables are idle.
+template <typename idx_t, int BITS>
+void sort_run_buckets(Backend& be, const uint32_t* P, uint64_t n, const SortResult<idx_t>& r, idx_t* dSA, idx_t* dLCP)
+{
+    for (const auto& rb : r.run_buckets) {
+        const uint64_t len = rb.s1 - rb.s0;
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((len + 255) / 256, 4096);
+        SegBufs t = r.run_tables;
+        t.G = 1;
+        t.seg_end = nullptr;
+        CAPS_LAUNCH(segment_range_kernel, 1, 64, be, t.seg_start, rb.s0, rb.s1);
+        prepare_segments(be, t, tiles_of(len));
+        CAPS_LAUNCH((run_rekey_kernel<idx_t, BITS>), grid, 256, be, P, n, rb.s0, rb.s1, rb.key, r.buf[0].key, (const idx_t*)r.buf[0].sa);
+        SortOpts o;                                   // order only: the LCPs come from the run keys
+        const SortResult<idx_t> rr = segmented_sort<idx_t, BITS>(be, P, n, r.run_desc, t, tiles_of(len), len, r.buf[0], r.buf[1], len, o);
+        const ElemBuf<idx_t> res = rr.uniform();
+        CAPS_LAUNCH((run_emit_kernel<idx_t, BITS>), grid, 256, be, P, n, rb.s0, rb.s1, r.total, (const uint64_t*)res.key, (const idx_t*)res.sa,
+                    dSA, dLCP);
+    }
+}
+
 // Gather SA/LCP of a sorted segment set into the caller's arrays + segment-head LCPs (a11).
 // With boundary records (r.fin) only the segments that needed merge passes are still to be
 // copied; the heads are then fixed from the records.
@@ -732,6 +795,7 @@ void finalize(Backend& be, const uint32_t* P, uint64_t n, const SortResult<idx_t
     if (r.fin.sa != nullptr)
         CAPS_LAUNCH((head_lcp_kernel<idx_t, BITS>), (r.segs.G + 255) / 256, 256, be, P, n, (const uint64_t*)r.segs.seg_start, r.segs.G,
                     r.fin, r.k32 ? 1u : 0u);
+    if (!r.run_buckets.empty()) sort_run_buckets<idx_t, BITS>(be, P, n, r, dSA, dLCP);
 }
 
 // Shape of the direct path's two-level distribution: PG consecutive partitions per group, K1 groups.  Level A
@@ -794,7 +858,7 @@ private:
     uint32_t passes1_ = 0, passes2_ = 0, passesS_ = 0;
     BackendEvent e2_, e3_, e4_, e5_, e6_, e7_, la0_, la1_;
     uint64_t max_part_ = 0;
-    uint32_t path_direct_ = 0, path_fallback_ = 0, direct_groups_ = 0, direct_quantile_ = 0, direct_k32_ = 0;
+    uint32_t path_direct_ = 0, path_fallback_ = 0, direct_groups_ = 0, direct_quantile_ = 0, direct_k32_ = 0, run_buckets_ = 0;
     uint64_t direct_max_group_ = 0;
 
     // timed: the full-size sorts (phase 1, phase 2) feed the kernel clocks of caps_sa_stats;
@@ -1127,6 +1191,7 @@ private:
         SortResult<idx_t> r2 = seg_sort<BITS>(groups, n_tiles2, max_part_, pl_.A, pl_.B, n, o2, true);
         if (r2.failed) return run_direct<BITS>(dSA, dLCP, PG, K1, e1, false);      // a slot overflowed under 32-bit keys: again with 64
         passes2_ = r2.passes;
+        run_buckets_ = (uint32_t)r2.run_buckets.size();
         e6_ = be_.record();
         finalize<idx_t, BITS>(be_, pl_.P, n, r2, dSA, dLCP);
         e7_ = be_.record();
@@ -1208,6 +1273,7 @@ private:
             st->path_fallback = path_fallback_;
             st->direct_groups = direct_groups_;
             st->direct_quantile = direct_quantile_;
+            st->run_buckets = run_buckets_;
             st->direct_key_bits = path_direct_ && direct_k32_ ? 32u : 64u;
             st->direct_max_group = direct_max_group_;
             st->level_a_ms = direct_groups_ ? be_.elapsed_ms(la0_, la1_) : 0.0;

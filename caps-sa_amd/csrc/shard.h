@@ -178,7 +178,7 @@ public:
                                               local_ ? ((uint64_t)K1_ + world_ - 1) / world_ * SUB_ * capA_ : (uint64_t)n_streams_ * capA_);
         o->exchange = direct_fb_ == CAPS_SA_FB_NONE && local_ ? 0u : 1u;
         o->direct_quantile = quantile_ ? 1u : 0u;
-        o->reserved_ = 0;
+        o->run_buckets = run_buckets_;
         o->ms_scatter = ms_scatter_; o->ms_sort = ms_sort_;
         o->key_bytes = key_bits_ / 8;
         o->ms_level_a = ms_level_a_; o->ms_level_b = ms_level_b_ + ms_count_; o->ms_tile_sort = ms_tile_sort_; o->ms_merge_passes = ms_merge_;
@@ -536,6 +536,7 @@ private:
     uint64_t s_ = 0, text_base_ = 0, local_n_ = 0, m_local_ = 0, m_total_ = 0, recv_total_ = 0, slice_off_ = 0, max_len2_ = 0;
     int bits_ = 0;
     uint32_t slot_stats_[2] = {0, 0};    // bucket splits of the current build: kept with slots / redone
+    uint32_t run_buckets_ = 0;           // letter-run buckets of the last sort_owned (text.h "letter runs")
     uint32_t* P_ = nullptr;
     uint32_t* present_ = nullptr;
     uint8_t* lut_ = nullptr;
@@ -677,6 +678,7 @@ private:
         if (quantile_) {                          // the owned groups' buckets are (knots[k - 1], knots[k]], KPG per group
             o.knots = knots_ + (size_t)jlo_ * KPG_;
             o.knots_per_parent = KPG_;
+            o.knots_have_prev = jlo_ > 0;                 // bucket 0 of the slice starts above the previous group's last knot
             o.skewed_keys = skewed_ && !std::getenv("CAPS_SA_TRY_LINEAR_TILES");
         }
         KernelClock tile_clock, scatter_clock, count_clock, merge_clock;
@@ -686,6 +688,7 @@ private:
         o.merge_clock = &merge_clock;
         SortResult<idx_t> r = segmented_sort<idx_t, BITS>(be_, P_, n_, tdesc_, seg2_, n_tiles2_, max_len2_, A_, B_, recv_total_, o);
         clocks_ = {tile_clock, scatter_clock, count_clock, merge_clock};
+        run_buckets_ = (uint32_t)r.run_buckets.size();
         if (r.failed) return false;
         finalize<idx_t, BITS>(be_, P_, n_, r, static_cast<idx_t*>(dSA), static_cast<idx_t*>(dLCP));
         return true;
@@ -784,6 +787,8 @@ private:
         k.fcount = get<uint64_t>((size_t)EQ_FINE * k.nb_cap);
         k.gfirst = get<uint32_t>(k.nb_cap);
         k.kshift = get<uint8_t>(k.nb_cap);
+        k.skip = get<uint8_t>(k.nb_cap);
+        k.run_list = get<uint64_t>(1 + 4 * RUN_BUCKET_MAX);
         return k;
     }
 };

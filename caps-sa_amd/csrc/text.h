@@ -294,6 +294,80 @@ HD uint32_t tie_order_lcp_bounded(const uint32_t* __restrict__ P, uint64_t n, ui
 }
 static_assert(64 / 2 + TIE_WINDOWS * (64 / 2) < (1u << 15) && 64 / 8 + TIE_WINDOWS * (64 / 8) < (1u << 15), "bounded tie lcps fit 15 bits");
 
+// ---- letter runs (N-blocks: the CLI maps N to G, src/main.cpp:61-68): order WITHOUT comparing ------------------------
+// Every suffix whose key is one letter c repeated (key = c^KCH) lies in a maximal run of c that ends at e (T[e] != c, or
+// e = n); r = e - position is what is left of the run.  Two such suffixes a, b with r_a < r_b differ at offset r_a, where a
+// shows its terminator T[e_a] and b another c: a < b iff T[e_a] < c (or e_a = n: a is a prefix of b).  With r_a = r_b the
+// text behind the runs decides.  So among the suffixes of key c^KCH the suffix order is the order of
+//     (terminator < c ? 0 : 1,   r ascending in class 0 / descending in class 1,   T[e ..))
+// and their LCPs are min(r_a, r_b), or r + lcp(T[e_a ..), T[e_b ..)) when the r are equal.  run_key() packs (class, r, the
+// first chars behind the run) into 64 bits: sorting a bucket that holds only such suffixes (a frequent key's own bucket,
+// kernels.h run_bucket_mark_kernel) by these keys needs the text only where two runs of one length are followed by the
+// same RUN_FLANK bits -- instead of ~50 run-table comparisons per element and LCP-merge pass (12 passes, 58 of the 216 ms of
+// the genome-like text with N-block stand-ins at n = 3e9).  The reference compares such suffixes char by char
+// (include/Suffix_Array.hpp:195-241: 32-byte blocks).
+template <int BITS> HD uint64_t letter_pattern(uint32_t c)          // the key c^KCH
+{
+    uint64_t p = c;
+    for (uint32_t s = BITS; s < 64; s <<= 1) p |= p << s;
+    return p;
+}
+template <int BITS> HD bool is_letter_key(uint64_t key)
+{
+    return key == letter_pattern<BITS>((uint32_t)(key >> (64 - BITS)));
+}
+
+// End e of the run of the letter of `key` (= c^KCH: the key of suffix pos) that holds pos: pos < e <= n.
+template <int BITS>
+HD uint64_t letter_run_end(const uint32_t* __restrict__ P, uint64_t n, uint64_t pos, uint64_t key)
+{
+    constexpr uint32_t KCH = TextTraits<BITS>::KCH;
+    const uint64_t* __restrict__ R = run_table(P, n);
+    uint64_t x = pos + KCH;                                     // chars [pos, x) are c (or lie past the end: code 0 = c)
+    while (x < n) {
+        const uint64_t w = window64<BITS>(P, x);
+        if (w != key) { x += (uint32_t)caps_clz64(w ^ key) / BITS; break; }
+        // 2 * KCH chars from x - KCH on are c: the aligned block that starts in [x - KCH, x) lies inside them
+        const uint64_t rb = R[(x - 1) / KCH];
+        if ((rb >> 56) == 1u) { x = rb & RUN_POS_MASK; break; }
+        x += KCH;                                               // (a block that reaches past the text has no entry: walk on)
+    }
+    return x < n ? x : n;
+}
+
+// idx_t-wide texts: r < 2^RB.  key = class << 63 | (class ? 2^RB - 1 - r : r) << FB | first FB bits behind the run
+template <int IDX_BYTES> struct RunKey {
+    static constexpr uint32_t RB = IDX_BYTES == 4 ? 32 : 40;
+    static constexpr uint32_t FB = 63 - RB;
+    static constexpr uint64_t RMASK = (1ull << RB) - 1;
+};
+template <int IDX_BYTES, int BITS>
+HD uint64_t run_key(const uint32_t* __restrict__ P, uint64_t n, uint64_t pos, uint64_t key)
+{
+    using RK = RunKey<IDX_BYTES>;
+    const uint64_t e = letter_run_end<BITS>(P, n, pos, key);
+    const uint64_t r = e - pos;
+    if (e >= n) return r << RK::FB;                             // the text ends with the run: a prefix of the longer ones
+    const uint64_t w = window64<BITS>(P, e);
+    const uint64_t cls = (w >> (64 - BITS)) < (key >> (64 - BITS)) ? 0u : 1u;
+    return (cls << 63) | ((cls ? RK::RMASK - r : r) << RK::FB) | (w >> (64 - RK::FB));
+}
+template <int IDX_BYTES> HD uint64_t run_key_r(uint64_t rk)
+{
+    using RK = RunKey<IDX_BYTES>;
+    const uint64_t f = (rk >> RK::FB) & RK::RMASK;
+    return (rk >> 63) ? RK::RMASK - f : f;
+}
+// lcp of two distinct suffixes a, b of one letter key from their run keys (text only when both runs have one length)
+template <int IDX_BYTES, int BITS>
+HD uint64_t run_pair_lcp(const uint32_t* __restrict__ P, uint64_t n, uint64_t ka, uint64_t a, uint64_t kb, uint64_t b)
+{
+    const uint64_t ra = run_key_r<IDX_BYTES>(ka), rb = run_key_r<IDX_BYTES>(kb);
+    if (ra != rb) return ra < rb ? ra : rb;
+    if (a + ra >= n || b + rb >= n) return ra;
+    return ra + deep_lcp<BITS, true>(P, n, a + ra, b + rb, 0);
+}
+
 // Strict total order on suffixes: true iff suffix a sorts before suffix b.
 // (a == b -> false.)  Shorter suffix first when one is a prefix of the other.
 template <int BITS, bool RUNS = true>

@@ -76,7 +76,8 @@ typedef struct caps_sa_stats {
     uint64_t direct_max_group;     /* largest stream of a group (elements) */
     double level_a_ms;             /* direct path: the text -> groups scatter (also counted in bucket_scatter_ms) */
     uint32_t direct_key_bits;      /* key bits that travelled with every suffix through the direct path's passes: 64, or 32 */
-    uint32_t reserved_;
+    uint32_t run_buckets;          /* buckets of ONE single-letter key (the suffixes deep inside N-blocks) that were ordered by
+                                      (terminator class, rest of the run, text behind it) instead of being compared: csrc/text.h */
 } caps_sa_stats;
 
 #define CAPS_SA_FB_NONE 0
@@ -252,7 +253,7 @@ typedef struct caps_sa_shard_info {
                                       scattered the whole text and kept its own groups; shard_sort reads the send buffers */
     uint32_t direct_quantile;      /* 1: the last shard_scatter chose quantile buckets for level B (skewed keys, frequent keys, long
                                       runs; csrc/pipeline.h Builder::run_direct) -- no-exchange mode only */
-    uint32_t reserved_;
+    uint32_t run_buckets;          /* letter-run buckets of the last shard_sort (see caps_sa_stats.run_buckets) */
 } caps_sa_shard_info;
 
 int caps_sa_hip_shard_create(const void* dT, uint64_t n, uint64_t subproblem_count, int idx_bytes, int rank, int world,

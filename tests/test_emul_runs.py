@@ -82,3 +82,48 @@ def test_stretch_ends_at_every_offset_of_a_block():
         for off in range(0, 33, 3):
             parts += [rs.choice(DNA, size=40 + off), np.tile(unit, (1100 + 7 * off) // d + 1)[:1100 + 7 * off]]
         _chk(E, np.concatenate(parts), 3, long_runs=True)
+
+
+def _n_block_text(rs, scale):
+    """Random DNA with runs of every letter (A = the code of the end-of-text padding), one of them at the end of the text,
+    two G runs of one length followed by the same 40 chars, and a run shorter than a tile."""
+    n = 20000 * scale
+    T = rs.choice(DNA, size=n)
+    for at, ln, c in ((1000, 1500, "G"), (5000, 700, "G"), (9000, 900, "A"), (12000, 800, "T"), (15000, 500, "C")):
+        T[at * scale:(at + ln) * scale] = ord(c)
+    T[n - 600 * scale:] = ord("A")
+    fl = rs.choice(DNA, size=40)
+    fl[0] = ord("A")
+    for a in (17000 * scale, 18000 * scale):
+        T[a:a + 400 * scale] = ord("G")
+        T[a + 400 * scale:a + 400 * scale + 40] = fl
+    T[300:300 + 90] = ord("G")
+    return T
+
+
+@pytest.mark.parametrize("which", ["big", "small"])
+def test_letter_run_buckets_order_n_blocks_without_comparing(which, monkeypatch):
+    """text.h "letter runs": the suffixes deep inside single-letter runs (N-blocks: the CLI maps N to G, src/main.cpp:61-68)
+    get a bucket of their own and are ordered by (terminator class, rest of the run, text behind it); the LCP-merge passes
+    they used to need are gone.  Same arrays with the buckets switched off; 64-bit indices; 8-bit codes."""
+    E = emul() if which == "big" else emul_small()
+    scale = 16 if which == "big" else 1
+    T = _n_block_text(np.random.RandomState(3), scale)
+    for p in (0, 64):
+        st = _chk(E, T, p, long_runs=True)
+        assert st["path_direct"] == 1 and st["direct_quantile"] == 1 and st["run_buckets"] >= 3, st
+        assert st["merge_passes_phase2"] <= 1
+    st64 = _chk(E, T, 0, bits=64, long_runs=True)
+    assert st64["run_buckets"] >= 3
+    monkeypatch.setenv("CAPS_SA_NO_RUN_BUCKETS", "1")
+    st0 = _chk(E, T, 0, long_runs=True)
+    assert st0["run_buckets"] == 0 and st0["merge_passes_phase2"] >= 2
+    monkeypatch.delenv("CAPS_SA_NO_RUN_BUCKETS")
+    # 8-bit codes: runs of the smallest byte (0x80: the padding code), of the largest, and of a letter in between
+    B = rs_bytes = np.random.RandomState(5).choice(np.array([0x80, 0x41, 0x61, 0x7F, 0xFF, 0x00], dtype=np.uint8), size=20000 * scale)
+    for at, ln, c in ((2000, 1200, 0x80), (6000, 1000, 0x7F), (10000, 1100, 0x61)):
+        B[at * scale:(at + ln) * scale] = c
+    B[B.size - 500 * scale:] = 0x80
+    st8 = _chk(E, B, 0, long_runs=True)
+    assert st8["bits_per_char"] == 8
+    assert st8["run_buckets"] >= 1 or st8["path_direct"] == 0, st8
