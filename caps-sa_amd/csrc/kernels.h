@@ -2296,8 +2296,10 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_count_kernel(KCTX SegDesc sd, const uint
                                                      uint64_t text_base, const uint64_t* __restrict__ in_key, RunSrc<idx_t> rsrc,
                                                      const BucketParams* __restrict__ bps, const uint64_t* __restrict__ bstart,
                                                      uint64_t* __restrict__ count, const uint64_t* __restrict__ split,
-                                                     uint32_t split_stride, uint32_t in_sub)
+                                                     uint32_t split_stride, uint32_t in_sub, uint16_t* __restrict__ bid)
 {
+    // bid (MAP_SPLIT, optional): bid[element] = its bucket inside the parent -- the scatter that follows reads it back
+    // instead of searching the knots again (10 dependent LDS reads per suffix, as much as everything else it does)
     constexpr bool FROM_TEXT = SRC == SRC_TEXT, FROM_RUNS = SRC == SRC_RUNS;
     SHARED_ARRAY(uint32_t, hist, BUCKET_LDS);
     SHARED_ARRAY(uint64_t, stab, MAP == MAP_SPLIT ? BUCKET_LDS : 1);
@@ -2379,6 +2381,7 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_count_kernel(KCTX SegDesc sd, const uint
                 if (e < cnt) {
                     if (lds) FETCH_ADD_U32(&hist[bk[k]], 1u);
                     else ATOMIC_ADD_U64(&count[b0 + bk[k]], 1ull);
+                    if (MAP == MAP_SPLIT && bid && lds) bid[start + e] = (uint16_t)bk[k];
                 }
             }
         }
@@ -2411,7 +2414,7 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
                                                        const BucketParams* __restrict__ fbps, const uint32_t* __restrict__ gfirst,
                                                        const uint64_t* __restrict__ split, const uint16_t* __restrict__ split_lut,
                                                        const uint32_t* __restrict__ split_span, uint32_t sub, uint32_t split_stride,
-                                                       uint32_t in_sub)
+                                                       uint32_t in_sub, const uint16_t* __restrict__ bid)
 {
     // sub > 1 (slots only; level A of the direct path): bucket i owns `sub` slots, one per sub-stream; the tiles of a
     // launch are dealt to the sub-streams round-robin by block index, i.e. (observed dispatch order, MI355X_MICROARCH
@@ -2479,7 +2482,7 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
     if (lds || FROM_TEXT || FROM_RUNS) {
         PAR(tid) {
             if (lds) for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0;
-            if (MAP == MAP_SPLIT && lds) {
+            if (MAP == MAP_SPLIT && lds && !bid) {
                 for (uint32_t i = tid; i < n_split; i += K_BLOCK_DIM) stab[i] = tab[i];
                 if (split_lut) for (uint32_t i = tid; i <= SPLIT_LUT_CELLS; i += K_BLOCK_DIM) slut[i] = split_lut[i];
             }
@@ -2494,7 +2497,22 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
         }
         SYNC();
     }
-    if (MAP == MAP_SPLIT && lds) {
+    if (MAP == MAP_SPLIT && lds && bid) {
+        // the count pass has left every element's bucket (bucket_count_kernel): no table, no search
+        PAR(tid) {
+            UNROLL
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                const uint32_t e = tid + k * TILE_NT;
+                if (e < cnt) {
+                    const uint32_t bk = bid[start + e];
+                    TL(rk, tid, k) = in_key[start + e];
+                    TL(rs, tid, k) = in_sa[start + e];
+                    TL(rb, tid, k) = bk;
+                    TL(rr, tid, k) = FETCH_ADD_U32(&hist[bk], 1u);
+                }
+            }
+        }
+    } else if (MAP == MAP_SPLIT && lds) {
         // keys first, then the TILE_EPT table searches of a thread in lockstep (independent LDS reads in flight together)
         // depth of the search: the candidates per LUT cell (block-uniform), or all of the table without a LUT
         const uint32_t top = pow2_above(split_lut ? split_span[0] : n_split);

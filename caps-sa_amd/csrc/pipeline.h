@@ -445,6 +445,9 @@ struct SortOpts {
     const uint64_t* knots = nullptr;    // non-null (quantile mode): parent q's buckets are (knots[q * KPG + i - 1], knots[q * KPG + i]],
     uint32_t knots_per_parent = 0;      //   i < KPG = knots_per_parent -- count pass + exact scatter, no slots, no equalising
     bool knots_have_prev = false;       // knots[-1] exists: the slice of a shard that does not own the first group
+    uint64_t in_extent = 0;             // one past the largest element index of in_key / in_sa (0: unknown).  Quantile splits then
+                                        //   keep every element's bucket id between the count pass and the scatter (u16 per element, in
+                                        //   the idle LCP array of the scatter's destination) instead of searching the knots twice
     const void* runs = nullptr;   // RunSrc<idx_t>*: the segments are partitions still spread over the sorted subarrays in
                                   //   `cur` (requires the bucket split: bk != null and max_len > TILE_E)
     bool unify = false;           // gather the result into buf[0] (consumers that index whole segments)
@@ -516,6 +519,14 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         // where the elements are read from (SRC_ARRAYS / SRC_RUNS): `cur`, unless the caller keeps them elsewhere
         const uint64_t* src_key = o.in_key ? o.in_key : (const uint64_t*)cur.key;
         const idx_t* src_sa = o.in_key ? static_cast<const idx_t*>(o.in_sa) : (const idx_t*)cur.sa;
+        // bucket ids kept between count and scatter (quantile splits of arrays): in the LCP array of the scatter's destination
+        // (`oth`: nothing writes LCPs there before the scatter has read the ids back)
+        uint16_t* bid = nullptr;
+        if (by_knots && o.in_extent && !from_text && !o.runs && oth.region_bytes && !std::getenv("CAPS_SA_NO_BUCKET_IDS")) {
+            const size_t room = (size_t)((reinterpret_cast<char*>(oth.key) + oth.region_bytes) - reinterpret_cast<char*>(oth.lcp));
+            const uint64_t extent = o.in_key ? o.in_extent : n_elems;
+            if (room >= extent * sizeof(uint16_t)) bid = reinterpret_cast<uint16_t*>(oth.lcp);
+        }
         auto scatter = [&](const uint64_t* sub_start, uint32_t cap, uint64_t* okey, idx_t* osa, bool grouped = false) {
             const BucketParams* fbps = grouped ? bk.fparams : nullptr;
             const uint32_t* gfirst = grouped ? bk.gfirst : nullptr;
@@ -523,7 +534,8 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
 #define CAPS_SCATTER_LAUNCH(SRC_, MAP_, ikey, isa)                                                                          \
             CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, SRC_, MAP_>), n_tiles, TILE_NT, be, psd, P, n_words, tbase, ikey, isa, rsrc, \
                         (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, sub_start, (uint64_t)cap, static_cast<idx_t*>(bk.cursor),       \
-                        okey, osa, fbps, gfirst, o.knots, (const uint16_t*)nullptr, (const uint32_t*)nullptr, 1u, o.knots_per_parent, o.sub)
+                        okey, osa, fbps, gfirst, o.knots, (const uint16_t*)nullptr, (const uint32_t*)nullptr, 1u, o.knots_per_parent, o.sub, \
+                        (const uint16_t*)bid)
             const uint64_t* nokey = nullptr;
             const idx_t* nosa = nullptr;
             if (from_text) { if (grouped) CAPS_SCATTER_LAUNCH(SRC_TEXT, MAP_GROUPED, nokey, nosa); else CAPS_SCATTER_LAUNCH(SRC_TEXT, MAP_LINEAR, nokey, nosa); }
@@ -597,7 +609,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
                             (uint64_t)0, reinterpret_cast<const uint32_t*>(o.in_key), src_sa, rsrc, (const BucketParams*)bk.params,
                             (const uint64_t*)bk.bstart, (const uint64_t*)nullptr, (uint64_t)TILE_E, static_cast<idx_t*>(bk.cursor),
                             reinterpret_cast<uint32_t*>(slot_key), slot_sa, (const BucketParams*)nullptr, (const uint32_t*)nullptr,
-                            (const uint64_t*)nullptr, (const uint16_t*)nullptr, (const uint32_t*)nullptr, 1u, 0u, 1u);
+                            (const uint64_t*)nullptr, (const uint16_t*)nullptr, (const uint32_t*)nullptr, 1u, 0u, 1u, (const uint16_t*)nullptr);
                 BackendEvent s1 = be.record();
                 if (o.scatter_clock) { o.scatter_clock->spans.push_back({s0, s1}); o.scatter_clock->elems.push_back(n_elems); }
             } else
@@ -634,16 +646,16 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
             const uint64_t* no_tab = nullptr;
             if (from_text)
                 CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, SRC_TEXT>), pgrid, TILE_NT, be, psd, P, n_words, tbase, (const uint64_t*)nullptr, rsrc,
-                            cparams, cstart, ccount, no_tab, 0u, 1u);
+                            cparams, cstart, ccount, no_tab, 0u, 1u, (uint16_t*)nullptr);
             else if (runs)
                 CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, SRC_RUNS>), pgrid, TILE_NT, be, psd, P, n_words, tbase, src_key, rsrc,
-                            cparams, cstart, ccount, no_tab, 0u, 1u);
+                            cparams, cstart, ccount, no_tab, 0u, 1u, (uint16_t*)nullptr);
             else if (by_knots)
                 CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, SRC_ARRAYS, MAP_SPLIT>), pgrid, TILE_NT, be, psd, P, n_words, tbase, src_key, rsrc,
-                            cparams, cstart, ccount, o.knots, o.knots_per_parent, o.sub);
+                            cparams, cstart, ccount, o.knots, o.knots_per_parent, o.sub, bid);
             else
                 CAPS_LAUNCH((bucket_count_kernel<idx_t, BITS, SRC_ARRAYS>), pgrid, TILE_NT, be, psd, P, n_words, tbase, src_key, rsrc,
-                            cparams, cstart, ccount, no_tab, 0u, 1u);
+                            cparams, cstart, ccount, no_tab, 0u, 1u, (uint16_t*)nullptr);
             if (equalise) {
                 CAPS_LAUNCH(bucket_group_kernel, s.G < 16384 ? (s.G ? s.G : 1) : 16384, 256, be, s.G, (const uint64_t*)bk.segB, (const uint64_t*)bk.bstart,
                             (const uint64_t*)bk.fsegB, (const uint64_t*)bk.fstart, (const uint64_t*)bk.fcount, bk.count, bk.gfirst);
@@ -1147,7 +1159,7 @@ private:
                             packed_words(n, BITS), (uint64_t)0, (const uint64_t*)nullptr, (const idx_t*)nullptr, RunSrc<idx_t>(),
                             (const BucketParams*)pl_.bk.params, (const uint64_t*)pl_.bk.bstart, (const uint64_t*)nullptr, capA,
                             pl_.dcur, a_key, a_sa, (const BucketParams*)nullptr, (const uint32_t*)nullptr,
-                            (const uint64_t*)pl_.gkey, (const uint16_t*)pl_.glut, (const uint32_t*)(dflag + 1), SUB, 0u, 1u);
+                            (const uint64_t*)pl_.gkey, (const uint16_t*)pl_.glut, (const uint32_t*)(dflag + 1), SUB, 0u, 1u, (const uint16_t*)nullptr);
             BackendEvent s1 = be_.record();
             scatter_clock_.spans.push_back({s0, s1});
             scatter_clock_.elems.push_back(n);
@@ -1182,7 +1194,7 @@ private:
         o2.part_total = K1;
         o2.sub = SUB;
         o2.seg_ends = true;
-        if (quantile) { o2.knots = pl_.knots; o2.knots_per_parent = KPG; }
+        if (quantile) { o2.knots = pl_.knots; o2.knots_per_parent = KPG; o2.in_extent = (uint64_t)n_streams * capA; }
         o2.skewed_keys = quantile && probe[2] != 0 && !std::getenv("CAPS_SA_TRY_LINEAR_TILES");   // (the variable: measurement)
         if (k32) { o2.k32 = true; o2.range_mode = 2; o2.gshift = pl_.gshift; }
         o2.in_key = a_key;

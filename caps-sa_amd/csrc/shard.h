@@ -679,6 +679,7 @@ private:
             o.knots = knots_ + (size_t)jlo_ * KPG_;
             o.knots_per_parent = KPG_;
             o.knots_have_prev = jlo_ > 0;                 // bucket 0 of the slice starts above the previous group's last knot
+            o.in_extent = ((uint64_t)K1_ + world_ - 1) / world_ * SUB_ * capA_;   // the owned streams' regions fit this (scatter_bits)
             o.skewed_keys = skewed_ && !std::getenv("CAPS_SA_TRY_LINEAR_TILES");
         }
         KernelClock tile_clock, scatter_clock, count_clock, merge_clock;
