@@ -27,8 +27,13 @@ for _p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tools")):
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 WORKLOADS = {
     # name: (bases, kind, description)
-    "c3": (3_000_000_000, "uniform", "C3: 3e9 random DNA bases + remapped trailing newline, u32 indices, p=8000"),
-    "c2": (268_435_456, "uniform", "C2: 256 Mi random DNA bases + remapped trailing newline, u32 indices, p=8000"),
+    # "uniform" = the reference's generator itself: utils/gen_rand_seq.py <seed> <N> (CPython's MT19937 stream, reproduced bit for bit by
+    # caps_sa_hip_gen_rand_seq) + the newline its print() appends, which the CLI remaps to 'C' (src/main.cpp:61-70) -- SURVEY 8d's inputs
+    "c3": (3_000_000_000, "uniform", "C3: gen_rand_seq.py 42 3000000000 (MT19937 stream) + remapped trailing newline, u32 indices, p=8000"),
+    "c2": (268_435_456, "uniform", "C2: gen_rand_seq.py 42 268435456 (MT19937 stream) + remapped trailing newline, u32 indices, p=8000"),
+    # the same shapes from torch.randint (Philox): what rounds 1 and 2 benched; statistically the same text
+    "c3t": (3_000_000_000, "uniform-torch", "3e9 random DNA bases (torch.randint) + remapped trailing newline, u32 indices, p=8000"),
+    "c2t": (268_435_456, "uniform-torch", "256 Mi random DNA bases (torch.randint) + remapped trailing newline, u32 indices, p=8000"),
     # GRCh38 is not available offline: order-5 Markov chain with Dirichlet(0.5) transitions + 2 % planted mutated
     # repeats (tools/genome_like.py, seeded), and the same with N-block stand-ins (the CLI maps N to G: src/main.cpp:61-68)
     "g3": (3_000_000_000, "genome", "genome-like (tools/genome_like.py seed 7): 3e9 bases, u32 indices, p=8000"),
@@ -39,7 +44,7 @@ WORKLOADS = {
     "g3r": (3_000_000_000, "genome+r", "genome-like + satellite arrays, 1e5-copy 300-base family, segmental duplications: 3e9 bases, u32, p=8000"),
     "g2r": (268_435_456, "genome+r", "genome-like + satellite arrays, repeat family, segmental duplications: 256 Mi bases, u32, p=8000"),
     # BASELINE config 4's shape: needs --gpus 8 (one GPU cannot hold a whole build of it; tools/shard_probe.py c4 times one rank)
-    "c4": (8 << 30, "uniform", "C4: 8 Gi random DNA bases + remapped trailing newline, u64 indices, p=8000 (multi-GPU only)"),
+    "c4": (8 << 30, "uniform", "C4: gen_rand_seq.py 42 8589934592 + remapped trailing newline, u64 indices, p=8000 (multi-GPU only)"),
 }
 
 
@@ -61,6 +66,19 @@ def make_text(torch, n_bases, seed, device, kind="uniform"):
             from genome_like import plant_genome_repeats
             plant_genome_repeats(T, n_bases)
         T[n - 1] = ord("C")
+        return T
+    if kind == "uniform":
+        # host generator into page-locked memory (already touched: fresh pageable pages cost 3 x the generator itself), one copy up
+        import caps_sa_amd
+        L = caps_sa_amd.lib()
+        raw = L.pinned_empty(n, "uint8") if device.type == "cuda" else __import__("numpy").empty(n, dtype="uint8")
+        L.gen_rand_seq(seed, n_bases, raw)
+        raw[n - 1] = ord("C")
+        T = torch.empty(n, dtype=torch.uint8, device=device)
+        T.copy_(torch.from_numpy(raw))
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+        del raw
         return T
     g = torch.Generator(device=device)
     g.manual_seed(seed)
@@ -96,6 +114,18 @@ def cpu_baseline(T_dev, n_sample, p, n_full):
     }
 
 
+def kernel_sources_sha256():
+    """Hash of the sources the kernels are built from: profiles/traffic.json carries the hash of the build its PMC passes
+    profiled, and its figures are used only while the two agree (the GPU box has no git history to compare commits with)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "caps-sa_amd", "csrc")
+    for f in ("kernel_lang.h", "text.h", "kernels.h", "pipeline.h"):
+        with open(os.path.join(d, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def roofline(kernels, w, traffic_key):
     """kernels: {family: (ms summed over its launches, launches, elements summed)} over the timed steps.
     Every family is one streaming pass over the suffixes; algorithmic bytes = 4w per suffix (read + write of an SA- and
@@ -108,10 +138,16 @@ def roofline(kernels, w, traffic_key):
         "tile_sort_kernel": (8 + w) + 2 * w,                     # (key, sa) in, SA + LCP out
         "merge_pass_kernel": 2 * (8 + w),
     }
-    traffic = {}
+    traffic, traffic_note = {}, "no profiles/traffic.json"
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            traffic = json.load(f).get(traffic_key, {})
+            tj = json.load(f)
+        if tj.get("kernel_sources_sha256") == kernel_sources_sha256():
+            traffic = tj.get(traffic_key, {})
+            traffic_note = "profiles/traffic.json (rocprofv3 PMC passes of this build and workload, FETCH_SIZE x2 + WRITE_SIZE; tools/pmc_traffic.py)"
+        else:
+            traffic_note = ("profiles/traffic.json was measured on other kernel sources (its kernel_sources_sha256 differs): not used; "
+                            "re-run tools/pmc.sh + tools/pmc_traffic.py")
     except OSError:
         pass
     rows = {}
@@ -133,7 +169,7 @@ def roofline(kernels, w, traffic_key):
             "traffic": d["traffic"], "avg_launch_ms": d["avg_launch_ms"],
             "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
             "moved_bytes_per_launch_incl_keys": d["moved_bytes_per_launch_incl_keys"],
-            "traffic_source": "profiles/traffic.json (rocprofv3 PMC passes of this workload, FETCH_SIZE x2 + WRITE_SIZE)",
+            "traffic_source": traffic_note,
             "kernels": rows}
 
 
@@ -151,6 +187,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-verify", action="store_true", help="skip the device verifier after the timed steps")
     ap.add_argument("--verify", action="store_true", help="(default; kept for old command lines)")
     ap.add_argument("--no-host-path", action="store_true", help="skip timing the host-buffer entry point (PCIe inclusive)")
+    ap.add_argument("--shard-mode", default="auto", choices=["local", "exchange", "auto"],
+                    help="N > 1: how the direct path is sharded (caps_sa_dist.bench_main); auto times both in the warm-up and keeps the faster")
+    ap.add_argument("--text-file", default="", help="read the workload's text from this .npy file (tools/make_text.py wrote it) instead of "
+                    "generating it: the genome-like generators launch ~1e6 tiny kernels, which rocprofv3 --pmc does not survive")
     return ap.parse_args(argv)
 
 
@@ -186,7 +226,12 @@ def main():
         n_bases, desc = args.bases, f"custom: {args.bases} bases of kind {kind} + remapped newline, p={args.p}"
     n = n_bases + 1
     idx_bits = 32 if n <= 0xFFFFFFFF else 64
-    T = make_text(torch, n_bases, args.seed, dev, kind)
+    if args.text_file:
+        import numpy as np
+        T = torch.from_numpy(np.load(args.text_file, mmap_mode="r")[:n].copy()).to(dev)
+        assert T.numel() == n, "the text file belongs to another workload"
+    else:
+        T = make_text(torch, n_bases, args.seed, dev, kind)
     dt = torch.int32 if idx_bits == 32 else torch.int64
     SA = torch.empty(n, dtype=dt, device=dev)
     LCP = torch.empty(n, dtype=dt, device=dev)
@@ -244,6 +289,8 @@ def main():
                    "max_partition": last["max_partition"], "workspace": "preallocated",
                    "workspace_gb": ws_bytes / 1e9, "parallelism": "1 GPU"},
         "phases_ms": phases,
+        "whole_build_floor": {"bytes": (1 + 2 * w) * n, "frac_of_peak": (1 + 2 * w) * n / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "note": "compulsory traffic (read T once, write SA and LCP once) / ms_per_step / 8 TB/s"},
         "bytes_per_suffix": {"compulsory_floor": 1 + 2 * w,
                              "moved_by_the_big_kernels": (sum(r["moved_bytes_per_launch_incl_keys"] * r["launches"]
                                                               for r in roof["kernels"].values()) / (n * len(stats))) if roof else None},
@@ -257,6 +304,8 @@ def main():
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(T, min(args.cpu_sample, n), args.p, n)
     print(json.dumps(out))
+    if verify_errors:                       # a wrong result is not a benchmark result
+        raise SystemExit(f"verify_errors = {verify_errors}")
 
 
 def host_path(L, T_dev, n, p, idx_bits):

@@ -101,7 +101,7 @@ SHARD_EXPORTS = ["shard_create", "shard_destroy", "shard_info", "shard_phase1", 
                  "shard_phase2", "shard_last_sa", "shard_fix_first_lcp", "shard_scatter", "shard_plan", "shard_sort",
                  "shard_phase1_arrays", "shard_set_key_bits"]
 
-EXPORTS = ["device_count", "last_error", "version", "workspace_bytes", "release_cache", "host_alloc", "host_free"] + SHARD_EXPORTS + [
+EXPORTS = ["device_count", "last_error", "version", "workspace_bytes", "release_cache", "host_alloc", "host_free", "gen_rand_seq"] + SHARD_EXPORTS + [
     f"{name}_{sfx}"
     for sfx in ("u32", "u64")
     for name in ("build", "build_multi", "build_device", "verify_device", "verify_slice_device", "sort_suffixes", "sort_segments", "merge",
@@ -137,6 +137,8 @@ class CapsLib:
         f("host_alloc").argtypes = [_u64]
         f("host_free").restype = None
         f("host_free").argtypes = [_vp]
+        f("gen_rand_seq").restype = _ci
+        f("gen_rand_seq").argtypes = [ctypes.c_uint32, _u64, _vp]
         for sfx in ("u32", "u64"):
             f(f"build_{sfx}").restype = _ci
             f(f"build_{sfx}").argtypes = [_vp, _u64, _u64, _u64, _vp, _vp, _ci, ctypes.POINTER(Stats)]
@@ -220,6 +222,14 @@ class CapsLib:
     def release_cache(self) -> None:
         """Frees the device memory the host-buffer entry points keep between calls."""
         self._f("release_cache")()
+
+    def gen_rand_seq(self, seed: int, n: int, out: np.ndarray | None = None) -> np.ndarray:
+        """n letters of the reference's utils/gen_rand_seq.py stream (host; see include/caps_sa_hip.h)."""
+        if out is None:
+            out = np.empty(n, dtype=np.uint8)
+        assert out.dtype == np.uint8 and out.size >= n and out.flags.c_contiguous
+        self._check(self._f("gen_rand_seq")(seed, n, out.ctypes.data))
+        return out[:n]
 
     def pinned_empty(self, count: int, dtype) -> np.ndarray:
         """numpy array over page-locked host memory (caps_sa_hip_host_alloc); freed with the array."""

@@ -181,11 +181,11 @@ int build_host(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context, 
 }
 
 // ---- one process, several GPUs (`devices, n_devices` under construct(); 8e) -----------------------------
-// The sharded direct path of shard.h with one Shard per device, driven from this process: text replicated, every device
-// distributes every n_devices-th tile of it (level A), the blocks of (key, sa) go straight from device to device (peer
-// copies over xGMI: inside one process nothing else is needed -- the multi-PROCESS driver, caps_sa_dist.py, does the same
-// exchange with RCCL), every device sorts its groups, and the slices of SA / LCP are copied to the caller's arrays by
-// all devices at once.  A device may be listed more than once (several ranks share it: how a one-GPU box tests this).
+// The sharded direct path of shard.h with one Shard per device, driven from this process: text replicated; by default every
+// device classifies the WHOLE text (level A) and keeps the groups it owns -- nothing crosses a link -- sorts them, and the
+// slices of SA / LCP are copied to the caller's arrays by all devices at once.  With CAPS_SA_SHARD_EXCHANGE=1 every device
+// classifies every n_devices-th tile and the blocks of (key, sa) go straight from device to device (peer copies over xGMI:
+// inside one process nothing else is needed -- the multi-PROCESS driver, caps_sa_dist.py, does that exchange with RCCL).  A device may be listed more than once (several ranks share it: how a one-GPU box tests this).
 // Texts the direct path does not take (long repeats) are built on devices[0] alone.
 template <typename idx_t> struct MultiRank {
     int dev = 0;
@@ -694,6 +694,58 @@ void CAPS_API(release_cache)(void)
     caps::DeviceScope restore_device_;
     if (hc.device >= 0 && caps::set_device(hc.device) != CAPS_SA_OK) return;
     caps::release_host_cache_locked(hc);
+}
+
+int CAPS_API(gen_rand_seq)(uint32_t seed, uint64_t n, char* out_)
+{
+    if (!out_ && n) return caps::fail(CAPS_SA_EINVAL, "null pointer");
+    char* __restrict__ out = out_;
+    // MT19937 (Matsumoto & Nishimura): init_genrand(19650218), then init_by_array with the one-word key {seed} -- what
+    // CPython's random.seed(int) does for 0 <= seed < 2^32
+    constexpr int N = 624, M = 397;
+    alignas(64) uint32_t mt[N];
+    mt[0] = 19650218u;
+    for (int i = 1; i < N; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+    {
+        int i = 1;
+        for (int k = N; k; --k) {                                   // key length 1: j stays 0
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + seed;
+            if (++i >= N) { mt[0] = mt[N - 1]; i = 1; }
+        }
+        for (int k = N - 1; k; --k) {
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+            if (++i >= N) { mt[0] = mt[N - 1]; i = 1; }
+        }
+        mt[0] = 0x80000000u;
+    }
+    // a block of 624 outputs at a time: the recurrence in three loops without wrap-around (the first two vectorise: their
+    // dependence distance is 227), tempering into a buffer, then a branch-free compaction of the accepted draws
+    auto twist = [](uint32_t a, uint32_t b, uint32_t c) {
+        const uint32_t y = (a & 0x80000000u) | (b & 0x7FFFFFFFu);
+        return c ^ (y >> 1) ^ ((0u - (y & 1u)) & 0x9908B0DFu);
+    };
+    alignas(64) uint8_t k3[N + 8];
+    char tail[N + 8];
+    uint64_t done = 0;
+    while (done < n) {
+        for (int k = 0; k < N - M; ++k) mt[k] = twist(mt[k], mt[k + 1], mt[k + M]);
+        for (int k = N - M; k < N - 1; ++k) mt[k] = twist(mt[k], mt[k + 1], mt[k + M - N]);
+        mt[N - 1] = twist(mt[N - 1], mt[0], mt[M - 1]);
+        for (int k = 0; k < N; ++k) {
+            uint32_t y = mt[k];
+            y ^= y >> 11;
+            y ^= (y << 7) & 0x9D2C5680u;
+            y ^= (y << 15) & 0xEFC60000u;
+            y ^= y >> 18;
+            k3[k] = (uint8_t)(y >> 29);                             // getrandbits(3); a draw >= 4 is rejected
+        }
+        char* __restrict__ o = n - done >= (uint64_t)N ? out + done : tail;      // room for a whole block: straight into the output
+        uint32_t c = 0;
+        for (int k = 0; k < N; ++k) { const uint8_t v = k3[k]; o[c] = "ACGTACGT"[v]; c += v < 4 ? 1u : 0u; }
+        if (o == tail) { if (c > n - done) c = (uint32_t)(n - done); std::memcpy(out + done, tail, c); }
+        done += c;
+    }
+    return CAPS_SA_OK;
 }
 
 void* CAPS_API(host_alloc)(uint64_t bytes)

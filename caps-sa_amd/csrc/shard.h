@@ -537,6 +537,7 @@ private:
     int bits_ = 0;
     uint32_t slot_stats_[2] = {0, 0};    // bucket splits of the current build: kept with slots / redone
     uint32_t run_buckets_ = 0;           // letter-run buckets of the last sort_owned (text.h "letter runs")
+    uint32_t h_flag_ = 0;                // scatter_bits: the fallback word on its way to the device
     uint32_t* P_ = nullptr;
     uint32_t* present_ = nullptr;
     uint8_t* lut_ = nullptr;
@@ -599,7 +600,8 @@ private:
             skewed_ = probe[2] != 0;
             if (quantile_) key_bits_ = 64;            // (knot buckets carry 64-bit keys)
             const uint64_t token = 2 * GA_E / K1_ + 16;
-            uint32_t code = 0;
+            uint32_t& code = h_flag_;                 // (a member: the asynchronous copy below must not read a dead stack slot)
+            code = 0;
             if (quantile_ && probe[3] > p_ / 4) code = CAPS_SA_FB_PIVOT_TIES;        // one key over a quarter of the text: the samplesort path's
             else if (quantile_ && capA_ <= 2 * token) code = CAPS_SA_FB_SHAPE;
             if (quantile_ && code == 0) {

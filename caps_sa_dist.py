@@ -177,7 +177,7 @@ def build_sharded(lib, T: torch.Tensor, p: int = 0, idx_bits: int | None = None,
             lap("exchange")
             mine = sh.sort_owned(recv_k.data_ptr(), recv_s.data_ptr(), B.SA.data_ptr(), B.LCP.data_ptr())
             worst = torch.tensor([mine], dtype=torch.int64, device=dev)
-            if world > 1 and now["exchange"]:                     # (32-bit keys only exist in exchange mode)
+            if world > 1:                                         # (CAPS_SA_KEYS=32 gives the no-exchange mode 32-bit keys too)
                 dist.all_reduce(worst, op=dist.ReduceOp.MAX)      # a slot overflow on ANY rank sends every rank round again
             lap("sort")
             if int(worst.item()) != 0:
@@ -291,8 +291,42 @@ def bench_main(args, rank: int, local_rank: int, world: int):
     T = make_text(torch, n_bases, args.seed, dev, kind)          # identical on every rank (same seed)
     stream = torch.cuda.current_stream().cuda_stream
 
-    sh = L.shard(T.data_ptr(), n, args.p, idx_bits, rank, world, stream)     # workspace of the rank, allocated once
-    bufs = ShardBuffers(sh.info(), dev, _idx_dtype(idx_bits))
+    # --shard-mode: "local" = no data-path collective (every rank classifies the whole replicated text and keeps its groups),
+    # "exchange" = every rank classifies every world-th tile, ONE all-to-all of (key32, sa) over xGMI, "auto" = both are run
+    # once during the warm-up and the faster one (max over the ranks) is timed.  The library reads the mode when a shard is made.
+    def make_shard(mode):
+        if mode == "exchange":
+            os.environ["CAPS_SA_SHARD_EXCHANGE"] = "1"
+        else:
+            os.environ.pop("CAPS_SA_SHARD_EXCHANGE", None)
+        s = L.shard(T.data_ptr(), n, args.p, idx_bits, rank, world, stream)     # workspace of the rank, allocated once
+        return s, ShardBuffers(s.info(), dev, _idx_dtype(idx_bits))
+
+    mode = getattr(args, "shard_mode", "auto")
+    if os.environ.get("CAPS_SA_SHARD_EXCHANGE") == "1" and mode == "auto":
+        mode = "exchange"
+    calib = None
+    if mode == "auto" and world > 1:
+        calib = {}
+        for m in ("local", "exchange"):
+            s_, b_ = make_shard(m)
+            build_sharded(L, T, args.p, idx_bits, stream, shard=s_, bufs=b_)            # first build: allocations, RCCL connections
+            dist.barrier()
+            torch.cuda.synchronize()
+            t_ = time.perf_counter()
+            build_sharded(L, T, args.p, idx_bits, stream, shard=s_, bufs=b_)
+            dist.barrier()
+            torch.cuda.synchronize()
+            el_ = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device=dev)
+            dist.all_reduce(el_, op=dist.ReduceOp.MAX)
+            calib[m] = 1e3 * float(el_.item())
+            s_.close()
+            del s_, b_
+            torch.cuda.empty_cache()
+        mode = min(calib, key=calib.get)
+    elif mode == "auto":
+        mode = "local"
+    sh, bufs = make_shard(mode)
 
     def step():
         return build_sharded(L, T, args.p, idx_bits, stream, shard=sh, bufs=bufs)
@@ -313,11 +347,30 @@ def bench_main(args, rank: int, local_rank: int, world: int):
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     errs = None if args.no_verify else verify_sharded(L, T, SA, LCP, off, idx_bits)
+    # every rank's stage times of the last build (max and min over the ranks: imbalance shows here, not in rank 0's figures)
+    last = infos[-1]
+    stage_keys = ("ms_level_a", "ms_scatter", "ms_exchange", "ms_sort", "ms_level_b", "ms_tile_sort", "ms_merge_passes", "ms_phase1", "ms_pivots",
+                  "ms_collate", "ms_phase2")
+    mine_v = torch.tensor([float(last.get(k, 0.0) or 0.0) for k in stage_keys] + [float(last["recv_total"])], dtype=torch.float64, device=dev)
+    allr = torch.empty(world * mine_v.numel(), dtype=torch.float64, device=dev)
+    dist.all_gather_into_tensor(allr, mine_v)
+    allr = allr.view(world, -1)
+    ranks_ms = {k: {"max": float(allr[:, i].max()), "min": float(allr[:, i].min())} for i, k in enumerate(stage_keys) if float(allr[:, i].max()) > 0}
+    share = allr[:, -1]
+    if int(share.sum().item()) != n:
+        raise SystemExit(f"the ranks' slices hold {int(share.sum().item())} suffixes, the text has {n}")
     if rank == 0:
         info = infos[-1]
         direct = all(i["path"] == "direct" for i in infos)
         mine = info["recv_total"]
         roof = None
+        if not direct:    # samplesort sequence: each phase is two streaming passes (bucket scatter + tile sort) over the rank's share
+            k = len(infos)
+            roof = roofline({"phase1_sort_subarrays": (sum(i["ms_phase1"] for i in infos) / 2, k, sum(i["local_elems"] for i in infos)),
+                             "phase2_sort_partitions": (sum(i["ms_phase2"] for i in infos) / 2, k, sum(i["recv_total"] for i in infos))}, w, "")
+            if roof:
+                roof["scope"] = (f"rank 0 of {world}, samplesort sequence: a phase is two streaming passes (bucket scatter + tile sort) over the "
+                                 "rank's share; avg_launch_ms = half the phase")
         if direct:        # rank 0's kernels over ITS share of the suffixes, same convention as at N = 1
             k = len(infos)
             roof = roofline({"level_a_scatter": (sum(i["ms_level_a"] for i in infos), k, sum(i["level_a_elems"] for i in infos)),
@@ -349,6 +402,9 @@ def bench_main(args, rank: int, local_rank: int, world: int):
                                        f"{world} GPUs, one process each: text replicated, tiles of the text and groups of partitions "
                                        "sharded, one RCCL all-to-all over xGMI")},
             "rank0_ms": {k_: info[k_] for k_ in keys},
+            "ranks_ms": ranks_ms,
+            "suffixes_per_rank": {"max": int(share.max().item()), "min": int(share.min().item())},
+            "shard_mode": "exchange" if info.get("exchange") else "local",
             "exchange": {"ms": ms_x, "bytes_sent_per_rank": sent, "GBps_per_rank": (sent / 1e9) / (ms_x * 1e-3) if ms_x > 0 and sent else None,
                          "key_bytes": info.get("key_bytes", 8) if direct else 8, "key_retries": sum(i.get("key_retry", 0) for i in infos),
                          "note": ("no data-path collective: every rank scatters the whole (replicated) text and keeps the groups it owns"
@@ -359,22 +415,43 @@ def bench_main(args, rank: int, local_rank: int, world: int):
             "verify_errors": errs,
             "cpu_baseline": None,
         }
-        if world == 1 and not args.no_cpu_baseline:          # the CPU baseline is timed at N = 1 only (rank 0)
+        if calib:
+            out["shard_mode_calibration_ms"] = calib
+        if not args.no_cpu_baseline:          # rank 0 times the CPU baseline at every world size; the other ranks wait at the barrier below
             out["cpu_baseline"] = cpu_baseline(T, min(args.cpu_sample, n), args.p, n)
         print(json.dumps(out))
+    dist.barrier()
     sh.close()
     dist.destroy_process_group()
+    if errs:
+        raise SystemExit(f"verify_errors = {errs}")
 
 
 def verify_sharded(lib, T, SA, LCP, off, idx_bits) -> int:
-    """Gathers the slices on every rank and runs the device verifier (testing aid)."""
-    world = dist.get_world_size()
+    """Exact check of a sharded result WITHOUT gathering it (at BASELINE config 4 the gathered arrays would be 137 GB on every
+    GPU): every rank runs the slice verifier on its own slice (values in range, none twice, adjacent order, exact LCPs), checks
+    the pair (last suffix of the slice below, its own first suffix) the same way -- order and the LCP at its slice head -- and the
+    error counts and slice lengths are summed over the ranks.  Slices that are sorted, joined in order and n entries long in all
+    hold every suffix exactly once."""
+    world, rank = dist.get_world_size(), dist.get_rank()
     n = T.numel()
-    cnt = torch.tensor([SA.numel()], dtype=torch.int64, device=T.device)
-    cnts = torch.empty(world, dtype=torch.int64, device=T.device)
-    dist.all_gather_into_tensor(cnts, cnt)
-    counts = [int(x) for x in cnts.tolist()]
-    SA_all = _all_gather_var(SA, counts)
-    LCP_all = _all_gather_var(LCP, counts)
-    assert SA_all.numel() == n
-    return lib.verify_device(T.data_ptr(), n, SA_all.data_ptr(), LCP_all.data_ptr(), idx_bits=idx_bits)
+    dev = T.device
+    cnt = SA.numel()
+    errs = lib.verify_slice_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr(), cnt, off == 0, idx_bits=idx_bits) if cnt else 0
+    ends = torch.tensor([int(SA[-1].item()) if cnt else -1, cnt, off], dtype=torch.int64, device=dev)
+    allv = torch.empty(3 * world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(allv, ends)
+    allv = allv.view(world, 3).tolist()
+    below = [v for v in allv[:rank] if v[1] > 0]
+    if cnt and below:
+        if below[-1][2] + below[-1][1] != off:
+            errs += 1                                             # the slices do not join
+        pair_sa = torch.tensor([below[-1][0], int(SA[0].item())], dtype=SA.dtype, device=dev)
+        pair_lcp = torch.stack([LCP[0], LCP[0]])
+        errs += lib.verify_slice_device(T.data_ptr(), n, pair_sa.data_ptr(), pair_lcp.data_ptr(), 2, False, idx_bits=idx_bits)
+    elif cnt and off != 0:
+        errs += 1
+    tot = torch.tensor([errs, cnt], dtype=torch.int64, device=dev)
+    dist.all_reduce(tot)
+    errs_all, cnt_all = (int(x) for x in tot.tolist())
+    return errs_all + (0 if cnt_all == n else 1)

@@ -109,6 +109,15 @@ void caps_sa_hip_release_cache(void);
 void* caps_sa_hip_host_alloc(uint64_t bytes);
 void caps_sa_hip_host_free(void* p);
 
+/*
+ * The reference's input generator, utils/gen_rand_seq.py:9-13 -- random.seed(seed); n x random.choice(['A','C','G','T']) --
+ * bit for bit: MT19937 seeded like CPython's random.seed(int) (init_by_array([seed])), every choice = the top 3 bits of one
+ * 32-bit output, drawn again while >= 4 (random.choice -> _randbelow(4) -> getrandbits(3)).  Writes n letters to out (host
+ * memory; the script's print() adds a newline, which the CLI remaps to 'C': callers append it themselves).  Host code, no
+ * GPU: ~5 ns per letter.  BASELINE's workloads are quoted on this stream, so bench.py builds C2 / C3 from it.
+ */
+int caps_sa_hip_gen_rand_seq(uint32_t seed, uint64_t n, char* out);
+
 /* Device workspace a build of n suffixes needs (bytes). */
 int caps_sa_hip_workspace_bytes(uint64_t n, uint64_t subproblem_count, int idx_bytes, uint64_t* bytes);
 
@@ -128,9 +137,12 @@ int caps_sa_hip_build_u64(const char* T, uint64_t n, uint64_t subproblem_count, 
 /*
  * construct() on several GPUs of one node from ONE process (what Suffix_Array(T, n, p, ctx, devices)
  * calls): devices[0 .. n_devices) are HIP device ordinals, one rank of the sharded direct path each (a device may be listed
- * more than once).  The text is copied to every device; every device distributes every n_devices-th tile of it, the
- * blocks of (key, sa) are copied device to device over xGMI, every device sorts its share of the partitions and copies
- * its slice of SA / LCP into the caller's arrays.  n_devices = 1 is caps_sa_hip_build_*.  Texts the direct path does not
+ * more than once).  The text is copied to every device.  Default: NO element crosses a link -- every device classifies the
+ * whole text (level A), keeps the suffixes of the groups of partitions it owns (1 / n_devices of them), sorts them and
+ * copies its slice of SA / LCP into the caller's arrays; per device: the packed text + about 2.7 x 16 B x n / n_devices of
+ * work arrays.  CAPS_SA_SHARD_EXCHANGE=1 selects the variant in which every device classifies every n_devices-th tile only
+ * and the blocks of (key, sa) are then copied device to device over xGMI (8.8 B per suffix).  n_devices = 1 is
+ * caps_sa_hip_build_*.  Texts the direct path does not
  * take (stats->path_fallback says why) are built on devices[0] alone.  stats: host wall-clock per stage, all devices.
  */
 int caps_sa_hip_build_multi_u32(const char* T, uint64_t n, uint64_t subproblem_count, uint64_t max_context,

@@ -45,6 +45,9 @@ def main():
     runs = rs.choice(dna, size=180_000)
     runs[20_000:26_000] = ord("G")                                           # an N-block: long run -> every rank falls back together
     cases.append((runs, 0, 32))
+    if world >= 8:          # a node's worth of ranks: every case with a few partitions per rank (fewer is refused, see "imbalance")
+        cases = [(rs.choice(dna, size=150_001), 24, 32), (rs.choice(np.frombuffer(b"abcdefgh", dtype=np.uint8), size=60_000), 32, 64),
+                 (rs.choice(dna, size=200_000, p=[0.6, 0.2, 0.1, 0.1]), 40, 64), (runs, 0, 32)]
     ok = True
     for T_np, p, bits in cases:
         T = torch.from_numpy(T_np.copy())
@@ -61,6 +64,15 @@ def main():
         dt = np.uint32 if bits == 32 else np.uint64
         SAo, LCPo = (O.naive_sa_lcp(T_np, idx_bits=bits) if T_np.size <= 200_000 else O.build_sa_lcp(T_np, p=p, idx_bits=bits)[:2])
         good = np.array_equal(SA_all.view(dt), SAo) and np.array_equal(LCP_all.view(dt), LCPo)
+        # the slice-wise verifier bench.py uses at N > 1 (nothing gathered): clean on the result, loud on a corrupted one
+        good = good and caps_sa_dist.verify_sharded(E, T, SA, LCP, off, bits) == 0
+        if T_np.size >= 40_000:
+            bad_sa, bad_lcp = SA.clone(), LCP.clone()
+            if rank == world - 1 and bad_sa.numel() > 1:
+                bad_sa[0], bad_sa[1] = SA[1].clone(), SA[0].clone()           # the slice head swapped with its neighbour
+            if rank == 0 and bad_lcp.numel() > 3:
+                bad_lcp[3] += 1
+            good = good and caps_sa_dist.verify_sharded(E, T, bad_sa, bad_lcp, off, bits) >= 2
         if rank == 0:
             print(f"case n={T_np.size} p={p} bits={bits} path={info['path']} fb={info.get('direct_fallback')} keys={info.get('key_bytes')} "
                   f"retry={info.get('key_retry')} exch={info.get('exchange')} quant={info.get('direct_quantile')} counts={counts} "
