@@ -235,7 +235,7 @@ def main():
     dt = torch.int32 if idx_bits == 32 else torch.int64
     SA = torch.empty(n, dtype=dt, device=dev)
     LCP = torch.empty(n, dtype=dt, device=dev)
-    ws_bytes = L.workspace_bytes(n, args.p, idx_bits)
+    ws_bytes = L.workspace_bytes(n, args.p, idx_bits, bits_per_char=2)       # every workload here is DNA: the 2-bit text arena
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
 

@@ -101,7 +101,7 @@ SHARD_EXPORTS = ["shard_create", "shard_destroy", "shard_info", "shard_phase1", 
                  "shard_phase2", "shard_last_sa", "shard_fix_first_lcp", "shard_scatter", "shard_plan", "shard_sort",
                  "shard_phase1_arrays", "shard_set_key_bits"]
 
-EXPORTS = ["device_count", "last_error", "version", "workspace_bytes", "release_cache", "host_alloc", "host_free", "gen_rand_seq"] + SHARD_EXPORTS + [
+EXPORTS = ["device_count", "last_error", "version", "workspace_bytes", "workspace_bytes_ex", "release_cache", "host_alloc", "host_free", "gen_rand_seq"] + SHARD_EXPORTS + [
     f"{name}_{sfx}"
     for sfx in ("u32", "u64")
     for name in ("build", "build_multi", "build_device", "verify_device", "verify_slice_device", "sort_suffixes", "sort_segments", "merge",
@@ -131,6 +131,8 @@ class CapsLib:
         f("version").restype = ctypes.c_char_p
         f("workspace_bytes").restype = _ci
         f("workspace_bytes").argtypes = [_u64, _u64, _ci, ctypes.POINTER(_u64)]
+        f("workspace_bytes_ex").restype = _ci
+        f("workspace_bytes_ex").argtypes = [_u64, _u64, _ci, _ci, ctypes.POINTER(_u64)]
         f("release_cache").restype = None
         f("release_cache").argtypes = []
         f("host_alloc").restype = _vp
@@ -207,9 +209,10 @@ class CapsLib:
     def version(self) -> str:
         return self._f("version")().decode()
 
-    def workspace_bytes(self, n: int, p: int = 0, idx_bits: int = 32) -> int:
+    def workspace_bytes(self, n: int, p: int = 0, idx_bits: int = 32, bits_per_char: int = 8) -> int:
+        """bits_per_char = 2: a text of at most 4 distinct bytes (anything behind the reference CLI) -- a smaller text arena."""
         out = _u64(0)
-        self._check(self._f("workspace_bytes")(n, p, idx_bits // 8, ctypes.byref(out)))
+        self._check(self._f("workspace_bytes_ex")(n, p, idx_bits // 8, bits_per_char, ctypes.byref(out)))
         return out.value
 
     # ------------------------------------------------------------------ host-buffer build

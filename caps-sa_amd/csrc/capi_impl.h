@@ -41,6 +41,9 @@ template <typename F> int guarded(F&& f)
     } catch (const HipError& e) {
         last_error_ref() = e.what();
         return CAPS_SA_EHIP;
+    } catch (const AlphabetError& e) {
+        last_error_ref() = e.what();
+        return CAPS_SA_EALPHABET;
     } catch (const std::bad_alloc&) {
         last_error_ref() = "host allocation failed";
         return CAPS_SA_ENOMEM;
@@ -84,10 +87,18 @@ template <typename idx_t> int check_common(const void* T, uint64_t n, uint64_t m
 
 int set_device(int device);   // defined by the including translation unit
 
+// waves / sink: Builder::set_waves (the host-buffer entry point streams finished slices of the result out while the rest is sorted)
+inline uint64_t wave_scratch_elems(uint64_t n, uint32_t waves) { return std::max<uint64_t>(4 * TILE_E, (n / waves) * 3 / 2 + 2 * TILE_E); }
+template <typename idx_t> inline size_t wave_scratch_bytes(uint64_t elems)
+{
+    return ((elems * sizeof(uint64_t) + 255) & ~size_t(255)) + 2 * ((elems * sizeof(idx_t) + 255) & ~size_t(255)) + 256;
+}
 template <typename idx_t>
 int build_device(const void* dT, uint64_t n, uint64_t p_arg, uint64_t max_context, void* dSA, void* dLCP, void* workspace,
-                 uint64_t workspace_bytes, void* stream, caps_sa_stats* stats)
+                 uint64_t workspace_bytes, void* stream, caps_sa_stats* stats, uint32_t waves = 1, WaveSink* sink = nullptr,
+                 bool* sink_served = nullptr, int arena_bits = 0)
 {
+    // arena_bits: the code width the workspace's text arena was sized for (0: told by the size of the workspace)
     if (int rc = check_common<idx_t>(dT, n, max_context)) return rc;
     if (n && (!dSA || !dLCP)) return fail(CAPS_SA_EINVAL, "null output");
     return guarded([&]() -> int {
@@ -95,16 +106,58 @@ int build_device(const void* dT, uint64_t n, uint64_t p_arg, uint64_t max_contex
         DevAllocs da(be);
         Plan<idx_t> need = make_plan<idx_t>(n, p_arg, nullptr);
         char* base = static_cast<char*>(workspace);
+        int text_bits = arena_bits == 2 ? 2 : 8;
         if (!base) base = da.get<char>(need.bytes);
-        else if (workspace_bytes < need.bytes) return fail(CAPS_SA_EINVAL, "workspace too small");
+        else if (arena_bits == 2) {
+            if (workspace_bytes < make_plan<idx_t>(n, p_arg, nullptr, 2).bytes) return fail(CAPS_SA_EINVAL, "workspace too small");
+        } else if (workspace_bytes < need.bytes) {
+            // a workspace of caps_sa_hip_workspace_bytes_ex(.., 2, ..): the text arena holds 2-bit codes only
+            if (workspace_bytes < make_plan<idx_t>(n, p_arg, nullptr, 2).bytes) return fail(CAPS_SA_EINVAL, "workspace too small");
+            text_bits = 2;
+        }
         // carve from a 256-byte aligned base
         char* aligned = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(base) + 255) & ~uintptr_t(255));
-        Plan<idx_t> pl = make_plan<idx_t>(n, p_arg, aligned);
+        Plan<idx_t> pl = make_plan<idx_t>(n, p_arg, aligned, text_bits);
         Builder<idx_t> b(be, pl);
+        ElemBuf<idx_t> scratch;
+        uint64_t scratch_elems = 0;
+        if (waves > 1 && sink) {                         // the waves' work arrays, behind the plan in the caller's workspace
+            scratch_elems = wave_scratch_elems(n, waves);
+            char* sb = aligned + ((pl.bytes + 255) & ~size_t(255));
+            if (workspace && static_cast<char*>(workspace) + workspace_bytes >= sb + wave_scratch_bytes<idx_t>(scratch_elems)) {
+                scratch.key = reinterpret_cast<uint64_t*>(sb);
+                scratch.sa = reinterpret_cast<idx_t*>(sb + ((scratch_elems * sizeof(uint64_t) + 255) & ~size_t(255)));
+                scratch.lcp = reinterpret_cast<idx_t*>(reinterpret_cast<char*>(scratch.sa) + ((scratch_elems * sizeof(idx_t) + 255) & ~size_t(255)));
+                scratch.region_bytes = wave_scratch_bytes<idx_t>(scratch_elems);
+            } else scratch_elems = 0;
+        }
+        b.set_waves(waves, sink, scratch, scratch_elems);
         b.build(static_cast<const uint8_t*>(dT), static_cast<idx_t*>(dSA), static_cast<idx_t*>(dLCP), stats);
+        if (sink_served) *sink_served = b.sink_served();
         return CAPS_SA_OK;
     });
 }
+
+// Results of the host-buffer entry point leave the device slice by slice: when a wave of groups has been sorted (its slice of
+// SA / LCP is final), a second stream waits for that point of the build's stream and copies the slice to the caller's arrays
+// while the next wave is sorted -- the D2H of 2 n indices (24 GB at C3: 420 ms at the link rate) then hides the rest of the
+// build instead of following it.  (The upload of T cannot hide anything: sampling and level A need the whole text.)
+template <typename idx_t> struct HostCopySink : WaveSink {
+    decltype(Backend::stream) copy_stream;
+    idx_t *SA, *LCP;
+    const idx_t *dSA, *dLCP;
+    uint64_t copied = 0;
+    void wave_done(Backend& be, uint64_t base, uint64_t cnt) override
+    {
+        Backend::stream_wait(copy_stream, be.record());
+        Backend::d2h_on(copy_stream, SA + base, dSA + base, cnt * sizeof(idx_t));
+        Backend::d2h_on(copy_stream, LCP + base, dLCP + base, cnt * sizeof(idx_t));
+        copied += cnt;
+    }
+};
+#ifndef CAPS_HOST_WAVES
+#define CAPS_HOST_WAVES 12
+#endif
 
 // Device memory of the host-buffer entry points, kept between calls: hipMalloc + hipFree of the
 // text, the result arrays and the workspace cost far more than the build they serve (n = 1e9:
@@ -147,10 +200,24 @@ int build_host(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context, 
         std::lock_guard<std::mutex> lock(hc.mu);
         Backend be(nullptr);
         auto up = [](size_t b) { return (b + 255) & ~size_t(255); };
-        const Plan<idx_t> need = make_plan<idx_t>(n, p_arg, nullptr);
+        // the text arena is sized for 2-bit codes when the first MiB of the text shows at most 4 distinct bytes (a text that
+        // turns out to have more is built again below with the arena of 8-bit codes)
+        int text_bits = 8;
+        {
+            bool seen[256] = {false};
+            int sigma = 0;
+            const uint64_t look = n < (1u << 20) ? n : (1u << 20);
+            for (uint64_t i = 0; i < look && sigma <= 4; ++i)
+                if (!seen[(uint8_t)T[i]]) { seen[(uint8_t)T[i]] = true; ++sigma; }
+            if (sigma <= 4 && !std::getenv("CAPS_SA_FULL_ALPHABET")) text_bits = 2;
+        }
+        for (;; text_bits = 8) {
+        const Plan<idx_t> need = make_plan<idx_t>(n, p_arg, nullptr, text_bits);
         const size_t off_sa = up(n ? n : 1), off_lcp = off_sa + up((n ? n : 1) * sizeof(idx_t));
         const size_t off_ws = off_lcp + up((n ? n : 1) * sizeof(idx_t));
-        const size_t total = off_ws + need.bytes + 512;
+        uint32_t waves = CAPS_HOST_WAVES;
+        if (const char* e = std::getenv("CAPS_SA_HOST_WAVES")) waves = (uint32_t)std::max(1, std::atoi(e));
+        const size_t total = off_ws + need.bytes + 1024 + wave_scratch_bytes<idx_t>(wave_scratch_elems(n, waves));
         if (hc.device != device || hc.bytes < total) {
             release_host_cache_locked(hc);
             hc.base = static_cast<char*>(be.alloc(total));
@@ -166,17 +233,34 @@ int build_host(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context, 
         BackendEvent h1 = be.record();
         be.sync();
         caps_sa_stats local;
-        int rc = build_device<idx_t>(dT, n, p_arg, max_context, dSA, dLCP, base + off_ws, hc.bytes - off_ws - 256, nullptr, &local);
-        if (rc) return rc;
-        BackendEvent d0 = be.record();
-        be.d2h(SA, dSA, n * sizeof(idx_t));
-        be.d2h(LCP, dLCP, n * sizeof(idx_t));
-        BackendEvent d1 = be.record();
-        be.sync();
+        HostCopySink<idx_t> sink;
+        sink.copy_stream = Backend::create_stream();
+        sink.SA = SA;
+        sink.LCP = LCP;
+        sink.dSA = dSA;
+        sink.dLCP = dLCP;
+        struct StreamGuard { decltype(Backend::stream) s; ~StreamGuard() { Backend::destroy_stream(s); } } guard{sink.copy_stream};
+        bool served = false;
+        const auto t0 = std::chrono::steady_clock::now();
+        int rc = build_device<idx_t>(dT, n, p_arg, max_context, dSA, dLCP, base + off_ws, hc.bytes - off_ws - 256, nullptr, &local, waves,
+                                     &sink, &served, text_bits);
+        if (rc == CAPS_SA_EALPHABET && text_bits == 2) { Backend::sync_stream(sink.copy_stream); continue; }
+        if (rc) { Backend::sync_stream(sink.copy_stream); return rc; }
+        if (!served || sink.copied != n) {           // another construction (samplesort path, tiny input): nothing was streamed out
+            Backend::sync_stream(sink.copy_stream);
+            be.d2h(SA, dSA, n * sizeof(idx_t));
+            be.d2h(LCP, dLCP, n * sizeof(idx_t));
+            be.sync();
+        } else {
+            Backend::sync_stream(sink.copy_stream);
+        }
         local.ms_h2d = be.elapsed_ms(h0, h1);
-        local.ms_d2h = be.elapsed_ms(d0, d1);
+        // build + result copies, overlapped: host wall clock from the launch of the build to the last byte on the host, minus the build
+        const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        local.ms_d2h = wall > local.ms_total ? wall - local.ms_total : 0.0;
         if (stats) *stats = local;
         return CAPS_SA_OK;
+        }
     });
 }
 
@@ -757,12 +841,16 @@ void* CAPS_API(host_alloc)(uint64_t bytes)
 
 void CAPS_API(host_free)(void* p) { caps::Backend::host_free(p); }
 
+int CAPS_API(workspace_bytes_ex)(uint64_t n, uint64_t subproblem_count, int idx_bytes, int bits_per_char, uint64_t* bytes)
+{
+    if (!bytes || (idx_bytes != 4 && idx_bytes != 8) || (bits_per_char != 2 && bits_per_char != 8)) return caps::fail(CAPS_SA_EINVAL, "bad argument");
+    *bytes = (idx_bytes == 4 ? caps::make_plan<uint32_t>(n, subproblem_count, nullptr, bits_per_char).bytes
+                             : caps::make_plan<uint64_t>(n, subproblem_count, nullptr, bits_per_char).bytes) + 256;
+    return CAPS_SA_OK;
+}
 int CAPS_API(workspace_bytes)(uint64_t n, uint64_t subproblem_count, int idx_bytes, uint64_t* bytes)
 {
-    if (!bytes || (idx_bytes != 4 && idx_bytes != 8)) return caps::fail(CAPS_SA_EINVAL, "bad argument");
-    *bytes = (idx_bytes == 4 ? caps::make_plan<uint32_t>(n, subproblem_count, nullptr).bytes
-                             : caps::make_plan<uint64_t>(n, subproblem_count, nullptr).bytes) + 256;
-    return CAPS_SA_OK;
+    return CAPS_API(workspace_bytes_ex)(n, subproblem_count, idx_bytes, 8, bytes);
 }
 
 #define CAPS_DEFINE_WIDTH(SFX, IDX)                                                                                        \

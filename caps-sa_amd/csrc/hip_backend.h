@@ -93,6 +93,14 @@ public:
         return s;
     }
     static void destroy_stream(hipStream_t s) { if (s) (void)hipStreamDestroy(s); }
+    // result copies that overlap the rest of a build (capi_impl.h build_host): stream `s` waits for an event of this backend's
+    // stream, then copies device -> host
+    static void stream_wait(hipStream_t s, BackendEvent e) { CAPS_HIP(hipStreamWaitEvent(s, e.ev, 0)); }
+    static void d2h_on(hipStream_t s, void* h, const void* d, size_t bytes)
+    {
+        if (bytes) CAPS_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s));
+    }
+    static void sync_stream(hipStream_t s) { CAPS_HIP(hipStreamSynchronize(s)); }
     void peer_copy(void* dst, int dst_dev, const void* src, int src_dev, size_t bytes)
     {
         if (!bytes) return;

@@ -3491,6 +3491,17 @@ GLOBAL_FN LAUNCH_BOUNDS(256) regroup_kernel(KCTX const uint64_t* __restrict__ de
 
 // LCP of the first suffix of a rank's slice with the last suffix of the previous
 // non-empty slice (the a11 boundary between GPUs).
+// SA[base - 1] and SA[base] are neighbours in the suffix array but were sorted by different waves: their LCP from the text
+template <typename idx_t, int BITS>
+GLOBAL_FN LAUNCH_BOUNDS(64) wave_head_lcp_kernel(KCTX const uint32_t* __restrict__ P, uint64_t n, const idx_t* __restrict__ dSA,
+                                                 idx_t* __restrict__ dLCP, uint64_t base)
+{
+    PAR(tid) {
+        if (tid == 0 && K_BLOCK_IDX == 0)
+            dLCP[base] = (idx_t)deep_lcp<BITS, true>(P, n, (uint64_t)dSA[base - 1], (uint64_t)dSA[base], 0);
+    }
+}
+
 template <typename idx_t, int BITS>
 GLOBAL_FN LAUNCH_BOUNDS(64) first_lcp_kernel(KCTX const uint32_t* __restrict__ P, uint64_t n, uint64_t prev_sa,
                                              const idx_t* __restrict__ sa, idx_t* __restrict__ lcp)

@@ -113,6 +113,7 @@ struct BucketBufs {
 
 template <typename idx_t> struct Plan {
     uint64_t n = 0;
+    int text_bits = 8;       // code width the text arena holds (make_plan)
     uint32_t p = 0;          // effective subproblem count (0/1 -> single segment)
     uint32_t ppp = 0;        // samples per subarray
     uint64_t m = 0;          // number of samples
@@ -158,11 +159,13 @@ inline void effective_params(uint64_t n, uint64_t p_arg, uint32_t* p_eff, uint32
     *ppp = (uint32_t)(a < b ? a : b);
 }
 
+// text_bits: the code width the text arena is sized for (8: any text; 2: texts of at most 4 distinct bytes -- a quarter of it)
 template <typename idx_t>
-Plan<idx_t> make_plan(uint64_t n, uint64_t p_arg, char* base)
+Plan<idx_t> make_plan(uint64_t n, uint64_t p_arg, char* base, int text_bits = 8)
 {
     Plan<idx_t> pl;
     pl.n = n;
+    pl.text_bits = text_bits;
     effective_params(n, p_arg, &pl.p, &pl.ppp);
     Arena ar;
     ar.base = base;
@@ -175,7 +178,7 @@ Plan<idx_t> make_plan(uint64_t n, uint64_t p_arg, char* base)
     pl.bk.nb_cap = BucketBufs::bucket_bound(nn, p);
     pl.bk.tile_cap = nn / TILE_E + pl.bk.nb_cap + 2;
     pl.tile_cap = pl.bk.tile_cap;
-    pl.P = ar.take<uint32_t>(text_alloc_words(nn));
+    pl.P = ar.take<uint32_t>(text_alloc_words(nn, text_bits));
     for (ElemBuf<idx_t>* b : {&pl.A, &pl.B}) {
         b->key = ar.take<uint64_t>(nn);
         const size_t at = ar.off - nn * sizeof(uint64_t);
@@ -285,11 +288,11 @@ inline void build_run_table(Backend& be, uint32_t* P, uint64_t n, int bits)
 {
     const uint64_t entries = run_table_entries(n, bits);
     const uint32_t chunks = (uint32_t)run_table_chunks(entries);
-    uint64_t* R = run_table_mut(P, n);
+    uint64_t* R = run_table_mut(P, n, bits);
     uint64_t* flag = R - 2;
     uint64_t* longest = R - 1;
-    uint64_t* head = R + run_table_entries(n, 8);
-    uint64_t* carry = head + run_table_chunks(run_table_entries(n, 8));
+    uint64_t* head = R + entries;
+    uint64_t* carry = head + chunks;
     be.memset(flag, 0, 2 * sizeof(uint64_t));
     const uint64_t want = (entries + 255) / 256;
     const uint32_t grid = (uint32_t)(want < 16384 ? want : 16384);
@@ -307,7 +310,10 @@ inline void build_run_table(Backend& be, uint32_t* P, uint64_t n, int bits)
 
 // Alphabet scan + packing of the raw device text dT into P (input
 // preparation on device).  present_dev: 8 x u32, lut_dev: 256 bytes.  Returns BITS.
-inline int prepare_text(Backend& be, const uint8_t* dT, uint64_t n, uint32_t* P, uint32_t* present_dev, uint8_t* lut_dev)
+// arena_bits: the code width the arena at P was sized for; a text that needs more is refused (CAPS_SA_EALPHABET thrown as
+// std::length_error: the caller sized the workspace for a smaller alphabet than the text has).
+struct AlphabetError : std::length_error { AlphabetError() : std::length_error("the text has more than 4 distinct bytes, the workspace was sized for 2-bit codes") {} };
+inline int prepare_text(Backend& be, const uint8_t* dT, uint64_t n, uint32_t* P, uint32_t* present_dev, uint8_t* lut_dev, int arena_bits = 8)
 {
     // present_dev: 16 x u32 -- [0..8) the presence bits, [8] pack_kernel's "unknown byte" flag
     auto alphabet = [&](uint64_t len, uint32_t present[8]) {
@@ -348,6 +354,7 @@ inline int prepare_text(Backend& be, const uint8_t* dT, uint64_t n, uint32_t* P,
     }
     alphabet(n, present);
     const int bits = build_lut(present, lut);
+    if (bits > arena_bits) throw AlphabetError();
     pack(bits, lut, nullptr);
     build_run_table(be, P, n, bits);              // ends with a sync (lut[] lives on this stack frame)
     return bits;
@@ -405,7 +412,7 @@ template <typename idx_t> struct SortResult {
     // letter-run buckets (text.h "letter runs"): they sat out the sort; finalize() orders them by their run keys
     struct RunBucket { uint64_t s0, s1, key; };
     std::vector<RunBucket> run_buckets;
-    SegBufs run_tables;                                               // segment tables for their sort (the parents': idle by then)
+    SegBufs run_tables;                                               // segment tables for their sort (the bucket tables: idle by then)
     const BucketBufs* run_bk = nullptr;
     TileDesc* run_desc = nullptr;
     uint64_t total = 0;                                               // elements of the whole sort (= end of the result arrays)
@@ -577,7 +584,8 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
                 for (uint64_t j = 0; j < cnt; ++j) r.run_buckets.push_back({rl[2 + 4 * j], rl[3 + 4 * j], rl[4 + 4 * j]});
                 std::sort(r.run_buckets.begin(), r.run_buckets.end(),
                           [](const typename SortResult<idx_t>::RunBucket& a, const typename SortResult<idx_t>::RunBucket& b) { return a.s0 < b.s0; });
-                r.run_tables = s;
+                r.run_tables = bk.sub;               // (idle once finalize() has gathered the sorted buckets; the parents' tables may
+                                                     //  belong to a wave whose neighbours are still to be sorted)
                 r.run_bk = &bk;
                 r.run_desc = desc;
                 r.total = n_elems;
@@ -836,9 +844,29 @@ inline int direct_shape(uint64_t n, uint32_t p, uint64_t m, uint32_t* PG, uint32
 }
 
 
+// Consumer of finished slices of the result (capi_impl.h build_host: copies them to the caller's arrays on a second stream while
+// the next groups are still being sorted).  Called on the host when everything that produces SA / LCP[base, base + cnt) has been
+// enqueued on the build's stream.
+struct WaveSink {
+    virtual void wave_done(Backend& be, uint64_t base, uint64_t cnt) = 0;
+    virtual ~WaveSink() {}
+};
+
 template <typename idx_t> class Builder {
 public:
     Builder(Backend& be, const Plan<idx_t>& pl) : be_(be), pl_(pl) {}
+    // The direct path's level B + tile sort in `waves` runs over consecutive groups (= consecutive slices of the suffix array),
+    // each reported to `sink` as soon as it is enqueued.  One wave (the default) is the device-resident build.
+    // scratch: element arrays for the largest wave (scratch_elems entries each).  While later waves' input still sits in buffer A
+    // (level A's streams, a view over ALL of A's bytes), nothing may use A's arrays as a work buffer: the waves sort in scratch and B.
+    void set_waves(uint32_t waves, WaveSink* sink, ElemBuf<idx_t> scratch = ElemBuf<idx_t>(), uint64_t scratch_elems = 0)
+    {
+        waves_ = waves ? waves : 1;
+        sink_ = sink;
+        wave_scratch_ = scratch;
+        wave_scratch_elems_ = scratch_elems;
+    }
+    bool sink_served() const { return sink_served_; }          // every slice of the result went through the sink
 
     // dT: n raw bytes on the device.  dSA/dLCP: n idx_t each on the device.
     void build(const uint8_t* dT, idx_t* dSA, idx_t* dLCP, caps_sa_stats* st)
@@ -847,7 +875,7 @@ public:
         if (st) { *st = caps_sa_stats(); st->n = n; st->idx_bytes = sizeof(idx_t); st->p_eff = pl_.p; }
         if (n == 0) return;
         BackendEvent e0 = be_.record();
-        bits_ = prepare_text(be_, dT, n, pl_.P, pl_.present, pl_.lut);
+        bits_ = prepare_text(be_, dT, n, pl_.P, pl_.present, pl_.lut, pl_.text_bits);
         BackendEvent e1 = be_.record();
         if (bits_ == 2) run<2>(dSA, dLCP, st, e0, e1);
         else run<8>(dSA, dLCP, st, e0, e1);
@@ -859,6 +887,11 @@ private:
     Backend& be_;
     const Plan<idx_t>& pl_;
     int bits_ = 0;
+    uint32_t waves_ = 1;
+    WaveSink* sink_ = nullptr;
+    ElemBuf<idx_t> wave_scratch_;
+    uint64_t wave_scratch_elems_ = 0;
+    bool sink_served_ = false;
     KernelClock merge_clock_;
     KernelClock tile_clock_;
     KernelClock scatter_clock_;
@@ -1172,13 +1205,19 @@ private:
                     (const uint64_t*)rstart, (const uint64_t*)rcap, groups.seg_start, groups.seg_end, pl_.dstat);
         ::caps::prepare_segments(be_, groups, n / TILE_E + n_streams + 1, nullptr, nullptr, true);
         uint64_t out2[2], dstat[4];
+        // waves (set_waves): the groups' sizes on the host tell where every wave's slice of the suffix array starts
+        uint32_t W = (k32 || waves_ < 2 || !wave_scratch_.key) ? 1u : std::min<uint32_t>(waves_, K1);
+        std::vector<idx_t> h_cur;
+        if (W > 1) {
+            h_cur.resize(n_streams);
+            be_.d2h(h_cur.data(), pl_.dcur, (size_t)n_streams * sizeof(idx_t));
+        }
         be_.d2h(out2, groups.out2, sizeof out2);
         be_.d2h(dstat, pl_.dstat, sizeof dstat);
         be_.sync();                                   // out2 = {#tiles, largest sub-stream (clamped to its region)}
         direct_groups_ = K1;
         direct_max_group_ = dstat[1] ? dstat[1] : out2[1];
         if (dstat[1] != 0 || dstat[0] != n) { path_fallback_ = CAPS_SA_FB_GROUP_OVERFLOW; return false; }
-        const uint32_t n_tiles2 = (uint32_t)out2[0];
         max_part_ = out2[1];
         e2_ = e1;                                     // no sort_subarrays, no locate_pivots
         e4_ = e3_;
@@ -1199,13 +1238,67 @@ private:
         if (k32) { o2.k32 = true; o2.range_mode = 2; o2.gshift = pl_.gshift; }
         o2.in_key = a_key;
         o2.in_sa = a_sa;
-        set_final(o2, dSA, dLCP);
-        SortResult<idx_t> r2 = seg_sort<BITS>(groups, n_tiles2, max_part_, pl_.A, pl_.B, n, o2, true);
-        if (r2.failed) return run_direct<BITS>(dSA, dLCP, PG, K1, e1, false);      // a slot overflowed under 32-bit keys: again with 64
-        passes2_ = r2.passes;
-        run_buckets_ = (uint32_t)r2.run_buckets.size();
+        passes2_ = 0;
+        run_buckets_ = 0;
+        // wave boundaries: consecutive groups, about n / W suffixes each, never more than the scratch arrays hold
+        std::vector<uint32_t> wave_end;
+        if (W > 1) {
+            auto group_size = [&](uint32_t g) {
+                uint64_t z = 0;
+                for (uint32_t x = 0; x < SUB; ++x) { const uint32_t s = g * SUB + x; z += (uint64_t)h_cur[big_tiles ? (size_t)(s % SUB) * K1 + s / SUB : s]; }
+                return z;
+            };
+            const uint64_t target = std::min<uint64_t>((n + W - 1) / W, wave_scratch_elems_);
+            uint64_t acc = 0;
+            for (uint32_t g = 0; g < K1; ++g) {
+                const uint64_t z = group_size(g);
+                if (z > wave_scratch_elems_) { wave_end.clear(); break; }            // a group the scratch cannot take: one wave
+                if (acc && acc + z > target) { wave_end.push_back(g); acc = 0; }
+                acc += z;
+                if (g + 1 == K1) wave_end.push_back(K1);
+            }
+            W = wave_end.empty() ? 1u : (uint32_t)wave_end.size();
+        }
+        uint64_t base = 0;
+        for (uint32_t w = 0; w < W; ++w) {
+            const uint32_t g0 = W > 1 && w ? wave_end[w - 1] : 0u, g1 = W > 1 ? wave_end[w] : K1;
+            SegBufs gw = groups;
+            uint32_t n_tiles_w = (uint32_t)out2[0];
+            uint64_t max_len_w = out2[1], elems_w = n;
+            SortOpts ow = o2;
+            if (W > 1) {
+                // the wave's streams as a segment list of their own (the tile tables are rebuilt for it)
+                gw.seg_start = groups.seg_start + (size_t)g0 * SUB;
+                gw.seg_end = groups.seg_end + (size_t)g0 * SUB;
+                gw.G = (g1 - g0) * SUB;
+                elems_w = 0;
+                max_len_w = 0;
+                uint64_t tiles = 0;
+                for (uint32_t s = g0 * SUB; s < g1 * SUB; ++s) {
+                    const uint64_t z = (uint64_t)h_cur[big_tiles ? (size_t)(s % SUB) * K1 + s / SUB : s];     // (slot_segments_kernel's layout)
+                    elems_w += z;
+                    max_len_w = std::max(max_len_w, z);
+                    tiles += (z + TILE_E - 1) / TILE_E;
+                }
+                n_tiles_w = (uint32_t)tiles;
+                ::caps::prepare_segments(be_, gw, tiles + 1, nullptr, nullptr, true);
+                ow.part_off = g0;
+                if (quantile) { ow.knots = pl_.knots + (size_t)g0 * KPG; ow.knots_have_prev = g0 > 0; }
+            }
+            set_final(ow, dSA + base, dLCP + base);
+            if (elems_w) {
+                SortResult<idx_t> r2 = seg_sort<BITS>(gw, n_tiles_w, max_len_w, W > 1 ? wave_scratch_ : pl_.A, pl_.B, elems_w, ow, true);
+                if (r2.failed) return run_direct<BITS>(dSA, dLCP, PG, K1, e1, false);      // a slot overflowed under 32-bit keys: again with 64
+                passes2_ = std::max(passes2_, r2.passes);
+                run_buckets_ += (uint32_t)r2.run_buckets.size();
+                finalize<idx_t, BITS>(be_, pl_.P, n, r2, dSA + base, dLCP + base);
+                if (base) CAPS_LAUNCH((wave_head_lcp_kernel<idx_t, BITS>), 1, 64, be_, (const uint32_t*)pl_.P, n, (const idx_t*)dSA, dLCP, base);
+            }
+            if (sink_ && elems_w) sink_->wave_done(be_, base, elems_w);
+            base += elems_w;
+        }
+        sink_served_ = sink_ != nullptr;
         e6_ = be_.record();
-        finalize<idx_t, BITS>(be_, pl_.P, n, r2, dSA, dLCP);
         e7_ = be_.record();
         return true;
     }

@@ -75,21 +75,22 @@ constexpr uint32_t RUN_NT = 256;            // threads per workgroup of the run-
 constexpr uint32_t RUN_PER = 8;             // consecutive blocks per thread
 constexpr uint32_t RUN_CHUNK = RUN_NT * RUN_PER;
 
-HD uint64_t run_table_offset_words(uint64_t n) { return (packed_words(n, 8) + 1) & ~1ull; }   // u32 words from P
+// The layout depends on the code width: a text arena of 2-bit codes is n / 4 (text) + n / 4 (table) bytes, one of 8-bit codes 2 n.
+HD uint64_t run_table_offset_words(uint64_t n, int bits) { return (packed_words(n, bits) + 1) & ~1ull; }   // u32 words from P
 HD uint64_t run_table_entries(uint64_t n, int bits) { return n / (64 / bits) + 2; }
 HD uint64_t run_table_chunks(uint64_t entries) { return (entries + RUN_CHUNK - 1) / RUN_CHUNK; }
-// u32 words of one text allocation: packed text + flag + run table (sized for BITS = 8, the larger
-// case) + the two per-chunk arrays of its construction
-HD uint64_t text_alloc_words(uint64_t n)
+// u32 words of one text allocation for `bits`-wide codes: packed text + flag + run table + the two per-chunk arrays of its
+// construction.  bits = 8 holds any text (a 2-bit text then uses the front of it).
+HD uint64_t text_alloc_words(uint64_t n, int bits = 8)
 {
-    const uint64_t e = run_table_entries(n, 8);
-    return run_table_offset_words(n) + 2 * (2 + e + 2 * run_table_chunks(e));
+    const uint64_t e = run_table_entries(n, bits);
+    return run_table_offset_words(n, bits) + 2 * (2 + e + 2 * run_table_chunks(e));
 }
-HD const uint64_t* run_table(const uint32_t* P, uint64_t n)
+template <int BITS> HD const uint64_t* run_table(const uint32_t* P, uint64_t n)
 {
-    return reinterpret_cast<const uint64_t*>(P + run_table_offset_words(n)) + 2;
+    return reinterpret_cast<const uint64_t*>(P + run_table_offset_words(n, BITS)) + 2;
 }
-HD uint64_t* run_table_mut(uint32_t* P, uint64_t n) { return reinterpret_cast<uint64_t*>(P + run_table_offset_words(n)) + 2; }
+HD uint64_t* run_table_mut(uint32_t* P, uint64_t n, int bits) { return reinterpret_cast<uint64_t*>(P + run_table_offset_words(n, bits)) + 2; }
 
 // Smallest period d in [1, KCH/2] of the KCH chars of block word w; 0 if there is none.
 template <int BITS> HD uint32_t block_period(uint64_t w)
@@ -146,7 +147,7 @@ HD uint64_t deep_scan(const uint32_t* __restrict__ P, uint64_t n, uint64_t a, ui
         if (wa != wb) return l + (uint32_t)caps_clz64(wa ^ wb) / BITS;
     }
     if (l >= maxlen) return maxlen;
-    const uint64_t* __restrict__ R = run_table(P, n);
+    const uint64_t* __restrict__ R = run_table<BITS>(P, n);
     while (l < maxlen) {
         // the four windows and the two table entries of a step are fetched TOGETHER: one memory latency per step instead of
         // three (a merge over the suffixes of an N-block makes ~20 such comparisons per element and pass)
@@ -322,7 +323,7 @@ template <int BITS>
 HD uint64_t letter_run_end(const uint32_t* __restrict__ P, uint64_t n, uint64_t pos, uint64_t key)
 {
     constexpr uint32_t KCH = TextTraits<BITS>::KCH;
-    const uint64_t* __restrict__ R = run_table(P, n);
+    const uint64_t* __restrict__ R = run_table<BITS>(P, n);
     uint64_t x = pos + KCH;                                     // chars [pos, x) are c (or lie past the end: code 0 = c)
     while (x < n) {
         const uint64_t w = window64<BITS>(P, x);

@@ -33,6 +33,7 @@ extern "C" {
 #define CAPS_SA_EHIP (-3)         /* HIP runtime error; see caps_sa_hip_last_error() */
 #define CAPS_SA_ENOMEM (-4)       /* device or host allocation failed */
 #define CAPS_SA_ENODEVICE (-5)    /* no usable GPU */
+#define CAPS_SA_EALPHABET (-6)    /* the workspace was sized for a 2-bit text (caps_sa_hip_workspace_bytes_ex), the text has more than 4 bytes */
 
 /* Per-build record; replaces the per-phase stderr lines of construct()
  * (src/Suffix_Array.cpp:469-493).  Times are HIP-event milliseconds on the build's stream. */
@@ -118,8 +119,13 @@ void caps_sa_hip_host_free(void* p);
  */
 int caps_sa_hip_gen_rand_seq(uint32_t seed, uint64_t n, char* out);
 
-/* Device workspace a build of n suffixes needs (bytes). */
+/* Device workspace a build of n suffixes needs (bytes), for any text. */
 int caps_sa_hip_workspace_bytes(uint64_t n, uint64_t subproblem_count, int idx_bytes, uint64_t* bytes);
+/* The same for a text of at most 4 distinct bytes (bits_per_char = 2: everything behind the reference CLI, src/main.cpp:61-70):
+ * the packed text and its run table then take n / 2 bytes instead of 2 n.  caps_sa_hip_build_device_* reads the alphabet it
+ * may assume off the size of the workspace it is given; a text with more letters is refused with CAPS_SA_EALPHABET.
+ * bits_per_char = 8 is caps_sa_hip_workspace_bytes. */
+int caps_sa_hip_workspace_bytes_ex(uint64_t n, uint64_t subproblem_count, int idx_bytes, int bits_per_char, uint64_t* bytes);
 
 /*
  * Replaces the body of Suffix_Array<uint32_t>::construct() / <uint64_t>

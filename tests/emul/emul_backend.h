@@ -55,6 +55,9 @@ public:
     void sync() {}
     static void* create_stream() { return nullptr; }
     static void destroy_stream(void*) {}
+    static void stream_wait(void*, BackendEvent) {}
+    static void d2h_on(void*, void* h, const void* d, size_t bytes) { std::memcpy(h, d, bytes); }
+    static void sync_stream(void*) {}
     void peer_copy(void* dst, int, const void* src, int, size_t bytes) { std::memmove(dst, src, bytes); }
     uint32_t persistent_blocks() { return 3; }     // small on purpose: exercises the tile loop
     void check_launch(const char*) {}
