@@ -11,7 +11,7 @@
 //  * errors: the reference calls std::exit (src/Suffix_Array.cpp:33-37); construct()
 //    here throws std::runtime_error carrying caps_sa_hip_last_error();
 //  * valid for every n >= 0 (the reference divides by zero for n < 32 / p_eff < 2);
-//  * bounded max_context is rejected (output not unique);
+//  * bounded max_context (0 < max_context < n) runs the reference's own merge sequence on ONE device (csrc/bounded.h);
 //  * SA_ / LCP_ are page-locked (caps_sa_hip_host_alloc) when the driver grants it, plain malloc otherwise: the
 //    results then leave the GPU at the PCIe link rate (C2: 38 ms instead of 88 ms for the two arrays) -- like the
 //    reference's mallocs (src/Suffix_Array.cpp:20-21) the allocation belongs to the constructor, not to construct();

@@ -78,10 +78,9 @@ template <typename idx_t> int check_common(const void* T, uint64_t n, uint64_t m
     if (n && !T) return fail(CAPS_SA_EINVAL, "null text");
     if (n > (uint64_t)std::numeric_limits<idx_t>::max())
         return fail(CAPS_SA_EINVAL, "n does not fit the index type (use the _u64 entry point, src/main.cpp:76)");
-    if (max_context != 0 && max_context < n)
-        return fail(CAPS_SA_EUNSUPPORTED,
-                    "bounded max_context is not supported: its output depends on the merge history "
-                    "(src/Suffix_Array.cpp:72,76-77) and is unpinned by any reference test");
+    // bounded context (csrc/bounded.h): defined where the reference is -- n >= 32 and at least two subproblems
+    if (max_context != 0 && max_context < n && n < 32)
+        return fail(CAPS_SA_EUNSUPPORTED, "bounded max_context needs n >= 32 (the reference is undefined below that)");
     return CAPS_SA_OK;
 }
 
@@ -132,7 +131,9 @@ int build_device(const void* dT, uint64_t n, uint64_t p_arg, uint64_t max_contex
             } else scratch_elems = 0;
         }
         b.set_waves(waves, sink, scratch, scratch_elems);
-        b.build(static_cast<const uint8_t*>(dT), static_cast<idx_t*>(dSA), static_cast<idx_t*>(dLCP), stats);
+        if (max_context != 0 && max_context < n && pl.p < 2)
+            return fail(CAPS_SA_EUNSUPPORTED, "bounded max_context needs at least two subproblems (the reference divides by zero there)");
+        b.build(static_cast<const uint8_t*>(dT), static_cast<idx_t*>(dSA), static_cast<idx_t*>(dLCP), stats, max_context);
         if (sink_served) *sink_served = b.sink_served();
         return CAPS_SA_OK;
     });
@@ -215,7 +216,9 @@ int build_host(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context, 
         const Plan<idx_t> need = make_plan<idx_t>(n, p_arg, nullptr, text_bits);
         const size_t off_sa = up(n ? n : 1), off_lcp = off_sa + up((n ? n : 1) * sizeof(idx_t));
         const size_t off_ws = off_lcp + up((n ? n : 1) * sizeof(idx_t));
-        uint32_t waves = CAPS_HOST_WAVES;
+        // waves pay when the build is long enough to hide: measured at C2 (256 Mi: 5 ms of build against 38 ms of copies) twelve
+        // waves cost 14 ms (per-wave host synchronisations, 24 copies instead of 2), at C3 (3e9) they save 31 of 524 ms
+        uint32_t waves = n >= (400ull << 20) ? CAPS_HOST_WAVES : 1u;
         if (const char* e = std::getenv("CAPS_SA_HOST_WAVES")) waves = (uint32_t)std::max(1, std::atoi(e));
         const size_t total = off_ws + need.bytes + 1024 + wave_scratch_bytes<idx_t>(wave_scratch_elems(n, waves));
         if (hc.device != device || hc.bytes < total) {
@@ -331,6 +334,8 @@ int build_multi(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context,
     if (int rc = check_common<idx_t>(T, n, max_context)) return rc;
     if (n && (!SA || !LCP)) return fail(CAPS_SA_EINVAL, "null output");
     if (n_devices == 1) return build_host<idx_t>(T, n, p_arg, max_context, SA, LCP, devices[0], stats);
+    // bounded context: the reference's merge trees are one sequence (csrc/bounded.h); built on devices[0] alone
+    if (max_context != 0 && max_context < n) return build_host<idx_t>(T, n, p_arg, max_context, SA, LCP, devices[0], stats);
     DeviceScope restore_device_;
     for (int i = 0; i < n_devices; ++i)
         if (int rc = set_device(devices[i])) return rc;

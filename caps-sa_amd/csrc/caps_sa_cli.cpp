@@ -4,8 +4,8 @@
 //     caps_sa <input_path> <output_path> [subproblem-count] [bounded-context] [--pretty-print] [--gpus N]
 //
 // * --gpus N (not in the reference): shard the build over HIP devices 0 .. N-1;
-// * bounded-context: only 0 or a value >= the text length is accepted (the bounded mode's output is not unique and is not
-//   implemented: SURVEY.md 8f row f4) -- checked before anything is written;
+// * bounded-context (main.cpp:57): 0 or >= the text length = the suffix array; a smaller bound takes the reference's own
+//   sequence of merges (csrc/bounded.h: its output depends on them; a compatibility mode, seconds instead of milliseconds);
 // * every input byte is remapped to {A,C,G,T} with lookup[(toupper(c) & 0x6) >> 1],
 //   lookup = {A,C,T,G} (main.cpp:61-70) -- FASTA headers and newlines are kept and remapped;
 // * n = file size; n <= UINT32_MAX selects 32-bit indices, else 64-bit (main.cpp:76-87);
@@ -85,8 +85,7 @@ int main(int argc, char* argv[])
     }
     if (pos.size() < 2) {
         std::cerr << "Usage: caps_sa <input_path> <output_path> <(optional)-subproblem-count> "
-                     "<(optional)-bounded-context> <(optional)--pretty-print> <(optional)--gpus N>\n"
-                     "  bounded-context: 0 (default) or >= the text length; a smaller bound is not supported\n";
+                     "<(optional)-bounded-context> <(optional)--pretty-print> <(optional)--gpus N>\n";
         return EXIT_FAILURE;
     }
     size_t p = 0, ctx = 0;
@@ -95,11 +94,6 @@ int main(int argc, char* argv[])
 
     std::string text;
     if (!read_input(pos[0], text)) return EXIT_FAILURE;
-    if (ctx != 0 && ctx < text.size()) {
-        std::cerr << "bounded-context " << ctx << " < text length " << text.size()
-                  << ": the bounded mode is not supported (its output depends on the merge order)\n";
-        return EXIT_FAILURE;
-    }
     // the byte remap of main.cpp:61-70, on all host threads like the reference's parallel_for
     {
         static const char lookup[4] = {'A', 'C', 'T', 'G'};

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "bounded.h"
 #include "../../include/caps_sa_hip.h"
 
 // The backend (device memory, copies, launches, events): hip_backend.h in the product.  A translation unit that has
@@ -868,8 +869,9 @@ public:
     }
     bool sink_served() const { return sink_served_; }          // every slice of the result went through the sink
 
-    // dT: n raw bytes on the device.  dSA/dLCP: n idx_t each on the device.
-    void build(const uint8_t* dT, idx_t* dSA, idx_t* dLCP, caps_sa_stats* st)
+    // dT: n raw bytes on the device.  dSA/dLCP: n idx_t each on the device.  max_context: 0 or >= n = the suffix array and
+    // LCP array of T; else the reference's bounded-context result (bounded.h).
+    void build(const uint8_t* dT, idx_t* dSA, idx_t* dLCP, caps_sa_stats* st, uint64_t max_context = 0)
     {
         const uint64_t n = pl_.n;
         if (st) { *st = caps_sa_stats(); st->n = n; st->idx_bytes = sizeof(idx_t); st->p_eff = pl_.p; }
@@ -877,6 +879,29 @@ public:
         BackendEvent e0 = be_.record();
         bits_ = prepare_text(be_, dT, n, pl_.P, pl_.present, pl_.lut, pl_.text_bits);
         BackendEvent e1 = be_.record();
+        if (max_context != 0 && max_context < n) {
+            if (pl_.p < 2 || pl_.ppp < 1) throw std::invalid_argument("bounded max_context needs n >= 32 and at least two subproblems (the reference is undefined below that)");
+            if (bits_ == 2) run_bounded<2>(dSA, dLCP, max_context);
+            else run_bounded<8>(dSA, dLCP, max_context);
+            BackendEvent e2 = be_.record();
+            be_.sync();
+            if (st) {
+                st->bits_per_char = (uint32_t)bits_;
+                st->ppp = pl_.ppp;
+                st->workspace_bytes = pl_.bytes;
+                st->ms_pack = be_.elapsed_ms(e0, e1);
+                st->ms_total = be_.elapsed_ms(e0, e2);
+                st->ms_sort_subarrays = be_.elapsed_ms(e1, e2_);
+                st->ms_select_pivots = be_.elapsed_ms(e2_, e3_);
+                st->ms_locate_pivots = be_.elapsed_ms(e3_, e4_);
+                st->ms_partition = be_.elapsed_ms(e4_, e5_);
+                st->ms_merge_partitions = be_.elapsed_ms(e5_, e6_);
+                st->ms_boundary_lcp = be_.elapsed_ms(e6_, e2);
+                st->path_fallback = CAPS_SA_FB_BOUNDED;
+            }
+            be_.release_events();
+            return;
+        }
         if (bits_ == 2) run<2>(dSA, dLCP, st, e0, e1);
         else run<8>(dSA, dLCP, st, e0, e1);
     }
@@ -937,6 +962,51 @@ private:
         o.bnd.last_key = pl_.bk.last_key;
         o.bnd.first_sa = pl_.bk.first_sa;
         o.bnd.last_sa = pl_.bk.last_sa;
+    }
+
+    // ---- bounded context (bounded.h): the reference's own sequence, one thread per merge node ----
+    static uint32_t tree_depth(uint64_t cnt) { uint32_t d = 0; while ((1ull << d) < cnt) ++d; return d; }
+    template <int BITS>
+    void run_bounded(idx_t* dSA, idx_t* dLCP, uint64_t ctx)
+    {
+        const uint64_t n = pl_.n, s = n / pl_.p, last = s + n % pl_.p, m = pl_.ppp, nsamp = pl_.m;
+        const uint32_t p = pl_.p;
+        idx_t *SAw = pl_.A.sa, *LCPw = pl_.A.lcp;
+        idx_t *pivot = pl_.SA_.sa, *pw = pl_.SB_.sa, *t1 = pl_.SA_.lcp, *t2 = pl_.SB_.lcp;
+        idx_t *Pm = pl_.Pm, *ruler = pl_.PmT;
+        uint64_t* scan = pl_.seg2.seg_start;
+        const uint32_t* P = pl_.P;
+        auto grid = [](uint64_t threads) { return capped_grid((threads + 255) / 256, 256); };
+        // permute + sort_subarrays (:148-184)
+        CAPS_LAUNCH((bounded_init_kernel<idx_t>), grid(n), 256, be_, n, (const idx_t*)nullptr, dSA, SAw, dLCP, LCPw);
+        for (uint32_t d = tree_depth(last); d-- > 0;)
+            CAPS_LAUNCH((bounded_sort_level_kernel<idx_t, BITS>), grid((uint64_t)p << d), 256, be_, P, n, ctx, n, p, s, d, dSA, dLCP, SAw, LCPw);
+        e2_ = be_.record();
+        // select_pivots (:197-222)
+        CAPS_LAUNCH((bounded_sample_kernel<idx_t>), grid((uint64_t)p * m), 256, be_, (const idx_t*)dSA, n, p, s, m, pivot);
+        CAPS_LAUNCH((bounded_init_kernel<idx_t>), grid(nsamp), 256, be_, nsamp, (const idx_t*)pivot, pw, pivot, t1, t2);
+        for (uint32_t d = tree_depth(nsamp); d-- > 0;)
+            CAPS_LAUNCH((bounded_sort_level_kernel<idx_t, BITS>), grid(1ull << d), 256, be_, P, n, ctx, nsamp, 1u, nsamp, d, pw, t1, pivot, t2);
+        CAPS_LAUNCH((bounded_sample_kernel<idx_t>), grid(p - 1), 256, be_, (const idx_t*)pw, nsamp, 1u, nsamp, (uint64_t)(p - 1), pivot);
+        e3_ = be_.record();
+        // locate_pivots (:225-249)
+        CAPS_LAUNCH((bounded_locate_kernel<idx_t, BITS>), grid((uint64_t)p * (p + 1)), 256, be_, P, n, ctx, p, s, (const idx_t*)dSA, (const idx_t*)pivot, Pm);
+        e4_ = be_.record();
+        // partition_sub_subarrays (:300-368) + the duplication of merge_sub_subarrays (:376-384)
+        CAPS_LAUNCH((bounded_ruler_kernel<idx_t>), (p + 255) / 256, 256, be_, p, (const idx_t*)Pm, ruler, pl_.sizes);
+        CAPS_LAUNCH(scan_sizes_kernel, 1, 1024, be_, (const uint64_t*)pl_.sizes, p, scan);
+        CAPS_LAUNCH((bounded_collate_kernel<idx_t>), grid(n), 256, be_, n, p, s, (const uint64_t*)scan, (const idx_t*)ruler, (const idx_t*)Pm,
+                    (const idx_t*)dSA, (const idx_t*)dLCP, SAw, LCPw);
+        be_.d2d(dSA, SAw, n * sizeof(idx_t));
+        be_.d2d(dLCP, LCPw, n * sizeof(idx_t));
+        e5_ = be_.record();
+        // merge_sub_subarrays (:386-409): sort_partition's merge tree of every partition
+        for (uint32_t d = tree_depth(p); d-- > 0;)
+            CAPS_LAUNCH((bounded_partition_level_kernel<idx_t, BITS>), grid((uint64_t)p << d), 256, be_, P, n, ctx, p, (const uint64_t*)scan,
+                        (const idx_t*)ruler, d, dSA, dLCP, SAw, LCPw);
+        e6_ = be_.record();
+        // compute_partition_boundary_lcp (:431-447)
+        CAPS_LAUNCH((bounded_boundary_kernel<idx_t, BITS>), (p + 255) / 256, 256, be_, P, n, p, (const uint64_t*)scan, (const idx_t*)dSA, dLCP);
     }
 
     // ---- the samplesort path: the reference's six phases (src/Suffix_Array.cpp:466-494) ----

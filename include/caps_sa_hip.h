@@ -29,7 +29,7 @@ extern "C" {
 
 #define CAPS_SA_OK 0
 #define CAPS_SA_EINVAL (-1)       /* bad argument (null pointer, n too large for the index type) */
-#define CAPS_SA_EUNSUPPORTED (-2) /* bounded max_context (output not unique) */
+#define CAPS_SA_EUNSUPPORTED (-2) /* bounded max_context on several devices / in a shard, or with fewer than two subproblems */
 #define CAPS_SA_EHIP (-3)         /* HIP runtime error; see caps_sa_hip_last_error() */
 #define CAPS_SA_ENOMEM (-4)       /* device or host allocation failed */
 #define CAPS_SA_ENODEVICE (-5)    /* no usable GPU */
@@ -88,6 +88,7 @@ typedef struct caps_sa_stats {
 #define CAPS_SA_FB_PIVOT_TIES 4    /* two sampled pivots share their key */
 #define CAPS_SA_FB_GROUP_OVERFLOW 5 /* a group outgrew its region (a very frequent key) */
 #define CAPS_SA_FB_KEY32 6         /* sharded build: a bucket slot overflowed under 32-bit keys; repeat with caps_sa_hip_shard_set_key_bits(s, 64) */
+#define CAPS_SA_FB_BOUNDED 7       /* 0 < max_context < n: the reference's own sequence, one thread per merge node (csrc/bounded.h) */
 
 int caps_sa_hip_device_count(void);
 const char* caps_sa_hip_last_error(void);

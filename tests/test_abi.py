@@ -39,7 +39,7 @@ def test_argument_errors_without_gpu():
     lib = caps_sa_amd.lib()
     T = np.frombuffer(b"ACGT" * 10, dtype=np.uint8)
     with pytest.raises(caps_sa_amd.CapsSaError) as e:
-        lib.build(T, max_context=5)                    # bounded context: unsupported, checked before any GPU work
+        lib.build(T[:20], max_context=5)               # bounded context below the reference's domain (n < 32): checked before any GPU work
     assert e.value.code == -2
     assert lib.workspace_bytes(1 << 20, 64, 32) > (1 << 20) * 32
 

@@ -74,13 +74,41 @@ def test_u64_indices(oracle):
     _same(emul(), oracle, rs.choice(DNA, size=120000), 11, bits=64)
 
 
-def test_unbounded_context_only(oracle):
-    E = emul()
-    T = np.random.RandomState(6).choice(DNA, size=1000)
+def _bounded(E, oracle, T, p, ctx, bits=32):
+    SA, LCP, st = E.build(T, p=p, max_context=ctx, idx_bits=bits)
+    SAo, LCPo = oracle.build_sa_lcp(T, p=p, max_context=ctx, idx_bits=bits)[:2]
+    assert np.array_equal(SA, SAo), f"SA mismatch n={T.size} p={p} ctx={ctx}"
+    assert np.array_equal(LCP, LCPo), f"LCP mismatch n={T.size} p={p} ctx={ctx}"
+    return st
+
+
+def test_bounded_context_follows_the_reference_merge_history(oracle):
+    """SURVEY f4 (csrc/bounded.h): with 0 < max_context < n ties are broken by the reference's merge order (src/Suffix_Array.cpp:
+    71-92), so the whole sequence -- merge_sort's halving, truncated-gap pivots, truncated upper_bound, sort_partition's tree --
+    is reproduced, one thread per merge node.  PARITY UNPINNED by the reference (no vector exists): compared with the oracle's
+    restatement of the same functions, on texts where ties are everywhere (tiny contexts, unary, periodic, a text repeated
+    three times), with 64-bit indices and 8-bit codes."""
     import caps_sa_amd
-    with pytest.raises(caps_sa_amd.CapsSaError):
-        E.build(T, max_context=10)
-    E.build(T, max_context=1000)        # >= n is unbounded
+    E = emul()
+    rs = np.random.RandomState(5)
+    assert _bounded(E, oracle, rs.choice(DNA, size=5000), 7, 3)["path_fallback"] == 7          # CAPS_SA_FB_BOUNDED
+    _bounded(E, oracle, rs.choice(DNA, size=5000), 0, 5)
+    _bounded(E, oracle, rs.choice(DNA, size=20001), 13, 8)
+    _bounded(E, oracle, rs.choice(DNA, size=20001), 13, 1)
+    _bounded(E, oracle, rs.choice(DNA, size=3000), 16, 2, bits=64)
+    _bounded(E, oracle, np.tile(rs.choice(DNA, size=37), 200), 9, 20)
+    _bounded(E, oracle, np.full(4000, ord("A"), np.uint8), 4, 10)
+    _bounded(E, oracle, rs.choice(np.frombuffer(b"abcdefgh\x80\xff", dtype=np.uint8), size=8000), 5, 2)
+    _bounded(E, oracle, rs.choice(DNA, size=5000), 7, 4999)
+    S = rs.choice(DNA, size=3000)
+    _bounded(E, oracle, np.concatenate([S, S, S]), 6, 50)
+    _bounded(E, oracle, rs.choice(DNA, size=100), 0, 3)
+    T = rs.choice(DNA, size=1000)
+    a = E.build(T, max_context=1000)        # >= n is unbounded: the suffix array itself
+    b = E.build(T)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    with pytest.raises(caps_sa_amd.CapsSaError):          # below the reference's domain (n < 32: it divides by zero)
+        E.build(T[:20], max_context=3)
 
 
 def test_kernel_level_entry_points(oracle):

@@ -129,12 +129,26 @@ def test_u64_indices(L, oracle):
     _same(L, oracle, rs.choice(DNA, size=1_200_000), 111, bits=64)
 
 
-def test_unbounded_context_only(L):
+def test_bounded_context_follows_the_reference_merge_history(L, oracle):
+    """SURVEY f4 (csrc/bounded.h): 0 < max_context < n reproduces the reference's merge history (ties go to run "Y",
+    src/Suffix_Array.cpp:71-92) -- PARITY UNPINNED by any reference-held vector; compared with the oracle's restatement."""
     import caps_sa_amd
-    T = np.random.RandomState(6).choice(DNA, size=1000)
+    rs = np.random.RandomState(5)
+    S = rs.choice(DNA, size=30000)
+    for T, p, ctx, bits in [(rs.choice(DNA, size=50000), 7, 3, 32), (rs.choice(DNA, size=200001), 0, 9, 32), (rs.choice(DNA, size=200001), 113, 1, 32),
+                            (rs.choice(DNA, size=30000), 16, 2, 64), (np.tile(rs.choice(DNA, size=37), 2000), 9, 20, 32),
+                            (np.full(40000, ord("A"), np.uint8), 4, 10, 32), (np.concatenate([S, S, S]), 6, 50, 32),
+                            (rs.choice(np.frombuffer(b"abcdefgh\x80\xff", dtype=np.uint8), size=80000), 5, 2, 32),
+                            (rs.choice(DNA, size=1_000_000), 8000, 12, 32)]:
+        SA, LCP, st = L.build(T, p=p, max_context=ctx, idx_bits=bits)
+        SAo, LCPo = oracle.build_sa_lcp(T, p=p, max_context=ctx, idx_bits=bits)[:2]
+        assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), (T.size, p, ctx, bits)
+        assert st["path_fallback"] == 7                      # CAPS_SA_FB_BOUNDED
+    T = rs.choice(DNA, size=1000)
+    a, b = L.build(T, max_context=1000), L.build(T)          # >= n is unbounded
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     with pytest.raises(caps_sa_amd.CapsSaError):
-        L.build(T, max_context=10)
-    L.build(T, max_context=1000)
+        L.build(T[:20], max_context=3)
 
 
 def test_kernel_level_entry_points(L, oracle):
@@ -344,6 +358,11 @@ def test_cli_dump_matches_reference_digest(L, oracle, tmp_path):
     SA, LCP = oracle.build_sa_lcp(oracle.remap(small.read_bytes()))
     assert lines[0].split() == [str(x) for x in SA.tolist()]
     assert lines[1].split() == [str(x) for x in LCP.tolist()]
+    # argv[4] = bounded context (src/main.cpp:57): the dump of the reference's bounded result (csrc/bounded.h; oracle restatement)
+    outb = tmp_path / "bounded.bin"
+    subprocess.check_call([exe, str(inp), str(outb), "64", "7"])
+    SAb, LCPb = oracle.build_sa_lcp(oracle.remap(raw), p=64, max_context=7)[:2]
+    assert hashlib.sha256(outb.read_bytes()).hexdigest() == oracle.dump_sha256(SAb, LCPb)
 
 
 def test_u64_device_resident_50m(L):
