@@ -1041,6 +1041,7 @@ constexpr uint32_t TIE_G2 = 64;                   //   per tie that is still equ
 constexpr uint32_t TIE_LIST_CAP = TILE_E / 8;     // list entries per tile (pairs from the bottom, elements' own entries from the top)
 constexpr uint32_t TIE_LIST_MAX = CAPS_TIE_LIST_MAX;   // an element lists up to this many equal keys (more: it scans them itself)
 constexpr uint32_t TIE_DEEP_CAP = 64;             // entries that may go to the second round
+constexpr uint32_t TIE_VDEEP_CAP = 32;            //   ... and on to the third (any depth: long exact duplicates)
 constexpr uint32_t EQ_FRAC_BITS = 13;             // position inside a bin; a position is bin * 2^13 + fraction < 2^24 at 2048 bins
 static_assert((uint64_t)TILE_BINS_ << EQ_FRAC_BITS <= (1u << 24), "positions fit 24 bits");
 
@@ -1058,6 +1059,15 @@ DEV_INLINE uint32_t eq_pos(const BucketParams& bp, uint64_t key)
     return x < top ? x : top;
 }
 
+// the lcp noted for slot e in the table of the few lcps beyond 15 bits (0: not there -- the caller derives it from the text)
+DEV_INLINE uint32_t eq_big_lcp(const uint16_t* vslot, const uint32_t* vlcp, uint32_t cnt, uint32_t e)
+{
+    uint32_t l = 0;
+    for (uint32_t q = 0; q < cnt && q < TIE_VDEEP_CAP; ++q)
+        if (vslot[q] == e) l = vlcp[q];
+    return l;
+}
+
 #ifndef CAPS_EQ_WAVES
 #define CAPS_EQ_WAVES TILE_WAVES_PER_SIMD
 #endif
@@ -1065,13 +1075,19 @@ DEV_INLINE uint32_t eq_pos(const BucketParams& bp, uint64_t key)
 #undef TILE_SYNC
 #define TILE_SYNC() SYNC_LDS()
 #endif
-template <typename idx_t, int BITS, bool FROM_TEXT>
+// VDEEP: the build with the third tie stage (any depth).  A build of its own, behind the plain one in the queue chain: the
+// plain kernel runs at the register budget, and the stage's code in it cost every tile of a genome-like text 14 % (76 -> 87 ms
+// at 3e9) for the sake of the few that hold an exact long duplicate.
+template <typename idx_t, int BITS, bool FROM_TEXT, bool VDEEP = false>
 GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
                                                   uint64_t text_base, uint32_t lcp_mode, uint32_t slot_cap, const uint64_t* in_key,
                                                   const idx_t* in_sa, uint64_t* out_key, idx_t* out_sa, idx_t* out_lcp,
                                                   FinalOut<idx_t> fin, const BucketParams* __restrict__ seg_map,
-                                                  const uint32_t* __restrict__ redo, uint32_t* __restrict__ redo2, uint32_t keys_from_text)
+                                                  const uint32_t* __restrict__ redo, uint32_t* __restrict__ redo2, uint32_t keys_from_text,
+                                                  uint32_t* __restrict__ redo_deep)
 {
+    // redo_deep (the plain build): the queue of the tiles whose ONLY obstacle was a tie deeper than the first two rounds see -- the
+    // VDEEP build's; everything else this kernel cannot finish goes to redo2, the comparison sort's
     // keys_from_text != 0: the slots hold 32-bit keys (tile_sort_kernel<..., uint32_t> ran first); this kernel works on the
     // 64-bit keys, cut from the text at the elements' positions (seg_map is then null: the tile's own key range)
     constexpr bool TILE_RUNS = false;
@@ -1081,7 +1097,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
     SHARED_ARRAY(idx_t, ssa, TILE_E);
     SHARED_ARRAY(uint32_t, hist, TILE_BINS + 1);
     SHARED_ARRAY(uint64_t, kmm, 2);
-    SHARED_ARRAY(uint32_t, flag, 1);
+    SHARED_ARRAY(uint32_t, flag, 2);         // [0] the tile is the comparison sort's; [1] it only needs the third tie stage
     TL_DECL(uint64_t, rk, TILE_EPT);
     TL_DECL(idx_t, rs, TILE_EPT);
     TL_DECL(uint32_t, rd, TILE_EPT);
@@ -1094,11 +1110,17 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
     SHARED_ARRAY(uint32_t, plist, TIE_LIST_CAP);      // ties: first differing window << 24 | slot << 12 | the other's slot;
                                                       //   an own entry once settled: 0x80 | the other sorts first, << 24 | lcp
     SHARED_ARRAY(uint16_t, deep, TIE_DEEP_CAP);       // entries (virtual index) still equal after the first round
-    SHARED_ARRAY(uint32_t, pcnt, 4);                  // pairs listed, own entries listed, entries on `deep`
+    SHARED_ARRAY(uint16_t, vdeep, TIE_VDEEP_CAP);     //   ... and after the second: settled one by one, the whole workgroup on each
+    SHARED_ARRAY(uint32_t, pcnt, 6);                  // pairs listed, own entries listed, entries on `deep`, on `vdeep`, [4] first hit, [5] big lcps
+    SHARED_ARRAY(uint32_t, vlcp, TIE_VDEEP_CAP);      // third stage: the lcp of pair q (too large for the 15 bits of its members' notes);
+                                                      //   after the final placement: the lcps >= 0x7FFF, with ...
+    SHARED_ARRAY(uint16_t, vslot, TIE_VDEEP_CAP);     //   ... the slots they belong to
     static_assert((TILE_BINS + 1) * sizeof(uint32_t) >= TILE_E * sizeof(uint16_t) && TILE_E <= (1u << 12) && EQ_BIN_LIMIT <= 128 &&
                   TILE_NT % TIE_G1 == 0 && TILE_NT % TIE_G2 == 0 && TIE_G1 + TIE_G2 < 0x80u && TIE_LIST_CAP <= (1u << 12) &&
-                  TextTraits<BITS>::KCH * (1u + TIE_G1 + TIE_G2) < (1u << 15),
-                  "tinfo fits hist; slots and entries fit 12 bits; ranks inside a bin fit 8 bits; lcps of settled ties fit 15 bits");
+                  TextTraits<BITS>::KCH * (1u + TIE_G1 + TIE_G2) < 0x7FFFu,
+                  "tinfo fits hist; slots and entries fit 12 bits; ranks inside a bin fit 8 bits; lcps of the first two rounds fit 15 bits");
+    // per slot: "the other member of my pair sorts before me" << 15 | their lcp (0x7FFF: see vlcp); after the final placement: the
+    // lcp with the predecessor where a tie settled it (0x7FFF: see vslot / vlcp)
     uint16_t* tinfo = reinterpret_cast<uint16_t*>(hist);
     const uint32_t n_redo = redo[0];
     // the queue entry and the record of the NEXT tile are fetched while this one is sorted (two dependent loads off the
@@ -1167,7 +1189,8 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
         PHASE_MARK(9);                                         // equalisation rounds
         PAR(tid) {
             for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0;
-            if (tid < 4) pcnt[tid] = 0;
+            if (tid < 6) pcnt[tid] = 0;
+            if (tid == 0) flag[1] = 0;
         }
         TILE_SYNC();
         PAR(tid) {
@@ -1324,8 +1347,11 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                                         tinfo[lo] = (uint16_t)(lo_first ? 0u : 0x8000u | (uint32_t)d);
                                     }
                                 } else if ((ent >> 24) == 0xFFu && tid % G == 0) {
-                                    if (round) flag[0] = 1;               // deeper than TIE_G1 + TIE_G2 windows: not here
-                                    else {
+                                    if (round) {                          // deeper than TIE_G1 + TIE_G2 windows: the third stage
+                                        const uint32_t q = VDEEP ? FETCH_ADD_U32(&pcnt[3], 1u) : TIE_VDEEP_CAP;
+                                        if (q < TIE_VDEEP_CAP) vdeep[q] = (uint16_t)vj;
+                                        else flag[VDEEP ? 0 : 1] = 1;     // (the plain build: the tile goes on to the VDEEP one)
+                                    } else {
                                         const uint32_t q = FETCH_ADD_U32(&pcnt[2], 1u);
                                         if (q < TIE_DEEP_CAP) deep[q] = (uint16_t)vj;
                                     }
@@ -1335,6 +1361,65 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                         TILE_SYNC();
                     }
                     if (round || pcnt[2] == 0) break;
+                }
+                // ---- third stage: what is still equal after TIE_G1 + TIE_G2 windows (2,300 bases: an exact duplicate of a gene, a
+                // segmental duplication; ONE exact 50-kb duplicate in a 256 Mi text left a pair like that in a third of all tiles,
+                // each of which then went to the comparison sort: 43 of 58 ms).  One entry at a time, every thread of the workgroup
+                // a window of its own, TILE_NT windows per round trip to the text, until the first difference (or the end of the
+                // shorter suffix) is in sight: any depth.
+                const uint32_t nv = !VDEEP ? 0u : pcnt[3] < TIE_VDEEP_CAP ? pcnt[3] : TIE_VDEEP_CAP;   // block-uniform (more: flag is set)
+                for (uint32_t q = 0; q < nv && flag[0] == 0; ++q) {
+                    const uint32_t vj = vdeep[q];
+                    const uint32_t pi = vj < np ? vj : TIE_LIST_CAP - 1u - (vj - np);
+                    const uint32_t ent = plist[pi], lo = ent & 0xFFFu, hi = (ent >> 12) & 0xFFFu;
+                    const uint64_t a = (uint64_t)ssa[lo], b2 = (uint64_t)ssa[hi];
+                    const uint64_t maxlen = a < n && b2 < n ? n - (a > b2 ? a : b2) : 0;
+                    bool settled = false;
+                    for (uint64_t w0 = TIE_G1 + TIE_G2; !settled; w0 += TILE_NT) {
+                        PAR(tid) {
+                            if (tid == 0) pcnt[4] = ~0u;
+                        }
+                        TILE_SYNC();
+                        PAR(tid) {
+                            const uint64_t l = (uint64_t)KCH_ * (1u + w0 + tid);
+                            TL(twa, tid, 0) = 0;
+                            TL(twb, tid, 0) = 0;
+                            bool hit = l >= maxlen;
+                            if (!hit) {
+                                const uint64_t wa = window64<BITS>(P, a + l), wb = window64<BITS>(P, b2 + l);
+                                TL(twa, tid, 0) = wa;
+                                TL(twb, tid, 0) = wb;
+                                hit = wa != wb;
+                            }
+                            if (hit) ATOMIC_MIN_U32(&pcnt[4], tid);
+                        }
+                        TILE_SYNC();
+                        const uint32_t first = pcnt[4];                                        // block-uniform
+                        if (first != ~0u) {
+                            PAR(tid) {
+                                if (tid == first) {
+                                    const uint64_t l = (uint64_t)KCH_ * (1u + w0 + tid);
+                                    const uint64_t wa = TL(twa, tid, 0), wb = TL(twb, tid, 0);
+                                    uint64_t d = maxlen;
+                                    bool lo_first = a > b2;
+                                    if (l < maxlen) {
+                                        d = l + (uint32_t)caps_clz64(wa ^ wb) / BITS;
+                                        d = d < maxlen ? d : maxlen;
+                                        lo_first = wa < wb;
+                                    }
+                                    if (d >= (vj < np ? (1ull << 32) : (1ull << 24))) flag[0] = 1;       // (an lcp the notes cannot hold)
+                                    else if (vj >= np) plist[pi] = (lo_first ? 0x81000000u : 0x80000000u) | (uint32_t)d;
+                                    else {                                // a pair: both members point at vlcp[q]
+                                        vlcp[q] = (uint32_t)d;
+                                        tinfo[hi] = (uint16_t)(lo_first ? 0xFFFFu : 0u);
+                                        tinfo[lo] = (uint16_t)(lo_first ? 0u : 0xFFFFu);
+                                    }
+                                }
+                            }
+                            settled = true;
+                        }
+                        TILE_SYNC();
+                    }
                 }
             }
         }
@@ -1352,11 +1437,21 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                     uint32_t more = 0, best = 0;
                     if (ties == 1u) {
                         const uint32_t v = tinfo[slot];
-                        if (v & 0x8000u) { more = 1; best = v & 0x7FFFu; }
+                        if (v & 0x8000u) {
+                            more = 1;
+                            best = v & 0x7FFFu;
+                            if (VDEEP && best == 0x7FFFu) {                // settled in the third stage: its pair's lcp is in vlcp
+                                const uint32_t nq = pcnt[3] < TIE_VDEEP_CAP ? pcnt[3] : TIE_VDEEP_CAP;
+                                for (uint32_t q = 0; q < nq; ++q) {
+                                    const uint32_t vj = vdeep[q];
+                                    if (vj < pcnt[0]) { const uint32_t en = plist[vj]; if ((en & 0xFFFu) == slot || ((en >> 12) & 0xFFFu) == slot) best = vlcp[q]; }
+                                }
+                            }
+                        }
                     } else if (ties >= 2u && ties <= TIE_LIST_MAX) {
                         for (uint32_t q = 0; q < ties; ++q) {
                             const uint32_t r = plist[TIE_LIST_CAP - 1u - (own + q)];       // (anything when the tile has failed)
-                            if (r & 0x01000000u) { ++more; best = (r & 0xFFFFu) > best ? (r & 0xFFFFu) : best; }
+                            if (r & 0x01000000u) { ++more; best = (r & 0xFFFFFFu) > best ? (r & 0xFFFFFFu) : best; }
                         }
                     } else if (ties > TIE_LIST_MAX) {
                         // (fetching the first windows of four such suffixes at a time was measured: the extra registers cost
@@ -1378,7 +1473,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
             }
         }
         TILE_SYNC();
-        fast = flag[0] == 0;
+        fast = flag[0] == 0 && flag[1] == 0;
         PHASE_MARK(13);                                        // rank inside the bin
         if (fast) {
             PAR(tid) {
@@ -1389,7 +1484,14 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                         const uint32_t d = TL(rd, tid, k);
                         skey[d] = TL(rk, tid, k);
                         ssa[d] = TL(rs, tid, k);
-                        tinfo[d] = (uint16_t)TL(rl, tid, k);   // = slcp: the lcp with the predecessor, where a tie settled it
+                        // = slcp: the lcp with the predecessor, where a tie settled it (the few beyond 15 bits: in vslot / vlcp)
+                        uint32_t lc = TL(rl, tid, k);
+                        if (VDEEP && lc >= 0x7FFFu) {
+                            const uint32_t q = FETCH_ADD_U32(&pcnt[5], 1u);
+                            if (q < TIE_VDEEP_CAP) { vslot[q] = (uint16_t)d; vlcp[q] = lc; }
+                            lc = q < TIE_VDEEP_CAP ? 0x7FFFu : 0u;         // (no room: the emit phase derives it from the text)
+                        }
+                        tinfo[d] = (uint16_t)lc;
                     }
                 }
             }
@@ -1401,9 +1503,10 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
     caps_emul_count_tile3(fast);
 #endif
     if (!fast) {
-        PAR(tid) { if (tid == 0) redo2[1 + FETCH_ADD_U32(&redo2[0], 1u)] = b; }
+        uint32_t* q_ = !VDEEP && redo_deep && flag[0] == 0 ? redo_deep : redo2;        // block-uniform
+        PAR(tid) { if (tid == 0) q_[1 + FETCH_ADD_U32(&q_[0], 1u)] = b; }
     } else {
-        TILE_SORT_EMIT_((uint32_t)tinfo[e])
+        TILE_SORT_EMIT_((!VDEEP || tinfo[e] != 0x7FFFu ? (uint32_t)tinfo[e] : eq_big_lcp(vslot, vlcp, pcnt[5], e)))
     }
     TILE_SYNC();                                                    // the staging arrays are free for the next tile
     PHASE_MARK(15);                                            // emit (+ LCPs) and the barrier behind it

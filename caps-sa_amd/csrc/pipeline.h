@@ -710,14 +710,17 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
     r.fin = fin;
     // queues of unfinished tiles ([0] = length) in the (idle) tile descriptors' memory: tile_sort_kernel -> redo ->
     // tile_sort_eq_kernel -> redo2 -> tile_sort_general_kernel
+    // ... -> redo2 -> tile_sort_eq_kernel<VDEEP> (the build with the third tie stage: exact long duplicates) -> redo3 -> general
     uint32_t* redo = reinterpret_cast<uint32_t*>(desc);
     uint32_t* redo2 = redo + ((size_t)n_tiles + 2);
-    static_assert(sizeof(TileDesc) >= 2 * sizeof(uint32_t) + 1, "two queues fit the descriptor array");
+    uint32_t* redo3 = redo2 + ((size_t)n_tiles + 2);
+    static_assert(sizeof(TileDesc) >= 3 * sizeof(uint32_t) + 1, "three queues fit the descriptor array");
     be.memset(redo, 0, sizeof(uint32_t));
     be.memset(redo2, 0, sizeof(uint32_t));
+    be.memset(redo3, 0, sizeof(uint32_t));
     const uint32_t ggrid = n_tiles < 4 * be.persistent_blocks() ? n_tiles : 4 * be.persistent_blocks();
     const bool eq_tiles = !std::getenv("CAPS_SA_NO_EQ_TILES");        // measurement: skip tile_sort_eq_kernel
-    if (!eq_tiles) redo2 = redo;
+    if (!eq_tiles) redo3 = redo2 = redo;
     BackendEvent t0 = be.record();
     if (o.seg_ends && segs.seg_start == s.seg_start)
         throw std::invalid_argument("segments in fixed-capacity regions must be bucketed (results are written compactly)");
@@ -729,25 +732,31 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, sd, P, n, o.text_base, lcp_mode, 0u,
                     (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, seg_map, redo, no_shift);
         if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, true>), ggrid, TILE_NT, be, sd, P, n, o.text_base, lcp_mode, 0u,
-                    (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo, redo2, 0u);
+                    (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo, redo3, 0u, redo2);
+        if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, true, true>), ggrid, TILE_NT, be, sd, P, n, o.text_base, lcp_mode, 0u,
+                    (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo2, redo3, 0u, (uint32_t*)nullptr);
         CAPS_LAUNCH_RUNS(tile_sort_general_kernel, (idx_t, BITS, true), ggrid, TILE_NT, be, sd, P, n, o.text_base, lcp_mode, 0u,
-                    (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo2, 0u);
+                    (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo3, 0u);
     } else if (r.k32) {
         // 32-bit keys in the slots; the tiles the first kernel cannot finish are re-sorted from 64-bit keys cut from the text
         CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, false, uint32_t>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
                     reinterpret_cast<const uint32_t*>(in_key), in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, redo, (const uint8_t*)o.bk->kshift);
         if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false>), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
-                    (const uint64_t*)nullptr, in_sa, cur.key, cur.sa, cur.lcp, fin, (const BucketParams*)nullptr, (const uint32_t*)redo, redo2, 1u);
+                    (const uint64_t*)nullptr, in_sa, cur.key, cur.sa, cur.lcp, fin, (const BucketParams*)nullptr, (const uint32_t*)redo, redo3, 1u, redo2);
+        if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false, true>), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
+                    (const uint64_t*)nullptr, in_sa, cur.key, cur.sa, cur.lcp, fin, (const BucketParams*)nullptr, (const uint32_t*)redo2, redo3, 1u, (uint32_t*)nullptr);
         CAPS_LAUNCH_RUNS(tile_sort_general_kernel, (idx_t, BITS, false), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
-                    (const uint64_t*)nullptr, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo2, 1u);
+                    (const uint64_t*)nullptr, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo3, 1u);
     } else {
         if (o.skewed_keys && eq_tiles) CAPS_LAUNCH(queue_all_tiles_kernel, (n_tiles + 255) / 256, 256, be, sd, redo);
         else CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
                     in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, redo, no_shift);
         if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false>), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
-                    in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo, redo2, 0u);
+                    in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo, redo3, 0u, redo2);
+        if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false, true>), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
+                    in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo2, redo3, 0u, (uint32_t*)nullptr);
         CAPS_LAUNCH_RUNS(tile_sort_general_kernel, (idx_t, BITS, false), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
-                    in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo2, 0u);
+                    in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo3, 0u);
     }
     BackendEvent t1 = be.record();
     mark("tile sort");

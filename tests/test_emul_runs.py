@@ -127,3 +127,23 @@ def test_letter_run_buckets_order_n_blocks_without_comparing(which, monkeypatch)
     st8 = _chk(E, B, 0, long_runs=True)
     assert st8["bits_per_char"] == 8
     assert st8["run_buckets"] >= 1 or st8["path_direct"] == 0, st8
+
+
+@pytest.mark.parametrize("which", ["big", "small"])
+def test_exact_long_duplicates_are_settled_by_the_third_tie_stage(which):
+    """tile_sort_eq_kernel<VDEEP>: a pair of suffixes that agree on more than the first two tie rounds see (2,300 bases: an exact
+    duplicate of several kb, a copy that runs into the end of the text, a triple) is settled by the whole workgroup, any depth,
+    instead of sending its tile to the comparison sort."""
+    E = emul() if which == "big" else emul_small()
+    scale = 10 if which == "big" else 1
+    rs = np.random.RandomState(4)
+    n = 40000 * scale
+    T = rs.choice(DNA, size=n)
+    T[30000 * scale:35000 * scale] = T[2000 * scale:7000 * scale]                 # an exact duplicate: lcps up to 5000 * scale
+    T[20000 * scale:20000 * scale + 3000] = T[10000 * scale:10000 * scale + 3000]
+    T[20000 * scale + 1500] = ord("A") if T[20000 * scale + 1500] != ord("A") else ord("C")
+    T[33000 * scale:33000 * scale + 2500] = T[5000:7500]                          # three copies of one piece
+    T[36500 * scale:36500 * scale + 2500] = T[5000:7500]
+    for TT in (T, np.concatenate([T, T[:7000]])):                                 # ... and a duplicate that ends with the text
+        for p in (0, 16):
+            _chk(E, TT, p)
