@@ -56,6 +56,7 @@ static inline uint32_t caps_emul_phase_start() { static uint32_t c = 12345u; c =
 #define UNROLL
 #define ATOMIC_OR_U32(ptr, v) (*(ptr) |= (v))
 #define ATOMIC_MIN_U32(ptr, v) (*(ptr) = std::min<uint32_t>(*(ptr), (v)))
+#define ATOMIC_MAX_U32(ptr, v) (*(ptr) = std::max<uint32_t>(*(ptr), (v)))
 #define ATOMIC_ADD_U64(ptr, v) (*(ptr) += (v))
 #define ATOMIC_ADD_LDS_U64(ptr, v) (*(ptr) += (v))
 #define ATOMIC_MAX_U64(ptr, v) (*(ptr) = std::max<uint64_t>(*(ptr), (v)))
@@ -104,6 +105,7 @@ static __device__ __forceinline__ void caps_lds_barrier()
 #define UNROLL _Pragma("unroll")
 #define ATOMIC_OR_U32(ptr, v) atomicOr((ptr), (v))
 #define ATOMIC_MIN_U32(ptr, v) atomicMin((ptr), (v))
+#define ATOMIC_MAX_U32(ptr, v) atomicMax((ptr), (v))
 #define ATOMIC_ADD_U64(ptr, v) atomicAdd((unsigned long long*)(ptr), (unsigned long long)(v))
 #define ATOMIC_ADD_LDS_U64(ptr, v) atomicAdd((unsigned long long*)(ptr), (unsigned long long)(v))
 #define ATOMIC_MAX_U64(ptr, v) atomicMax((unsigned long long*)(ptr), (unsigned long long)(v))

@@ -854,6 +854,7 @@ __device__ unsigned long long caps_phase_clock[32];
 // sorted tile in LDS -> HBM (+ LCPs from adjacent keys, + boundary records)
 #define TILE_SORT_EMIT TILE_SORT_EMIT_(0u)
 /* OV: an lcp already known for slot e (0 = none: from the keys, the text on equal keys) */
+#define TILE_EMIT_LCP_(ka, a, kb, b) tile_pair_lcp<BITS, TILE_RUNS>(P, n, ka, a, kb, b, TILE_KEY_SHIFT)
 #define TILE_SORT_EMIT_(OV)                                                                                     \
     PAR(tid) {                                                                                                  \
         UNROLL                                                                                                  \
@@ -865,7 +866,7 @@ __device__ unsigned long long caps_phase_clock[32];
                 uint64_t l = 0;                                                                                 \
                 if (with_lcp && e) {                                                                            \
                     const uint32_t ov_ = (OV);                                                                  \
-                    l = ov_ ? ov_ : tile_pair_lcp<BITS, TILE_RUNS>(P, n, skey[e - 1], (uint64_t)ssa[e - 1], skey[e], (uint64_t)sa, TILE_KEY_SHIFT); \
+                    l = ov_ ? ov_ : TILE_EMIT_LCP_(skey[e - 1], (uint64_t)ssa[e - 1], skey[e], (uint64_t)sa);      \
                 }                                                                                               \
                 if (direct) {                                                                                   \
                     fin.sa[start + e] = sa;                                                                     \
@@ -1042,6 +1043,8 @@ constexpr uint32_t TIE_LIST_CAP = TILE_E / 8;     // list entries per tile (pair
 constexpr uint32_t TIE_LIST_MAX = CAPS_TIE_LIST_MAX;   // an element lists up to this many equal keys (more: it scans them itself)
 constexpr uint32_t TIE_DEEP_CAP = 64;             // entries that may go to the second round
 constexpr uint32_t TIE_VDEEP_CAP = 32;            //   ... and on to the third (any depth: long exact duplicates)
+constexpr uint32_t TIE_BIG_CAP = 1024;            // elements with more than TIE_LIST_MAX equal keys a tile may hold
+constexpr uint32_t TIE_BIG_LANES = 64;            //   lanes that share the equal keys of one of them (fewer when there are many)
 constexpr uint32_t EQ_FRAC_BITS = 13;             // position inside a bin; a position is bin * 2^13 + fraction < 2^24 at 2048 bins
 static_assert((uint64_t)TILE_BINS_ << EQ_FRAC_BITS <= (1u << 24), "positions fit 24 bits");
 
@@ -1068,9 +1071,24 @@ DEV_INLINE uint32_t eq_big_lcp(const uint16_t* vslot, const uint32_t* vlcp, uint
     return l;
 }
 
+// lcp of two neighbours of the sorted tile that no tie has settled.  TEXT = false (the plain build): their keys differ --
+// every pair of equal keys has its lcp from the tie phases, and those are never 0 -- so the keys tell; the comparator through
+// the text, unrolled four times in the emit phase, cost that phase registers (scratch) for a path no tile takes.
+template <int BITS, bool TEXT>
+DEV_INLINE uint64_t eq_emit_lcp(const uint32_t* __restrict__ P, uint64_t n, uint64_t ka, uint64_t a, uint64_t kb, uint64_t b)
+{
+    if (TEXT) return pair_lcp<BITS, false>(P, n, ka, a, kb, b);
+    const uint64_t maxlen = n - (a > b ? a : b);
+    const uint64_t x = ka ^ kb;
+    const uint64_t l = x ? (uint32_t)caps_clz64(x) / BITS : TextTraits<BITS>::KCH;
+    return l < maxlen ? l : maxlen;
+}
+
 #ifndef CAPS_EQ_WAVES
 #define CAPS_EQ_WAVES TILE_WAVES_PER_SIMD
 #endif
+#undef TILE_EMIT_LCP_
+#define TILE_EMIT_LCP_(ka, a, kb, b) eq_emit_lcp<BITS, VDEEP>(P, n, ka, a, kb, b)
 #ifndef CAPS_EQ_FULL_SYNC          /* measurement: -DCAPS_EQ_FULL_SYNC keeps __syncthreads() in this kernel */
 #undef TILE_SYNC
 #define TILE_SYNC() SYNC_LDS()
@@ -1078,7 +1096,11 @@ DEV_INLINE uint32_t eq_big_lcp(const uint16_t* vslot, const uint32_t* vlcp, uint
 // VDEEP: the build with the third tie stage (any depth).  A build of its own, behind the plain one in the queue chain: the
 // plain kernel runs at the register budget, and the stage's code in it cost every tile of a genome-like text 14 % (76 -> 87 ms
 // at 3e9) for the sake of the few that hold an exact long duplicate.
-template <typename idx_t, int BITS, bool FROM_TEXT, bool VDEEP = false>
+// PERSIST = false: one queue entry per workgroup (the grid covers the queue: the caller knows its length, or a bound).  The
+// loop over the queue lets the compiler hoist per-thread addresses and constants out of it, and what it hoists it must hold
+// across all ~20 phases of a tile: at the 64-register budget that put 41 registers in scratch memory, reloaded 58 times per
+// tile (and 13 GB of scratch stores reached HBM at 3e9); without the loop: 11, reloaded 5 times, 19 % fewer instructions.
+template <typename idx_t, int BITS, bool FROM_TEXT, bool VDEEP = false, bool PERSIST = true>
 GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
                                                   uint64_t text_base, uint32_t lcp_mode, uint32_t slot_cap, const uint64_t* in_key,
                                                   const idx_t* in_sa, uint64_t* out_key, idx_t* out_sa, idx_t* out_lcp,
@@ -1093,6 +1115,8 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
     constexpr bool TILE_RUNS = false;
     const bool TILE_KEYS_FROM_TEXT = keys_from_text != 0;
     const uint32_t TILE_KEY_SHIFT = 0;
+    (void)TILE_RUNS;
+    (void)TILE_KEY_SHIFT;
     SHARED_ARRAY(uint64_t, skey, TILE_E);
     SHARED_ARRAY(idx_t, ssa, TILE_E);
     SHARED_ARRAY(uint32_t, hist, TILE_BINS + 1);
@@ -1111,30 +1135,31 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                                                       //   an own entry once settled: 0x80 | the other sorts first, << 24 | lcp
     SHARED_ARRAY(uint16_t, deep, TIE_DEEP_CAP);       // entries (virtual index) still equal after the first round
     SHARED_ARRAY(uint16_t, vdeep, TIE_VDEEP_CAP);     //   ... and after the second: settled one by one, the whole workgroup on each
-    SHARED_ARRAY(uint32_t, pcnt, 6);                  // pairs listed, own entries listed, entries on `deep`, on `vdeep`, [4] first hit, [5] big lcps
+    SHARED_ARRAY(uint32_t, pcnt, 8);                  // pairs listed, own entries listed, entries on `deep`, on `vdeep`, [4] first hit, [5] big lcps,
+                                                      //   [6] elements on `big`
+    SHARED_ARRAY(uint32_t, big, TIE_BIG_CAP);         // elements with more than TIE_LIST_MAX equal keys: slot | first of bin << 12 | bin size - 1 << 24
+    SHARED_ARRAY(uint32_t, bmore, TIE_BIG_CAP);       //   how many of its equal keys sort before it,
+    SHARED_ARRAY(uint32_t, bbest, TIE_BIG_CAP);       //   the largest lcp with one of those
     SHARED_ARRAY(uint32_t, vlcp, TIE_VDEEP_CAP);      // third stage: the lcp of pair q (too large for the 15 bits of its members' notes);
                                                       //   after the final placement: the lcps >= 0x7FFF, with ...
     SHARED_ARRAY(uint16_t, vslot, TIE_VDEEP_CAP);     //   ... the slots they belong to
     static_assert((TILE_BINS + 1) * sizeof(uint32_t) >= TILE_E * sizeof(uint16_t) && TILE_E <= (1u << 12) && EQ_BIN_LIMIT <= 128 &&
                   TILE_NT % TIE_G1 == 0 && TILE_NT % TIE_G2 == 0 && TIE_G1 + TIE_G2 < 0x80u && TIE_LIST_CAP <= (1u << 12) &&
+                  TIE_BIG_CAP <= (1u << 12) && (TILE_NT & (TILE_NT - 1u)) == 0 &&
                   TextTraits<BITS>::KCH * (1u + TIE_G1 + TIE_G2) < 0x7FFFu,
                   "tinfo fits hist; slots and entries fit 12 bits; ranks inside a bin fit 8 bits; lcps of the first two rounds fit 15 bits");
     // per slot: "the other member of my pair sorts before me" << 15 | their lcp (0x7FFF: see vlcp); after the final placement: the
     // lcp with the predecessor where a tie settled it (0x7FFF: see vslot / vlcp)
     uint16_t* tinfo = reinterpret_cast<uint16_t*>(hist);
     const uint32_t n_redo = redo[0];
-    // the queue entry and the record of the NEXT tile are fetched while this one is sorted (two dependent loads off the
-    // head of every tile: the load phase was 13 % of this kernel's time, most of it these latencies)
-    uint32_t b_next = K_BLOCK_IDX < n_redo ? redo[1 + K_BLOCK_IDX] : 0u;
-    TileInfo t_next = tile_info(sd, b_next);
-    for (uint32_t qi = K_BLOCK_IDX; qi < n_redo; qi += K_GRID_DIM) {
-    const uint32_t b = b_next;
-    const TileInfo t = t_next;
+    // (fetching the queue entry and the record of the NEXT tile while this one is sorted was tried: no gain, and the record's
+    // registers, held across the whole tile, went to scratch)
+    uint32_t qi = K_BLOCK_IDX;
+    if (qi >= n_redo) return;
+    do {
+    const uint32_t b = redo[1 + qi];
+    const TileInfo t = tile_info(sd, b);
     const uint32_t g = t.g;
-    if (qi + K_GRID_DIM < n_redo) {
-        b_next = redo[1 + qi + K_GRID_DIM];
-        t_next = tile_info(sd, b_next);
-    }
     const uint64_t start = t.s0 + (uint64_t)t.tl * TILE_E;
     const uint32_t cnt = (uint32_t)(t.s1 - start < TILE_E ? t.s1 - start : TILE_E);
     const bool with_lcp = lcp_mode != 0 && (t.s1 - t.s0) <= TILE_E;
@@ -1189,8 +1214,9 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
         PHASE_MARK(9);                                         // equalisation rounds
         PAR(tid) {
             for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0;
-            if (tid < 6) pcnt[tid] = 0;
+            if (tid < 8) pcnt[tid] = 0;
             if (tid == 0) flag[1] = 0;
+            for (uint32_t i = tid; i < TIE_BIG_CAP; i += K_BLOCK_DIM) { bmore[i] = 0; bbest[i] = 0; }
         }
         TILE_SYNC();
         PAR(tid) {
@@ -1252,7 +1278,9 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                 if (e < cnt) {
                     const uint32_t bin = TL(rb, tid, k), slot = TL(rd, tid, k);
                     const uint32_t bs = hist[bin], be = hist[bin + 1];
-                    const uint64_t key = TL(rk, tid, k);
+                    const uint64_t key = skey[slot];                       // (not TL(rk): from here to the final placement the
+                                                                           //  elements live in skey / ssa only -- 12 registers
+                                                                           //  less across the tie phases, which ran on scratch)
                     uint32_t less = 0, ties = 0, tj = 0;
                     for (uint32_t j = bs; j < be; ++j) {
                         const uint64_t kj = skey[j];
@@ -1272,6 +1300,10 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                         } else {
                             own = 0;                                       // (the tile fails below: the list is full)
                         }
+                    } else if (ties > TIE_LIST_MAX) {
+                        own = FETCH_ADD_U32(&pcnt[6], 1u);                 // here: my place on `big`
+                        if (own < TIE_BIG_CAP) big[own] = slot | (bs << 12) | ((be - bs - 1u) << 24);
+                        else { own = 0; flag[0] = 1; }                     // (more such elements than the list holds: not here)
                     }
                     TL(rb, tid, k) = bs | (be << 16);                      // the bin id is not needed any more
                     TL(rt, tid, k) = less | (own << 8) | (ties > 15u ? 15u << 28 : ties << 28);   // less <= 127, own < 2^12
@@ -1280,6 +1312,37 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
         }
         TILE_SYNC();                                                // hist is free: tinfo / slcp from here on
         PHASE_MARK(16);                                        // R1: rank by keys
+        // B: the elements with more than TIE_LIST_MAX equal keys (0.05 % of a genome-like text's suffixes, in clusters: every
+        // tenth tile holds some).  Each gets up to TIE_BIG_LANES lanes that share its bin: every lane compares it with its share
+        // of the equal keys through the text, the comparisons of an element in flight at once -- in the pick-up phase, where every such element
+        // went through its equal keys one after the other (c - 1 dependent trips to the text for each member of a cluster of
+        // c), the whole workgroup waited for the longest chain, and the comparator's code, unrolled there four times, put
+        // that phase on scratch memory.
+        {
+            const uint32_t nb = pcnt[6] < TIE_BIG_CAP ? pcnt[6] : TIE_BIG_CAP;             // block-uniform
+            uint32_t lg = 0;                                                               // lanes per element: 2^lg <= TIE_BIG_LANES,
+            while ((2u << lg) <= TIE_BIG_LANES && (uint64_t)nb * (2u << lg) <= TILE_NT) ++lg;   //   as many as one round has room for
+            for (uint32_t base = 0; base < nb; base += TILE_NT >> lg) {
+                PAR(tid) {
+                    const uint32_t i = base + (tid >> lg);
+                    if (i < nb) {
+                        const uint32_t ent = big[i], slot = ent & 0xFFFu, bs = (ent >> 12) & 0xFFFu, be = bs + (ent >> 24) + 1u;
+                        const uint64_t key = skey[slot];
+                        const uint64_t sa = (uint64_t)ssa[slot];
+                        uint32_t more = 0, best = 0;
+                        for (uint32_t j = bs + (tid & ((1u << lg) - 1u)); j < be; j += 1u << lg) {
+                            if (skey[j] == key && j != slot) {
+                                uint32_t l;
+                                const uint32_t c = tie_order_lcp_bounded<BITS>(P, n, (uint64_t)ssa[j], sa, l);   // 1: j sorts before me
+                                if (c == 2u) flag[0] = 1;
+                                if (c == 1u) { ++more; best = l > best ? l : best; }
+                            }
+                        }
+                        if (more) { FETCH_ADD_U32(&bmore[i], more); ATOMIC_MAX_U32(&bbest[i], best); }
+                    }
+                }
+            }
+        }
         {
             const uint32_t np = pcnt[0], nm = pcnt[1];                                     // block-uniform
             constexpr uint32_t KCH_ = TextTraits<BITS>::KCH;
@@ -1433,7 +1496,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                 if (e < cnt) {
                     const uint32_t info = TL(rt, tid, k);
                     const uint32_t ties = info >> 28, slot = TL(rd, tid, k), own = (info >> 8) & 0xFFFu;
-                    const uint32_t bs = TL(rb, tid, k) & 0xFFFFu, be = TL(rb, tid, k) >> 16;
+                    const uint32_t bs = TL(rb, tid, k) & 0xFFFFu;
                     uint32_t more = 0, best = 0;
                     if (ties == 1u) {
                         const uint32_t v = tinfo[slot];
@@ -1454,20 +1517,12 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                             if (r & 0x01000000u) { ++more; best = (r & 0xFFFFFFu) > best ? (r & 0xFFFFFFu) : best; }
                         }
                     } else if (ties > TIE_LIST_MAX) {
-                        // (fetching the first windows of four such suffixes at a time was measured: the extra registers cost
-                        // more than the latencies saved, genome-like 3e9 151 -> 162 ms)
-                        const uint64_t key = TL(rk, tid, k);
-                        const uint64_t sa = (uint64_t)TL(rs, tid, k);
-                        for (uint32_t j = bs; j < be; ++j) {
-                            if (skey[j] == key && j != slot) {
-                                uint32_t l;
-                                const uint32_t c = tie_order_lcp_bounded<BITS>(P, n, (uint64_t)ssa[j], sa, l);   // 1: j sorts before me
-                                if (c == 2u) flag[0] = 1;
-                                if (c == 1u) { ++more; best = l > best ? l : best; }
-                            }
-                        }
+                        more = bmore[own];                                 // (phase B; anything when the tile has failed)
+                        best = bbest[own];
                     }
                     TL(rl, tid, k) = best;
+                    TL(rk, tid, k) = skey[slot];                           // picked up for the final placement (behind the barrier)
+                    TL(rs, tid, k) = ssa[slot];
                     TL(rd, tid, k) = bs + (((info & 0xFFu) + more) & 0xFFu);
                 }
             }
@@ -1510,11 +1565,14 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
     }
     TILE_SYNC();                                                    // the staging arrays are free for the next tile
     PHASE_MARK(15);                                            // emit (+ LCPs) and the barrier behind it
-    }
+    qi += K_GRID_DIM;
+    } while (PERSIST && qi < n_redo);
 }
 
 #undef TILE_SYNC
 #define TILE_SYNC() SYNC()
+#undef TILE_EMIT_LCP_
+#define TILE_EMIT_LCP_(ka, a, kb, b) tile_pair_lcp<BITS, TILE_RUNS>(P, n, ka, a, kb, b, TILE_KEY_SHIFT)
 
 // ---- tile_sort_general_kernel: the tiles tile_sort_kernel could not finish ------------------
 // (keys far from uniform inside the tile, or equal keys: repeats), taken from its queue
@@ -3102,6 +3160,7 @@ GLOBAL_FN LAUNCH_BOUNDS(256) group_keys_kernel(KCTX const uint64_t* __restrict__
             }
         }
         if (j + 1 < K1) gkey[j] = pkey[(uint64_t)(j + 1) * PG - 1];
+        if (j + 1 == K1) gkey[j] = ~0ull;                               // (as a knot table of K1 buckets: the last one is open above)
     }
 }
 

@@ -748,10 +748,16 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         CAPS_LAUNCH_RUNS(tile_sort_general_kernel, (idx_t, BITS, false), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
                     (const uint64_t*)nullptr, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo3, 1u);
     } else {
-        if (o.skewed_keys && eq_tiles) CAPS_LAUNCH(queue_all_tiles_kernel, (n_tiles + 255) / 256, 256, be, sd, redo);
+        // every tile queued (skewed keys): one workgroup per tile -- the build of tile_sort_eq_kernel without the loop over
+        // the queue (kernels.h PERSIST); otherwise the queue is short (often empty) and a fixed grid walks it
+        const bool all_queued = o.skewed_keys && eq_tiles;
+        const bool per_tile = all_queued && (uint64_t)n_tiles * TILE_NT <= 0xFFFFFFFFull && !std::getenv("CAPS_SA_EQ_PERSISTENT");
+        if (all_queued) CAPS_LAUNCH(queue_all_tiles_kernel, (n_tiles + 255) / 256, 256, be, sd, redo);
         else CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
                     in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, redo, no_shift);
-        if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false>), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
+        if (per_tile) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false, false, false>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
+                    in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo, redo3, 0u, redo2);
+        else if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false>), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
                     in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo, redo3, 0u, redo2);
         if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false, true>), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
                     in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo2, redo3, 0u, (uint32_t*)nullptr);
@@ -1224,6 +1230,13 @@ private:
             SortOpts oq;
             oq.bk = &pl_.bk;
             oq.unify = true;
+            // split by the group keys of the FIRST sample (K1 buckets, then tile sort + merge passes inside them).  One segment
+            // of 47 M skewed keys under a linear map has more buckets than an LDS histogram holds: count pass and scatter then
+            // do one global atomic per sample, most of them on a few hot buckets -- 3.3 + 3.7 ms of the 10 ms this sort took
+            // at 3e9 (the whole build: 144 ms)
+            oq.knots = pl_.gkey;
+            oq.knots_per_parent = K1;
+            oq.skewed_keys = probe[2] != 0;
             SortResult<idx_t> rq = seg_sort<BITS>(sseg, tiles_of(m2), m2, pl_.A, pl_.B, m2, oq, false);
             ElemBuf<idx_t> smp2 = rq.uniform();
             CAPS_LAUNCH(knots_kernel, (uint32_t)((NB + 255) / 256), 256, be_, (const uint64_t*)smp2.key, m2, NB, KPG, K1, pl_.knots, pl_.gkey);
