@@ -87,6 +87,14 @@ static inline uint32_t caps_bswap32(uint32_t x) { return __builtin_bswap32(x); }
 #define K_GRID_DIM (gridDim.x)
 #define K_BLOCK_DIM (blockDim.x)
 #define PAR(tid) for (uint32_t tid = threadIdx.x, par_once_ = 1; par_once_; par_once_ = 0)
+// PAR_FRESH: the same, but the compiler is kept from knowing that this region's thread index is the one of the regions
+// before it.  What a kernel with many phases derives from the index (addresses, element numbers) is otherwise computed
+// once, held in registers across all phases (or hoisted out of a loop over tiles) and, at the 64-register budget of two
+// 1024-thread workgroups per CU, spilled to scratch memory; recomputing it per region is a few instructions.  Pays in the
+// long kernels (tile_sort_eq_kernel, tile_sort_general_kernel: kernels.h switches PAR over for them); the short ones
+// (scatters, tile_sort_kernel) lose 2-7 % to it.
+static __device__ __forceinline__ uint32_t caps_tid_fresh() { uint32_t t = threadIdx.x; asm volatile("" : "+v"(t)); return t; }
+#define PAR_FRESH(tid) for (uint32_t tid = caps_tid_fresh(), par_once_ = 1; par_once_; par_once_ = 0)
 #define SYNC() __syncthreads()
 // Barrier that orders LDS traffic only: s_waitcnt lgkmcnt(0) + s_barrier.  __syncthreads() also drains the wave's
 // outstanding global stores and returning atomics (vmcnt); where nothing that went to global memory is handed to another

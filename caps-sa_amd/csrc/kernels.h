@@ -1093,6 +1093,14 @@ DEV_INLINE uint64_t eq_emit_lcp(const uint32_t* __restrict__ P, uint64_t n, uint
 #undef TILE_SYNC
 #define TILE_SYNC() SYNC_LDS()
 #endif
+// this kernel and tile_sort_general_kernel: every PAR region takes its thread index afresh (kernel_lang.h PAR_FRESH; measured
+// at 3e9 genome-like: 57.3 -> 54.1 ms here, no register left in scratch)
+#if !defined(CAPS_EMUL) && !defined(CAPS_PAR_PLAIN_ONLY)
+#pragma push_macro("PAR")
+#undef PAR
+#define PAR(tid) PAR_FRESH(tid)
+#define CAPS_PAR_SWITCHED
+#endif
 // VDEEP: the build with the third tie stage (any depth).  A build of its own, behind the plain one in the queue chain: the
 // plain kernel runs at the register budget, and the stage's code in it cost every tile of a genome-like text 14 % (76 -> 87 ms
 // at 3e9) for the sake of the few that hold an exact long duplicate.
@@ -1120,6 +1128,10 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
     SHARED_ARRAY(uint64_t, skey, TILE_E);
     SHARED_ARRAY(idx_t, ssa, TILE_E);
     SHARED_ARRAY(uint32_t, hist, TILE_BINS + 1);
+    // 32-bit indices: 80 KB of LDS with these two (two workgroups per CU); 64-bit indices have no room for sbin, and a shorter list
+    constexpr bool SLOT_ORDER = sizeof(idx_t) == 4;
+    constexpr uint32_t BIG_CAP = sizeof(idx_t) == 4 ? TIE_BIG_CAP : TIE_BIG_CAP / 4;
+    SHARED_ARRAY(uint16_t, sbin, SLOT_ORDER ? TILE_E : 1);   // the bin of the element in slot e (after the placement by bin)
     SHARED_ARRAY(uint64_t, kmm, 2);
     SHARED_ARRAY(uint32_t, flag, 2);         // [0] the tile is the comparison sort's; [1] it only needs the third tie stage
     TL_DECL(uint64_t, rk, TILE_EPT);
@@ -1137,9 +1149,9 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
     SHARED_ARRAY(uint16_t, vdeep, TIE_VDEEP_CAP);     //   ... and after the second: settled one by one, the whole workgroup on each
     SHARED_ARRAY(uint32_t, pcnt, 8);                  // pairs listed, own entries listed, entries on `deep`, on `vdeep`, [4] first hit, [5] big lcps,
                                                       //   [6] elements on `big`
-    SHARED_ARRAY(uint32_t, big, TIE_BIG_CAP);         // elements with more than TIE_LIST_MAX equal keys: slot | first of bin << 12 | bin size - 1 << 24
-    SHARED_ARRAY(uint32_t, bmore, TIE_BIG_CAP);       //   how many of its equal keys sort before it,
-    SHARED_ARRAY(uint32_t, bbest, TIE_BIG_CAP);       //   the largest lcp with one of those
+    SHARED_ARRAY(uint32_t, big, BIG_CAP);             // elements with more than TIE_LIST_MAX equal keys: slot | first of bin << 12 | bin size - 1 << 24
+    SHARED_ARRAY(uint32_t, bmore, BIG_CAP);           //   how many of its equal keys sort before it,
+    SHARED_ARRAY(uint32_t, bbest, BIG_CAP);           //   the largest lcp with one of those
     SHARED_ARRAY(uint32_t, vlcp, TIE_VDEEP_CAP);      // third stage: the lcp of pair q (too large for the 15 bits of its members' notes);
                                                       //   after the final placement: the lcps >= 0x7FFF, with ...
     SHARED_ARRAY(uint16_t, vslot, TIE_VDEEP_CAP);     //   ... the slots they belong to
@@ -1216,7 +1228,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
             for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0;
             if (tid < 8) pcnt[tid] = 0;
             if (tid == 0) flag[1] = 0;
-            for (uint32_t i = tid; i < TIE_BIG_CAP; i += K_BLOCK_DIM) { bmore[i] = 0; bbest[i] = 0; }
+            for (uint32_t i = tid; i < BIG_CAP; i += K_BLOCK_DIM) { bmore[i] = 0; bbest[i] = 0; }
         }
         TILE_SYNC();
         PAR(tid) {
@@ -1247,7 +1259,8 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                     const uint32_t slot = hist[TL(rb, tid, k)] + TL(rd, tid, k);
                     skey[slot] = TL(rk, tid, k);
                     ssa[slot] = TL(rs, tid, k);
-                    TL(rd, tid, k) = slot;
+                    if (SLOT_ORDER) sbin[slot] = (uint16_t)TL(rb, tid, k);
+                    else TL(rd, tid, k) = slot;
                 }
             }
         }
@@ -1276,11 +1289,15 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
             for (uint32_t k = 0; k < TILE_EPT; ++k) {
                 const uint32_t e = tid + k * TILE_NT;
                 if (e < cnt) {
-                    const uint32_t bin = TL(rb, tid, k), slot = TL(rd, tid, k);
+                    // from here on a thread works on the elements in SLOTS tid + k * TILE_NT (the slot's bin: sbin), not on the
+                    // ones it loaded: the lanes of a wave then hold neighbouring slots -- mostly one bin, so they scan the same
+                    // keys (one LDS read serves them all) for the same number of steps, where the lanes of a wave used to sit
+                    // in 64 bins of 64 sizes.  The elements live in skey / ssa only until the final placement.
+                    // (64-bit indices: no room in LDS for sbin; every thread stays with the elements it loaded)
+                    const uint32_t slot = SLOT_ORDER ? e : TL(rd, tid, k), bin = SLOT_ORDER ? (uint32_t)sbin[slot] : TL(rb, tid, k);
+                    TL(rd, tid, k) = slot;
                     const uint32_t bs = hist[bin], be = hist[bin + 1];
-                    const uint64_t key = skey[slot];                       // (not TL(rk): from here to the final placement the
-                                                                           //  elements live in skey / ssa only -- 12 registers
-                                                                           //  less across the tie phases, which ran on scratch)
+                    const uint64_t key = skey[slot];
                     uint32_t less = 0, ties = 0, tj = 0;
                     for (uint32_t j = bs; j < be; ++j) {
                         const uint64_t kj = skey[j];
@@ -1302,7 +1319,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                         }
                     } else if (ties > TIE_LIST_MAX) {
                         own = FETCH_ADD_U32(&pcnt[6], 1u);                 // here: my place on `big`
-                        if (own < TIE_BIG_CAP) big[own] = slot | (bs << 12) | ((be - bs - 1u) << 24);
+                        if (own < BIG_CAP) big[own] = slot | (bs << 12) | ((be - bs - 1u) << 24);
                         else { own = 0; flag[0] = 1; }                     // (more such elements than the list holds: not here)
                     }
                     TL(rb, tid, k) = bs | (be << 16);                      // the bin id is not needed any more
@@ -1319,7 +1336,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
         // c), the whole workgroup waited for the longest chain, and the comparator's code, unrolled there four times, put
         // that phase on scratch memory.
         {
-            const uint32_t nb = pcnt[6] < TIE_BIG_CAP ? pcnt[6] : TIE_BIG_CAP;             // block-uniform
+            const uint32_t nb = pcnt[6] < BIG_CAP ? pcnt[6] : BIG_CAP;                     // block-uniform
             uint32_t lg = 0;                                                               // lanes per element: 2^lg <= TIE_BIG_LANES,
             while ((2u << lg) <= TIE_BIG_LANES && (uint64_t)nb * (2u << lg) <= TILE_NT) ++lg;   //   as many as one round has room for
             for (uint32_t base = 0; base < nb; base += TILE_NT >> lg) {
@@ -1343,6 +1360,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                 }
             }
         }
+        PHASE_MARK(18);                                        // B: elements with many equal keys
         {
             const uint32_t np = pcnt[0], nm = pcnt[1];                                     // block-uniform
             constexpr uint32_t KCH_ = TextTraits<BITS>::KCH;
@@ -1805,6 +1823,10 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_general_kernel(
     SYNC();                                        // before the next queued tile re-uses the LDS
     }
 }
+#ifdef CAPS_PAR_SWITCHED
+#pragma pop_macro("PAR")
+#undef CAPS_PAR_SWITCHED
+#endif
 
 // ----------------------------------------------------------------------------------
 // a3: LCP-merge of run pairs (reference: merge, src/Suffix_Array.cpp:48-109).

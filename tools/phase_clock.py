@@ -15,7 +15,7 @@ import caps_sa_amd  # noqa: E402
 from bench import WORKLOADS, make_text  # noqa: E402
 
 NAMES = {0: "ts.load", 1: "ts.hist", 2: "ts.scan", 3: "ts.place", 4: "ts.rank", 5: "ts.final", 6: "ts.emit",
-         8: "eq.load", 9: "eq.rounds", 10: "eq.hist", 11: "eq.scan", 12: "eq.place", 13: "eq.rank", 14: "eq.final", 15: "eq.emit", 16: "eq.rank_keys", 17: "eq.rank_ties"}
+         8: "eq.load", 9: "eq.rounds", 10: "eq.hist", 11: "eq.scan", 12: "eq.place", 13: "eq.rank", 14: "eq.final", 15: "eq.emit", 16: "eq.rank_keys", 17: "eq.rank_ties", 18: "eq.big_ties"}
 
 L = caps_sa_amd.lib()
 raw = ctypes.CDLL(caps_sa_amd.LIB_PATH)
@@ -34,7 +34,7 @@ for wl in sys.argv[1:] or ["c3"]:
     assert raw.caps_sa_hip_phase_clock(clk) == 0
     v = list(clk)
     out = {"workload": wl, "ms_total": round(st["ms_total"], 1), "tile_sort_ms": round(st["tile_sort_ms"], 1)}
-    for grp, lo, hi in (("ts", 0, 8), ("eq", 8, 18)):
+    for grp, lo, hi in (("ts", 0, 8), ("eq", 8, 19)):
         tot = sum(v[lo:hi])
         if tot:
             out[grp] = {NAMES[i]: round(v[i] / tot, 3) for i in range(lo, hi) if i in NAMES}
