@@ -1609,7 +1609,8 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
 // Markov-skewed DNA it rescued < 20 % of the tiles and cost more than it saved.)
 constexpr uint32_t TILE_SAMPLE_LIMIT = 64;
 
-template <typename idx_t, int BITS, bool FROM_TEXT, bool RUNS>
+// PERSIST = false: one queue entry per workgroup, as in tile_sort_eq_kernel (the caller knows the queue's length)
+template <typename idx_t, int BITS, bool FROM_TEXT, bool RUNS, bool PERSIST = true>
 GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_general_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
                                                           uint64_t text_base, uint32_t lcp_mode, uint32_t slot_cap, const uint64_t* in_key,
                                                           const idx_t* in_sa, uint64_t* out_key, idx_t* out_sa, idx_t* out_lcp,
@@ -1631,7 +1632,9 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_general_kernel(
     TL_DECL(uint32_t, sd1, 1);
     constexpr bool TILE_RUNS = RUNS;
     const uint32_t n_redo = redo[0];
-    for (uint32_t qi = K_BLOCK_IDX; qi < n_redo; qi += K_GRID_DIM) {
+    uint32_t qi = K_BLOCK_IDX;
+    if (qi >= n_redo) return;
+    do {
     const uint32_t b = redo[1 + qi];
     const uint32_t g = sd.tile_rec[b].g;
     const TileInfo t = tile_info(sd, b);
@@ -1821,7 +1824,8 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_general_kernel(
     }
     TILE_SORT_EMIT
     SYNC();                                        // before the next queued tile re-uses the LDS
-    }
+    qi += K_GRID_DIM;
+    } while (PERSIST && qi < n_redo);
 }
 #ifdef CAPS_PAR_SWITCHED
 #pragma pop_macro("PAR")

@@ -755,14 +755,33 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         if (all_queued) CAPS_LAUNCH(queue_all_tiles_kernel, (n_tiles + 255) / 256, 256, be, sd, redo);
         else CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
                     in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, redo, no_shift);
-        if (per_tile) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false, false, false>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
-                    in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo, redo3, 0u, redo2);
-        else if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false>), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
-                    in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo, redo3, 0u, redo2);
-        if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false, true>), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
-                    in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo2, redo3, 0u, (uint32_t*)nullptr);
-        CAPS_LAUNCH_RUNS(tile_sort_general_kernel, (idx_t, BITS, false), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
-                    in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo3, 0u);
+        if (per_tile) {
+            CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false, false, false>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
+                        in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo, redo3, 0u, redo2);
+            // what is left goes on with exact grids, one workgroup per entry: the lengths of the two queues come back to the
+            // host (a round trip of ~20 us; a grid over all tiles for a queue that is mostly empty costs 0.8 ms at 3e9, and the
+            // builds that walk a queue with a fixed grid hold 6 - 20 x more registers in scratch)
+            uint32_t qn[2] = {0, 0};
+            be.d2h(&qn[0], redo2, sizeof(uint32_t));
+            be.d2h(&qn[1], redo3, sizeof(uint32_t));
+            be.sync();
+            if (qn[0]) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false, true, false>), qn[0], TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
+                        in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo2, redo3, 0u, (uint32_t*)nullptr);
+            const uint32_t ng = qn[0] + qn[1];           // (the third stage may pass entries on: a bound)
+            if (ng && be.long_runs)
+                CAPS_LAUNCH((tile_sort_general_kernel<idx_t, BITS, false, true, false>), ng, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
+                            in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo3, 0u);
+            else if (ng)
+                CAPS_LAUNCH((tile_sort_general_kernel<idx_t, BITS, false, false, false>), ng, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
+                            in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo3, 0u);
+        } else {
+            if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false>), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
+                        in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo, redo3, 0u, redo2);
+            if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false, true>), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
+                        in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo2, redo3, 0u, (uint32_t*)nullptr);
+            CAPS_LAUNCH_RUNS(tile_sort_general_kernel, (idx_t, BITS, false), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
+                        in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo3, 0u);
+        }
     }
     BackendEvent t1 = be.record();
     mark("tile sort");
