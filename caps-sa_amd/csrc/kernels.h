@@ -2474,6 +2474,17 @@ template <int BITS> HD uint64_t text_win_base(uint64_t pos0) { return pos0 / Tex
 //                scratch otherwise (level B in quantile mode: the knots of the segment's group).  Keys only: all
 //                suffixes with one key value land in one bucket, so buckets are consecutive slices of the suffix order.
 constexpr int MAP_LINEAR = 0, MAP_GROUPED = 1, MAP_SPLIT = 2;
+// Where entry i of a sorted table (<= 4096 entries of 8 bytes) sits in LDS.  A lock-step binary search probes, in step j, the
+// entries (2 m + 1) 2^j - 1: a stride of 2^(j + 1) entries -- for j >= 3 every probe of a wave falls into the same LDS banks,
+// and the upper steps of the search are serialised up to 32 ways (PMC: 87 % of the LDS cycles of the quantile count pass were
+// bank conflicts).  XOR-ing the next two index nibbles into the lowest one (which picks the bank pair inside a 128-byte row)
+// spreads those probes over all banks; a bijection inside every aligned block of 4096 entries.
+HD uint32_t lds_swz(uint32_t i) { return i ^ ((i >> 4) & 15u) ^ ((i >> 8) & 15u); }
+#ifdef CAPS_GA_NO_SWZ              /* measurement: level A's splitter table unswizzled */
+#define GA_SWZ(i) (i)
+#else
+#define GA_SWZ(i) lds_swz(i)
+#endif
 constexpr uint32_t COUNT_CHUNK = 8;            // tiles per chunk of bucket_count_kernel
 
 // Persistent workgroups (a tile is little work: launching one workgroup per tile is bound by
@@ -2528,7 +2539,7 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_count_kernel(KCTX SegDesc sd, const uint
                 for (uint32_t i = tid; i < cur_B; i += K_BLOCK_DIM)
                     if (hist[i]) ATOMIC_ADD_U64(&count[cur_b0 + i], (uint64_t)hist[i]);
                 if (lds) for (uint32_t i = tid; i < bp.B; i += K_BLOCK_DIM) hist[i] = 0;
-                if (MAP == MAP_SPLIT && lds) for (uint32_t i = tid; i < n_split; i += K_BLOCK_DIM) stab[i] = tab[i];
+                if (MAP == MAP_SPLIT && lds) for (uint32_t i = tid; i < n_split; i += K_BLOCK_DIM) stab[lds_swz(i)] = tab[i];
             }
             if (FROM_TEXT)
                 for (uint32_t i = tid; i < TEXT_WIN; i += K_BLOCK_DIM) twin[i] = w0 + i < n_words ? P[w0 + i] : 0u;
@@ -2551,13 +2562,21 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_count_kernel(KCTX SegDesc sd, const uint
                                        : in_key[start + e];
                 bk[k] = MAP == MAP_SPLIT ? 0u : bucket_of(bp, key[k]);
             }
-            if (MAP == MAP_SPLIT) {
-                const uint64_t* tb = lds ? stab : tab;                        // more knots than LDS holds: search in HBM
+            if (MAP == MAP_SPLIT && lds) {                                    // (two loops: one pointer for both tables would
+                for (uint32_t st = top >> 1; st >= 1; st >>= 1) {             //  make every probe a flat load)
+                    UNROLL
+                    for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                        const uint32_t idx = bk[k] + st - 1;
+                        const uint64_t mk = stab[lds_swz(idx < n_split ? idx : n_split - 1)];
+                        if (idx < n_split && mk < key[k]) bk[k] += st;
+                    }
+                }
+            } else if (MAP == MAP_SPLIT) {                                    // more knots than LDS holds: search in HBM
                 for (uint32_t st = top >> 1; st >= 1; st >>= 1) {
                     UNROLL
                     for (uint32_t k = 0; k < TILE_EPT; ++k) {
                         const uint32_t idx = bk[k] + st - 1;
-                        const uint64_t mk = tb[idx < n_split ? idx : n_split - 1];
+                        const uint64_t mk = tab[idx < n_split ? idx : n_split - 1];
                         if (idx < n_split && mk < key[k]) bk[k] += st;
                     }
                 }
@@ -2670,7 +2689,7 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
         PAR(tid) {
             if (lds) for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0;
             if (MAP == MAP_SPLIT && lds && !bid) {
-                for (uint32_t i = tid; i < n_split; i += K_BLOCK_DIM) stab[i] = tab[i];
+                for (uint32_t i = tid; i < n_split; i += K_BLOCK_DIM) stab[lds_swz(i)] = tab[i];
                 if (split_lut) for (uint32_t i = tid; i <= SPLIT_LUT_CELLS; i += K_BLOCK_DIM) slut[i] = split_lut[i];
             }
             if (grouped)                                   // slot i owns the fine buckets [gfirst[i], gfirst[i + 1]) (F for unused slots)
@@ -2725,7 +2744,7 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
                 UNROLL
                 for (uint32_t k = 0; k < TILE_EPT; ++k) {
                     const uint32_t idx = TL(rb, tid, k) + s - 1;
-                    const uint64_t mk = stab[idx < n_split ? idx : n_split - 1];
+                    const uint64_t mk = stab[lds_swz(idx < n_split ? idx : n_split - 1)];
                     if (idx < TL(rh, tid, k) && mk < TL(rk, tid, k)) TL(rb, tid, k) += s;
                 }
             }
@@ -2916,7 +2935,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) group_scatter_kernel(KCTX
     PAR(tid) {
         for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0;
         for (uint32_t i = tid; i < WIN; i += K_BLOCK_DIM) twin[i] = w0 + i < n_words ? P[w0 + i] : 0u;
-        for (uint32_t i = tid; i < n_split; i += K_BLOCK_DIM) stab[i] = split[i];
+        for (uint32_t i = tid; i < n_split; i += K_BLOCK_DIM) stab[GA_SWZ(i)] = split[i];
         for (uint32_t i = tid; i <= SPLIT_LUT_CELLS; i += K_BLOCK_DIM) slut[i] = split_lut[i];
         if (K32) for (uint32_t i = tid; i < K1; i += K_BLOCK_DIM) scs[i] = gshift[i];
     }
@@ -2952,7 +2971,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) group_scatter_kernel(KCTX
                 UNROLL
                 for (uint32_t j = 0; j < 4; ++j) {
                     const uint32_t idx = lo[j] + st - 1;
-                    const uint64_t mk = stab[idx < n_split ? idx : (n_split ? n_split - 1 : 0)];
+                    const uint64_t mk = stab[GA_SWZ(idx < n_split ? idx : (n_split ? n_split - 1 : 0))];
                     if (idx < hi[j] && mk < key[j]) lo[j] += st;
                 }
             }
