@@ -912,6 +912,13 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
     SHARED_ARRAY(uint32_t, hist, TILE_BINS + 1);
     SHARED_ARRAY(uint64_t, kmm, 2);          // min / max key of the tile
     SHARED_ARRAY(uint32_t, flag, 1);         // a bin overflowed
+    // SLOT_ORDER: from the rank phase on a thread works on the elements in slots tid + k * TILE_NT instead of the ones it
+    // loaded (their bins: sbin).  The lanes of a wave then hold neighbouring slots -- mostly one bin or two: the keys they scan
+    // are the same LDS words (one read serves all), the loops have the same length, and the final placement moves every
+    // element a few slots, neighbours to neighbours, where the loaded elements sat in 64 bins all over the tile (half of
+    // this kernel's LDS cycles were bank conflicts).  64-bit indices: no room in LDS (two workgroups per CU) for sbin.
+    constexpr bool SLOT_ORDER = sizeof(idx_t) == 4;
+    SHARED_ARRAY(uint16_t, sbin, SLOT_ORDER ? TILE_E : 1);
     TL_DECL(KT, rk, TILE_EPT);
     TL_DECL(idx_t, rs, TILE_EPT);
     TL_DECL(uint32_t, rd, TILE_EPT);
@@ -955,7 +962,8 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
                     const uint32_t slot = hist[TL(rb, tid, k)] + TL(rd, tid, k);
                     skey[slot] = TL(rk, tid, k);
                     ssa[slot] = TL(rs, tid, k);
-                    TL(rd, tid, k) = slot;
+                    if (SLOT_ORDER) sbin[slot] = (uint16_t)TL(rb, tid, k);
+                    else TL(rd, tid, k) = slot;
                 }
             }
         }
@@ -966,8 +974,9 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
             for (uint32_t k = 0; k < TILE_EPT; ++k) {
                 const uint32_t e = tid + k * TILE_NT;
                 if (e < cnt) {
-                    const uint32_t bin = TL(rb, tid, k), slot = TL(rd, tid, k);
+                    const uint32_t slot = SLOT_ORDER ? e : TL(rd, tid, k), bin = SLOT_ORDER ? (uint32_t)sbin[slot] : TL(rb, tid, k);
                     const uint32_t bs = hist[bin], be = hist[bin + 1];
+                    if (SLOT_ORDER) { TL(rk, tid, k) = skey[slot]; TL(rs, tid, k) = ssa[slot]; }    // mine from here on
                     const uint64_t key = TL(rk, tid, k);
                     const uint64_t sa = (uint64_t)TL(rs, tid, k);
                     uint32_t less = 0;                        // members of my bin that sort before me
