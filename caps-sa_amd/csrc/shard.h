@@ -613,7 +613,8 @@ private:
                 sseg.G = 1;
                 CAPS_LAUNCH(uniform_segments_kernel, 1, 256, be_, sseg.seg_start, 1u, m2_, m2_);
                 prepare_segments(be_, sseg, tiles_of(m2_));
-                ElemBuf<idx_t> smp2 = sort<BITS>(sseg, tiles_of(m2_), m2_, false, A_, B_, m2_, 0, false, false, &bk_, true).uniform();
+                ElemBuf<idx_t> smp2 = sort<BITS>(sseg, tiles_of(m2_), m2_, false, A_, B_, m2_, 0, false, false, &bk_, true, false, nullptr, nullptr,
+                                                 gkey_, K1_, skewed_).uniform();
                 CAPS_LAUNCH(knots_kernel, (uint32_t)((NB_ + 255) / 256), 256, be_, (const uint64_t*)smp2.key, m2_, NB_, KPG_, K1_, knots_, gkey_);
                 CAPS_LAUNCH(group_caps_kernel, (K1_ + 255) / 256, 256, be_, (const uint64_t*)knots_, NB_, KPG_, K1_, SUB_, capA_ - token, token, rcap_);
                 CAPS_LAUNCH(scan_sizes_kernel, 1, 1024, be_, (const uint64_t*)rcap_, n_streams_, rstart_);
@@ -740,9 +741,13 @@ private:
     template <int BITS>
     SortResult<idx_t> sort(const SegBufs& s, uint32_t n_tiles, uint64_t max_len, bool from_text, ElemBuf<idx_t> a, ElemBuf<idx_t> b,
                            uint64_t n_elems, uint64_t text_base, bool need_lcp, bool skip_finished, const BucketBufs* bk = nullptr,
-                           bool unify = false, bool between_pivots = false, void* final_sa = nullptr, void* final_lcp = nullptr)
+                           bool unify = false, bool between_pivots = false, void* final_sa = nullptr, void* final_lcp = nullptr,
+                           const uint64_t* knots = nullptr, uint32_t knots_per_parent = 0, bool skewed = false)
     {
         SortOpts o;
+        o.knots = knots;                          // (the second sample: split at the first sample's group keys, as Builder::run_direct)
+        o.knots_per_parent = knots_per_parent;
+        o.skewed_keys = skewed;
         if (final_sa && bk) {                     // completed segments go straight to the caller's arrays
             o.final_sa = final_sa;
             o.final_lcp = final_lcp;
