@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 # genome-like workloads: the text comes from a file (their generators launch ~1e6 tiny kernels: rocprofv3 --pmc segfaults on them)
 TXT=""
 case $WL in g*) python3 /root/repo/tools/make_text.py $WL /tmp/pmc_text_$WL.npy && TXT="--text-file /tmp/pmc_text_$WL.npy" ;; esac
-run() { tag=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /root/repo/gpurun_out/pmc_${WL}_$tag -- python3 /root/repo/bench.py --workload $WL $TXT --steps 1 --warmup 0 --no-cpu-baseline --no-host-path --no-verify > /root/repo/gpurun_out/pmc_${WL}_$tag.log 2>&1; tail -1 /root/repo/gpurun_out/pmc_${WL}_$tag.log | cut -c1-120; }
+run() { tag=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /root/repo/gpurun_out/pmc_${WL}_$tag -- python3 /root/repo/bench.py --workload $WL $TXT --steps 1 --warmup 0 --prewarm-s 0 --no-cpu-baseline --no-host-path --no-verify > /root/repo/gpurun_out/pmc_${WL}_$tag.log 2>&1; tail -1 /root/repo/gpurun_out/pmc_${WL}_$tag.log | cut -c1-120; }
 for g in $GROUPS_; do
   case $g in
     lds) run lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS ;;

@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 WL=${WL:-g2r}
 TAG=${TAG:-r3_prof_$WL}
 R=$GRAFT_REPO_ROOT
-cd /tmp && timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_d -o $TAG -- python3 $R/bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --no-host-path --no-verify > $R/gpurun_out/$TAG.log 2>&1
+cd /tmp && timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_d -o $TAG -- python3 $R/bench.py --workload $WL --steps 2 --warmup 1 --prewarm-s 0 --no-cpu-baseline --no-host-path --no-verify > $R/gpurun_out/$TAG.log 2>&1
 echo "prof rc=$?"
 cd $R
 f=$(find gpurun_out/${TAG}_d -name "*kernel_stats.csv" | head -1)

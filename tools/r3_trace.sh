@@ -8,7 +8,7 @@ TAG=${TAG:-r3_trace_$WL}
 R=$GRAFT_REPO_ROOT
 TXT=""
 case $WL in g*) python3 $R/tools/make_text.py $WL /tmp/trace_text_$WL.npy && TXT="--text-file /tmp/trace_text_$WL.npy" ;; esac
-cd /tmp && timeout -k 10 500 rocprofv3 --kernel-trace --output-format csv -d /tmp/${TAG}_d -o $TAG -- python3 $R/bench.py --workload $WL $TXT --steps 1 --warmup 1 --no-cpu-baseline --no-host-path --no-verify $EXTRA > $R/gpurun_out/$TAG.log 2>&1
+cd /tmp && timeout -k 10 500 rocprofv3 --kernel-trace --output-format csv -d /tmp/${TAG}_d -o $TAG -- python3 $R/bench.py --workload $WL $TXT --steps 1 --warmup 1 --prewarm-s 0 --no-cpu-baseline --no-host-path --no-verify $EXTRA > $R/gpurun_out/$TAG.log 2>&1
 echo "trace rc=$?"
 cd $R
 f=$(find /tmp/${TAG}_d -name "*kernel_trace.csv" | head -1)
