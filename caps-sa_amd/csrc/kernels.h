@@ -1032,8 +1032,8 @@ GLOBAL_FN LAUNCH_BOUNDS(256) queue_all_tiles_kernel(KCTX SegDesc sd, uint32_t* _
 // positions' bins is a piecewise-linear CDF, and the new position is the estimated rank it gives:
 // (count before my bin + fraction x count of my bin) * TILE_BINS / cnt.  After EQ_ROUNDS rounds the bin of
 // the position is the counting sort's bin -- monotone in the key, so the exact in-bin ranking of tile_sort_kernel
-// finish the job unchanged.  Takes the tiles from tile_sort_kernel's queue (redo[0] = length) with a
-// fixed grid; a tile that still has a bin above TILE_BIN_LIMIT (clusters of suffixes that share more
+// finish the job unchanged.  Takes the tiles from tile_sort_kernel's queue (redo[0] = length), with a fixed grid or one
+// workgroup per entry (PERSIST below); a tile that still has a bin above TILE_BIN_LIMIT (clusters of suffixes that share more
 // chars than the coarse bins resolve), or a deep tie, goes on to tile_sort_general_kernel (redo2).
 // A separate kernel rather than a branch of tile_sort_kernel: that one runs at the register budget.
 #ifndef CAPS_EQ_ROUNDS
@@ -1603,7 +1603,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
 
 // ---- tile_sort_general_kernel: the tiles tile_sort_kernel could not finish ------------------
 // (keys far from uniform inside the tile, or equal keys: repeats), taken from its queue
-// (redo[0] = length, redo[1..] = tile ids) by a fixed grid of workgroups.  Comparison based,
+// (redo[0] = length, redo[1..] = tile ids) by a fixed grid of workgroups, or one per entry (PERSIST).  Comparison based,
 // hence independent of the key distribution:
 //  1. samplesort in LDS: every 4th element is a sample; the (<= 1023) samples are sorted by
 //     rank-merge levels; every element finds its bin among the sorted samples by a branch-free
