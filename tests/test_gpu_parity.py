@@ -411,6 +411,42 @@ def test_genome_like_markov_with_repeats_device(L, sa_path):
     assert int(LCP.max().item()) > 200          # the planted repeats are there
 
 
+def test_skewed_texts_with_64_bit_indices_and_8_bit_codes_device(L):
+    """The builds of tile_sort_eq_kernel / tile_sort_general_kernel that take one queue entry per workgroup (skewed texts: quantile
+    level B, every tile queued) exist per index width and code width: genome-like text with 64-bit indices (no slot-order
+    ranking there: no room in LDS), and a skewed 20-letter text (8-bit codes) with both widths.  Exact device verifier."""
+    import os
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    from genome_like import markov_dna
+    n = 40_000_001
+    T = markov_dna(n, seed=13)
+    SA = torch.empty(n, dtype=torch.int64, device="cuda")
+    LCP = torch.empty(n, dtype=torch.int64, device="cuda")
+    st = L.build_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr(), p=1000, idx_bits=64)
+    assert st["path_direct"] == 1 and st["direct_quantile"] == 1
+    assert L.verify_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr(), idx_bits=64) == 0
+    del SA, LCP
+    # 20 letters, geometric frequencies, every 50th block of 200 chars repeats an earlier block (equal keys, deep ties)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    w = torch.tensor([0.75 ** i for i in range(20)], device="cuda")
+    n = 24_000_000
+    T = (torch.multinomial(w / w.sum(), n, replacement=True, generator=g) + 65).to(torch.uint8)
+    blocks = T.view(-1, 200)
+    src = torch.randint(0, blocks.shape[0], (blocks.shape[0] // 50,), device="cuda", generator=g)
+    blocks[torch.arange(0, (blocks.shape[0] // 50) * 50, 50, device="cuda")] = blocks[src]
+    for bits, dt in ((32, torch.int32), (64, torch.int64)):
+        SA = torch.empty(n, dtype=dt, device="cuda")
+        LCP = torch.empty(n, dtype=dt, device="cuda")
+        st = L.build_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr(), p=800, idx_bits=bits)
+        assert st["bits_per_char"] == 8
+        assert L.verify_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr(), idx_bits=bits) == 0
+        assert int(LCP.max().item()) >= 200
+        del SA, LCP
+
+
 def test_slot_splits_kept_on_uniform_keys_and_redone_on_skew(L, oracle, sa_path):
     """The bucket splits of phase 1 and phase 2 first scatter into fixed-capacity slots (no count pass).
     Uniform keys: both are kept (and C2 / C3 rely on that for their speed).  Skewed keys: a bucket
