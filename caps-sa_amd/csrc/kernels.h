@@ -1044,7 +1044,7 @@ constexpr uint32_t EQ_ROUNDS = CAPS_EQ_ROUNDS;
 #define CAPS_TIE_G1 8
 #endif
 #ifndef CAPS_TIE_LIST_MAX
-#define CAPS_TIE_LIST_MAX 6
+#define CAPS_TIE_LIST_MAX 2       /* g3 / g3r / g2r at 1, 2, 3, 6, 12: 97.9 98.2 98.4 99.9 100.1 / 150.7 150.5 151.7 153.0 - / 17.8 17.9 17.5 18.5 18.4 ms (beyond: phase B) */
 #endif
 constexpr uint32_t TIE_G1 = CAPS_TIE_G1;          // lanes (= windows) per listed tie in the first round,
 constexpr uint32_t TIE_G2 = 64;                   //   per tie that is still equal in the second
@@ -1172,13 +1172,15 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
     // per slot: "the other member of my pair sorts before me" << 15 | their lcp (0x7FFF: see vlcp); after the final placement: the
     // lcp with the predecessor where a tie settled it (0x7FFF: see vslot / vlcp)
     uint16_t* tinfo = reinterpret_cast<uint16_t*>(hist);
-    const uint32_t n_redo = redo[0];
+    // redo == nullptr (PERSIST = false only): every tile is this kernel's and the grid is the tile count -- no queue to read (one
+    // dependent round trip to memory less at the head of every tile)
+    const uint32_t n_redo = redo ? redo[0] : K_GRID_DIM;
     // (fetching the queue entry and the record of the NEXT tile while this one is sorted was tried: no gain, and the record's
     // registers, held across the whole tile, went to scratch)
     uint32_t qi = K_BLOCK_IDX;
     if (qi >= n_redo) return;
     do {
-    const uint32_t b = redo[1 + qi];
+    const uint32_t b = redo ? redo[1 + qi] : qi;
     const TileInfo t = tile_info(sd, b);
     const uint32_t g = t.g;
     const uint64_t start = t.s0 + (uint64_t)t.tl * TILE_E;
@@ -1289,7 +1291,8 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
         //      an own entry in the entry itself.  What is still equal (one tie in eight on such a text) goes on a short list
         //      and gets TIE_G2 lanes per entry in a second round; still equal after that (TIE_G1 + TIE_G2 windows), or more
         //      ties than the lists hold: the tile is the comparison sort's;
-        //  R3  the elements pick their outcomes up; one with more than TIE_LIST_MAX equal keys (rare) compares with each itself.
+        //  B   an element with more than TIE_LIST_MAX equal keys: its own lanes, one comparison each (below);
+        //  R3  the elements pick their outcomes up.
         // The lcp of an element with its predecessor in the final order is the largest lcp with a smaller member of its tie
         // group; it travels with the element to its final slot (slcp) and the emit phase uses it instead of the text.
         // tinfo / slcp: u16 per slot, in the memory of hist (free once R1 has read the bin bounds).
@@ -1338,7 +1341,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
         }
         TILE_SYNC();                                                // hist is free: tinfo / slcp from here on
         PHASE_MARK(16);                                        // R1: rank by keys
-        // B: the elements with more than TIE_LIST_MAX equal keys (0.05 % of a genome-like text's suffixes, in clusters: every
+        // B: the elements with more than TIE_LIST_MAX equal keys (0.1 % of a genome-like text's suffixes, in clusters: every
         // tenth tile holds some).  Each gets up to TIE_BIG_LANES lanes that share its bin: every lane compares it with its share
         // of the equal keys through the text, the comparisons of an element in flight at once -- in the pick-up phase, where every such element
         // went through its equal keys one after the other (c - 1 dependent trips to the text for each member of a cluster of

@@ -752,12 +752,13 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         // the queue (kernels.h PERSIST); otherwise the queue is short (often empty) and a fixed grid walks it
         const bool all_queued = o.skewed_keys && eq_tiles;
         const bool per_tile = all_queued && (uint64_t)n_tiles * TILE_NT <= 0xFFFFFFFFull && !std::getenv("CAPS_SA_EQ_PERSISTENT");
-        if (all_queued) CAPS_LAUNCH(queue_all_tiles_kernel, (n_tiles + 255) / 256, 256, be, sd, redo);
-        else CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
+        if (all_queued && !per_tile) CAPS_LAUNCH(queue_all_tiles_kernel, (n_tiles + 255) / 256, 256, be, sd, redo);
+        else if (!all_queued) CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
                     in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, redo, no_shift);
         if (per_tile) {
+            // (no queue: workgroup b takes tile b)
             CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false, false, false>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
-                        in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo, redo3, 0u, redo2);
+                        in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)nullptr, redo3, 0u, redo2);
             // what is left goes on with exact grids, one workgroup per entry: the lengths of the two queues come back to the
             // host (a round trip of ~20 us; a grid over all tiles for a queue that is mostly empty costs 0.8 ms at 3e9, and the
             // builds that walk a queue with a fixed grid hold 6 - 20 x more registers in scratch)
