@@ -448,6 +448,10 @@ struct SortOpts {
     const uint8_t* gshift = nullptr;    // non-null with range_mode 2: 32-bit keys (text.h key32_of), the parents' shifts
     bool k32 = false;                   // the elements (in_key, read as uint32_t) carry 32-bit keys; slots only: when a slot
                                         //   overflows the sort gives up (SortResult::failed) and the caller falls back to 64-bit keys
+    bool keys_only = false;             // order by key, equal keys by index: no comparison reads the text (the samples of the direct
+                                        //   path: only their keys are used -- pivots, knots -- and a text with long N-blocks has
+                                        //   millions of samples with one key).  Done by sorting as if the text had length 0: every
+                                        //   comparator settles a pair with an index beyond the text at once, by index (text.h)
     bool skewed_keys = false;           // the keys are far from uniform inside the buckets (skew probe): every tile goes to
                                         //   tile_sort_eq_kernel straight away, tile_sort_kernel's linear map is not tried
     const uint64_t* knots = nullptr;    // non-null (quantile mode): parent q's buckets are (knots[q * KPG + i - 1], knots[q * KPG + i]],
@@ -481,6 +485,10 @@ template <typename idx_t, int BITS>
 SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, TileDesc* desc, const SegBufs& s, uint32_t n_tiles,
                                  uint64_t max_len, ElemBuf<idx_t> cur, ElemBuf<idx_t> oth, uint64_t n_elems, const SortOpts& o)
 {
+    if (o.keys_only) {
+        if (o.from_text || o.need_lcp || o.runs) throw std::invalid_argument("a keys-only sort takes (key, index) arrays and emits no LCPs");
+        n = 0;
+    }
     SortResult<idx_t> r;
     r.buf[0] = cur;
     r.buf[1] = oth;
@@ -1181,6 +1189,7 @@ private:
         SortOpts os;
         os.bk = &pl_.bk;
         os.unify = true;
+        os.keys_only = true;                          // (this path uses the pivots' keys only)
         SortResult<idx_t> rs = seg_sort<BITS>(pl_.segS, tiles_of(m), m, pl_.SA_, pl_.SB_, m, os, false);
         passesS_ = rs.passes;
         ElemBuf<idx_t> smp = rs.uniform();
@@ -1257,6 +1266,7 @@ private:
             oq.knots = pl_.gkey;
             oq.knots_per_parent = K1;
             oq.skewed_keys = probe[2] != 0;
+            oq.keys_only = true;
             SortResult<idx_t> rq = seg_sort<BITS>(sseg, tiles_of(m2), m2, pl_.A, pl_.B, m2, oq, false);
             ElemBuf<idx_t> smp2 = rq.uniform();
             CAPS_LAUNCH(knots_kernel, (uint32_t)((NB + 255) / 256), 256, be_, (const uint64_t*)smp2.key, m2, NB, KPG, K1, pl_.knots, pl_.gkey);

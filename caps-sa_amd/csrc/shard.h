@@ -745,6 +745,7 @@ private:
                            const uint64_t* knots = nullptr, uint32_t knots_per_parent = 0, bool skewed = false)
     {
         SortOpts o;
+        o.keys_only = knots != nullptr;           // (the second sample: its keys become the knots, nothing else is used)
         o.knots = knots;                          // (the second sample: split at the first sample's group keys, as Builder::run_direct)
         o.knots_per_parent = knots_per_parent;
         o.skewed_keys = skewed;
