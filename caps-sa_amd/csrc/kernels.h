@@ -1203,7 +1203,10 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
         }
         // position -> estimated rank, EQ_ROUNDS times: histogram of the positions' bins, its prefix sums are a
         // piecewise-linear CDF, the new position is the CDF value scaled back to [0, TILE_BINS)
-        const uint64_t K = ((uint64_t)TILE_BINS << 32) / cnt;
+        // estimated rank -> position: E * TILE_BINS / cnt.  In single precision: only monotony in E counts (equal or larger E
+        // never gives a smaller position: conversion, product and truncation are all monotone), and E < 2^27, so the 64-bit
+        // product this used to be cost three times the instructions for bits the bins never see.
+        const float Kf = (float)TILE_BINS / (float)cnt;
         for (uint32_t round = 0; round < EQ_ROUNDS; ++round) {
             if (round) {
                 PAR(tid) { for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0; }
@@ -1226,8 +1229,8 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                         const uint32_t x = TL(rb, tid, k);
                         const uint32_t bn = x >> EQ_FRAC_BITS, fr = x & ((1u << EQ_FRAC_BITS) - 1u);
                         const uint32_t before = hist[bn], here = hist[bn + 1] - before;
-                        const uint64_t E = ((uint64_t)before << EQ_FRAC_BITS) + (uint64_t)here * fr;     // < cnt * 2^13
-                        const uint32_t y = (uint32_t)((E * K) >> 32);                                     // < TILE_BINS * 2^13
+                        const uint32_t E = (before << EQ_FRAC_BITS) + here * fr;                          // < cnt * 2^13 <= 2^25 (+ 2^25)
+                        const uint32_t y = (uint32_t)((float)E * Kf);                                     // ~ E * TILE_BINS / cnt
                         TL(rb, tid, k) = y < (TILE_BINS << EQ_FRAC_BITS) ? y : (TILE_BINS << EQ_FRAC_BITS) - 1u;
                     }
                 }
