@@ -677,12 +677,18 @@ DEV_INLINE void block_exclusive_scan(KCTX uint32_t* h)
     uint32_t v[BPT], sum = 0;
     UNROLL
     for (uint32_t i = 0; i < BPT; ++i) { v[i] = h[tid * BPT + i]; sum += v[i]; }
+    // inclusive scan over the wave with DPP moves (rows of 16 lanes: shifts by 1, 2, 4, 8; then the last lane of row 0 / 2 into
+    // row 1 / 3, and lane 31 into rows 2 and 3): six move + add pairs.  (__shfl_up costs an index computation and a
+    // ds_bpermute per step: the four scans of a tile were ~10 % of tile_sort_eq_kernel's instructions.)
     uint32_t x = sum;
-    UNROLL
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t y = __shfl_up(x, d, 64);
-        if ((int)lane >= d) x += y;
-    }
+#define CAPS_DPP_ADD(ctrl, rows) x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rows, 0xF, false)
+    CAPS_DPP_ADD(0x111, 0xF);        // row_shr:1
+    CAPS_DPP_ADD(0x112, 0xF);        // row_shr:2
+    CAPS_DPP_ADD(0x114, 0xF);        // row_shr:4
+    CAPS_DPP_ADD(0x118, 0xF);        // row_shr:8
+    CAPS_DPP_ADD(0x142, 0xA);        // row_bcast:15 -> rows 1 and 3
+    CAPS_DPP_ADD(0x143, 0xC);        // row_bcast:31 -> rows 2 and 3
+#undef CAPS_DPP_ADD
     if (lane == 63) wave_tot[wv] = x;
     SYNC_LDS();
     uint32_t run = x - sum;
