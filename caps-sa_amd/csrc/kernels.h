@@ -748,15 +748,29 @@ constexpr uint32_t EQ_BIN_LIMIT = CAPS_EQ_BIN_LIMIT;
 // LDS: TILE_E x (8 + sizeof(idx_t)).
 // ----------------------------------------------------------------------------------
 // LCP of two neighbours of a sorted tile from their keys, 64-bit or 32-bit (text.h); cs: the 32-bit keys' shift
-template <int BITS, bool RUNS>
-DEV_INLINE uint64_t tile_pair_lcp(const uint32_t* __restrict__ P, uint64_t n, uint64_t ka, uint64_t a, uint64_t kb, uint64_t b, uint32_t)
+// min(l, chars the shorter of the suffixes a, b has), in the width of the indices: with 32-bit indices n < 2^32, and the
+// 64-bit max / subtract / min of the generic form are a tenth of tile_sort_kernel's instructions per suffix
+template <typename idx_t>
+DEV_INLINE uint64_t lcp_capped(uint32_t l, uint64_t n, idx_t a, idx_t b)
 {
-    return pair_lcp<BITS, RUNS>(P, n, ka, a, kb, b);
+    if (sizeof(idx_t) == 4) {
+        const uint32_t room = (uint32_t)n - (uint32_t)(a > b ? a : b);
+        return l < room ? l : room;
+    }
+    const uint64_t room = n - (uint64_t)(a > b ? a : b);
+    return l < room ? l : room;
 }
-template <int BITS, bool RUNS>
-DEV_INLINE uint64_t tile_pair_lcp(const uint32_t* __restrict__ P, uint64_t n, uint32_t ka, uint64_t a, uint32_t kb, uint64_t b, uint32_t cs)
+template <int BITS, bool RUNS, typename idx_t>
+DEV_INLINE uint64_t tile_pair_lcp(const uint32_t* __restrict__ P, uint64_t n, uint64_t ka, idx_t a, uint64_t kb, idx_t b, uint32_t)
 {
-    return pair_lcp32<BITS, RUNS>(P, n, ka, a, kb, b, cs);
+    const uint64_t x = ka ^ kb;
+    if (x) return lcp_capped<idx_t>((uint32_t)caps_clz64(x) / BITS, n, a, b);
+    return pair_lcp<BITS, RUNS>(P, n, ka, (uint64_t)a, kb, (uint64_t)b);
+}
+template <int BITS, bool RUNS, typename idx_t>
+DEV_INLINE uint64_t tile_pair_lcp(const uint32_t* __restrict__ P, uint64_t n, uint32_t ka, idx_t a, uint32_t kb, idx_t b, uint32_t cs)
+{
+    return pair_lcp32<BITS, RUNS>(P, n, ka, (uint64_t)a, kb, (uint64_t)b, cs);
 }
 
 // Measurement only (make variant VARIANT_DEFS=-DCAPS_PHASE_CLOCK; never in the product build): thread 0 of every workgroup
@@ -872,7 +886,7 @@ __device__ unsigned long long caps_phase_clock[32];
                 uint64_t l = 0;                                                                                 \
                 if (with_lcp && e) {                                                                            \
                     const uint32_t ov_ = (OV);                                                                  \
-                    l = ov_ ? ov_ : TILE_EMIT_LCP_(skey[e - 1], (uint64_t)ssa[e - 1], skey[e], (uint64_t)sa);      \
+                    l = ov_ ? ov_ : TILE_EMIT_LCP_(skey[e - 1], ssa[e - 1], skey[e], sa);                          \
                 }                                                                                               \
                 if (direct) {                                                                                   \
                     fin.sa[start + e] = sa;                                                                     \
@@ -1089,14 +1103,12 @@ DEV_INLINE uint32_t eq_big_lcp(const uint16_t* vslot, const uint32_t* vlcp, uint
 // lcp of two neighbours of the sorted tile that no tie has settled.  TEXT = false (the plain build): their keys differ --
 // every pair of equal keys has its lcp from the tie phases, and those are never 0 -- so the keys tell; the comparator through
 // the text, unrolled four times in the emit phase, cost that phase registers (scratch) for a path no tile takes.
-template <int BITS, bool TEXT>
-DEV_INLINE uint64_t eq_emit_lcp(const uint32_t* __restrict__ P, uint64_t n, uint64_t ka, uint64_t a, uint64_t kb, uint64_t b)
+template <int BITS, bool TEXT, typename idx_t>
+DEV_INLINE uint64_t eq_emit_lcp(const uint32_t* __restrict__ P, uint64_t n, uint64_t ka, idx_t a, uint64_t kb, idx_t b)
 {
-    if (TEXT) return pair_lcp<BITS, false>(P, n, ka, a, kb, b);
-    const uint64_t maxlen = n - (a > b ? a : b);
+    if (TEXT) return pair_lcp<BITS, false>(P, n, ka, (uint64_t)a, kb, (uint64_t)b);
     const uint64_t x = ka ^ kb;
-    const uint64_t l = x ? (uint32_t)caps_clz64(x) / BITS : TextTraits<BITS>::KCH;
-    return l < maxlen ? l : maxlen;
+    return lcp_capped<idx_t>(x ? (uint32_t)caps_clz64(x) / BITS : TextTraits<BITS>::KCH, n, a, b);
 }
 
 #ifndef CAPS_EQ_WAVES
