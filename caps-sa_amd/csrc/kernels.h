@@ -692,7 +692,21 @@ DEV_INLINE void block_exclusive_scan(KCTX uint32_t* h)
     if (lane == 63) wave_tot[wv] = x;
     SYNC_LDS();
     uint32_t run = x - sum;
-    for (uint32_t w = 0; w < wv; ++w) run += wave_tot[w];
+    if (TILE_NT / 64 <= 16) {
+        // the waves' totals: lanes 0 .. 15 hold one each, prefix by DPP within the row, this wave's through readlane
+        const uint32_t wt = lane < TILE_NT / 64 ? wave_tot[lane] : 0u;
+        uint32_t ws = wt;
+#define CAPS_DPP_ADD(ctrl) ws += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ws, ctrl, 0xF, 0xF, false)
+        CAPS_DPP_ADD(0x111);
+        CAPS_DPP_ADD(0x112);
+        CAPS_DPP_ADD(0x114);
+        CAPS_DPP_ADD(0x118);
+#undef CAPS_DPP_ADD
+        const int wvs = __builtin_amdgcn_readfirstlane((int)wv);
+        run += (uint32_t)__builtin_amdgcn_readlane((int)ws, wvs) - (uint32_t)__builtin_amdgcn_readlane((int)wt, wvs);
+    } else {
+        for (uint32_t w = 0; w < wv; ++w) run += wave_tot[w];
+    }
     UNROLL
     for (uint32_t i = 0; i < BPT; ++i) { h[tid * BPT + i] = run; run += v[i]; }
     if (tid == TILE_NT - 1) h[NBINS] = run;
