@@ -47,9 +47,6 @@ static inline uint32_t caps_emul_phase_start() { static uint32_t c = 12345u; c =
 #else
 #define PAR(tid) for (uint32_t tid = 0; tid < kctx_.block_dim; ++tid)
 #endif
-#define PAR_TID_DECL ((void)0)
-#define PAR_FRESH_SET(tid) PAR(tid)
-#define PAR_SAME(tid) PAR(tid)
 #define SYNC() ((void)0)
 #define SYNC_LDS() ((void)0)
 #define SHARED_ARRAY(type, name, count) std::vector<type> name##_vec_(count); type* name = name##_vec_.data()
@@ -98,11 +95,6 @@ static inline uint32_t caps_bswap32(uint32_t x) { return __builtin_bswap32(x); }
 // (scatters, tile_sort_kernel) lose 2-7 % to it.
 static __device__ __forceinline__ uint32_t caps_tid_fresh() { uint32_t t = threadIdx.x; asm volatile("" : "+v"(t)); return t; }
 #define PAR_FRESH(tid) for (uint32_t tid = caps_tid_fresh(), par_once_ = 1; par_once_; par_once_ = 0)
-// ... and a middle way: PAR_FRESH_SET starts a group of regions, PAR_SAME regions behind it share its index (what they derive
-// from it may stay in registers across the group, not across the kernel).  PAR_TID_DECL: once at the head of the kernel.
-#define PAR_TID_DECL uint32_t caps_par_tid_ = 0
-#define PAR_FRESH_SET(tid) for (uint32_t tid = (caps_par_tid_ = caps_tid_fresh()), par_once_ = 1; par_once_; par_once_ = 0)
-#define PAR_SAME(tid) for (uint32_t tid = caps_par_tid_, par_once_ = 1; par_once_; par_once_ = 0)
 #define SYNC() __syncthreads()
 // Barrier that orders LDS traffic only: s_waitcnt lgkmcnt(0) + s_barrier.  __syncthreads() also drains the wave's
 // outstanding global stores and returning atomics (vmcnt); where nothing that went to global memory is handed to another

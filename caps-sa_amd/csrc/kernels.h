@@ -1207,7 +1207,6 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
     // redo == nullptr (PERSIST = false only): every tile is this kernel's and the grid is the tile count -- no queue to read (one
     // dependent round trip to memory less at the head of every tile)
     const uint32_t n_redo = redo ? redo[0] : K_GRID_DIM;
-    PAR_TID_DECL;
     // (fetching the queue entry and the record of the NEXT tile while this one is sorted was tried: no gain, and the record's
     // registers, held across the whole tile, went to scratch)
     uint32_t qi = K_BLOCK_IDX;
@@ -1227,7 +1226,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
     PHASE_MARK(8);                                             // load
     bool fast = cnt > EQ_BIN_LIMIT && tb.range > 0 && tb.B == TILE_BINS;
     if (fast) {
-        PAR_FRESH_SET(tid) {
+        PAR(tid) {
             UNROLL
             for (uint32_t k = 0; k < TILE_EPT; ++k) {
                 const uint32_t e = tid + k * TILE_NT;
@@ -1242,10 +1241,10 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
         const float Kf = (float)TILE_BINS / (float)cnt;
         for (uint32_t round = 0; round < EQ_ROUNDS; ++round) {
             if (round) {
-                PAR_SAME(tid) { for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0; }
+                PAR(tid) { for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0; }
                 TILE_SYNC();
             }
-            PAR_SAME(tid) {
+            PAR(tid) {
                 UNROLL
                 for (uint32_t k = 0; k < TILE_EPT; ++k) {
                     const uint32_t e = tid + k * TILE_NT;
@@ -1254,7 +1253,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
             }
             TILE_SYNC();
             block_exclusive_scan_bins(KCTX_PASS hist);
-            PAR_SAME(tid) {
+            PAR(tid) {
                 UNROLL
                 for (uint32_t k = 0; k < TILE_EPT; ++k) {
                     const uint32_t e = tid + k * TILE_NT;
@@ -1271,14 +1270,14 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
             TILE_SYNC();
         }
         PHASE_MARK(9);                                         // equalisation rounds
-        PAR_SAME(tid) {
+        PAR(tid) {
             for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0;
             if (tid < 8) pcnt[tid] = 0;
             if (tid == 0) flag[1] = 0;
             for (uint32_t i = tid; i < BIG_CAP; i += K_BLOCK_DIM) { bmore[i] = 0; bbest[i] = 0; }
         }
         TILE_SYNC();
-        PAR_SAME(tid) {
+        PAR(tid) {
             UNROLL
             for (uint32_t k = 0; k < TILE_EPT; ++k) {
                 const uint32_t e = tid + k * TILE_NT;
@@ -1298,7 +1297,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
     if (fast) {                                                // from here on: as in tile_sort_kernel
         block_exclusive_scan_bins(KCTX_PASS hist);
         PHASE_MARK(11);                                        // scan
-        PAR_SAME(tid) {
+        PAR(tid) {
             UNROLL
             for (uint32_t k = 0; k < TILE_EPT; ++k) {
                 const uint32_t e = tid + k * TILE_NT;
@@ -1421,7 +1420,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                     const uint32_t n_ent = round ? (pcnt[2] < TIE_DEEP_CAP ? pcnt[2] : TIE_DEEP_CAP) : np + nm;
                     if (round && pcnt[2] > TIE_DEEP_CAP) { PAR(tid) { if (tid == 0) flag[0] = 1; } }
                     for (uint32_t base = 0; base < n_ent; base += TILE_NT / G) {
-                        PAR_FRESH_SET(tid) {
+                        PAR(tid) {
                             const uint32_t vi = base + tid / G, W = W0 + tid % G;
                             TL(twa, tid, 0) = 0;
                             TL(twb, tid, 0) = 0;
@@ -1452,7 +1451,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                             }
                         }
                         TILE_SYNC();
-                        PAR_SAME(tid) {
+                        PAR(tid) {
                             const uint32_t W = W0 + tid % G, tp = TL(tpi, tid, 0);
                             if (tp != ~0u) {
                                 const uint32_t pi = tp & 0xFFFFu, vj = (tp >> 16) & 0x7FFFu;
@@ -1554,7 +1553,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
         }
         TILE_SYNC();
         PHASE_MARK(17);                                        // T: the listed ties
-        PAR_FRESH_SET(tid) {
+        PAR(tid) {
             UNROLL
             for (uint32_t k = 0; k < TILE_EPT; ++k) {
                 const uint32_t e = tid + k * TILE_NT;
@@ -1597,7 +1596,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
         fast = flag[0] == 0 && flag[1] == 0;
         PHASE_MARK(13);                                        // rank inside the bin
         if (fast) {
-            PAR_SAME(tid) {
+            PAR(tid) {
                 UNROLL
                 for (uint32_t k = 0; k < TILE_EPT; ++k) {
                     const uint32_t e = tid + k * TILE_NT;
