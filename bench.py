@@ -114,6 +114,64 @@ def cpu_baseline(T_dev, n_sample, p, n_full):
     }
 
 
+def host_memory_available_gb():
+    """What this process may still allocate: MemAvailable, capped by the cgroup's limit minus its usage (the GPU box runs the
+    command in a container)."""
+    avail = float("inf")
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) * 1024 / 1e9
+    except OSError:
+        pass
+    for lim, cur in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                     ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            m = open(lim).read().strip()
+            if m != "max":
+                avail = min(avail, (int(m) - int(open(cur).read().strip())) / 1e9)
+        except (OSError, ValueError):
+            pass
+    return avail
+
+
+def cpu_baseline_full(torch, T_dev, n, p, idx_bits, SA_dev, LCP_dev):
+    """--cpu-full: the oracle's construct() on the WHOLE text on all host threads (the interval the reference prints as
+    "Constructed the suffix array", src/Suffix_Array.cpp:469,492-493), in this process, and its SA / LCP compared entry by
+    entry with the arrays the GPU build left in HBM -- a size-matched parity check on top of the device verifier.  Needs
+    ~(1 + 4 w) n bytes of host memory (C3: 51 GB) and a few minutes; refused when the host cannot hold it."""
+    import numpy as np
+    import oracle as O
+    w = idx_bits // 8
+    need_gb = (1 + 4 * w) * n / 1e9 + 4.0
+    have_gb = host_memory_available_gb()
+    if have_gb < need_gb * 1.15:
+        return {"skipped": f"host memory: {have_gb:.0f} GB available, {need_gb:.0f} GB needed for the oracle at n = {n}"}
+    T = T_dev.cpu().numpy()
+    tm = {}
+    t0 = time.time()
+    SAo, LCPo = O.build_sa_lcp(T, p=p, idx_bits=idx_bits, timings=tm)
+    wall = time.time() - t0
+    dt = torch.int32 if idx_bits == 32 else torch.int64
+    sa_diff = lcp_diff = 0
+    step = 1 << 28
+    for o in range(0, n, step):                     # chunk by chunk through HBM: no second copy of the arrays on the host
+        m = min(step, n - o)
+        a = torch.from_numpy(SAo[o:o + m].view(np.int32 if idx_bits == 32 else np.int64)).to(SA_dev.device)
+        sa_diff += int((a != SA_dev[o:o + m].view(dt)).sum().item())
+        a = torch.from_numpy(LCPo[o:o + m].view(np.int32 if idx_bits == 32 else np.int64)).to(SA_dev.device)
+        lcp_diff += int((a != LCP_dev[o:o + m].view(dt)).sum().item())
+        del a
+    del SAo, LCPo
+    return {
+        "value": n / tm["total"], "unit": "suffixes/s", "cores": int(tm["threads"]), "kind": "port", "seconds": tm["total"],
+        "sample": f"full text ({n} chars), p={p}: oracle construct() interval {tm['total']:.1f} s (wall {wall:.1f} s) on "
+                  f"{int(tm['threads'])} threads of this host (cpus={os.cpu_count()})",
+        "phases_s": {k: v for k, v in tm.items() if k != "threads"},
+        "sa_mismatches_vs_gpu": sa_diff, "lcp_mismatches_vs_gpu": lcp_diff,
+    }
+
+
 def kernel_sources_sha256():
     """Hash of the sources the kernels are built from: profiles/traffic.json carries the hash of the build its PMC passes
     profiled, and its figures are used only while the two agree (the GPU box has no git history to compare commits with)."""
@@ -188,6 +246,9 @@ def parse_args(argv=None):
     ap.add_argument("--seed", type=int, default=42)
     ap.add_argument("--cpu-sample", type=int, default=256 * 1024 * 1024 + 1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-full", action="store_true",
+                    help="time the oracle on the WHOLE text (all host threads, minutes, ~(1 + 4w) n bytes of host memory) instead of on "
+                         "the --cpu-sample prefix, and compare its SA / LCP with the GPU's entry by entry")
     ap.add_argument("--no-verify", action="store_true", help="skip the device verifier after the timed steps")
     ap.add_argument("--verify", action="store_true", help="(default; kept for old command lines)")
     ap.add_argument("--no-host-path", action="store_true", help="skip timing the host-buffer entry point (PCIe inclusive)")
@@ -307,18 +368,30 @@ def main():
         "roofline": roof,
         "verify_errors": verify_errors,
     }
+    parity_errors = 0
+    if args.cpu_full and not args.no_cpu_baseline:
+        del ws
+        torch.cuda.empty_cache()
+        out["cpu_baseline"] = cpu_baseline_full(torch, T, n, args.p, idx_bits, SA, LCP)
+        parity_errors = out["cpu_baseline"].get("sa_mismatches_vs_gpu", 0) + out["cpu_baseline"].get("lcp_mismatches_vs_gpu", 0)
+        if "skipped" in out["cpu_baseline"]:
+            out["cpu_baseline_full_skipped"] = out["cpu_baseline"].pop("skipped")
+            out["cpu_baseline"] = cpu_baseline(T, min(args.cpu_sample, n), args.p, n)
+        ws = None
     if not args.no_host_path:
         del ws, SA, LCP
         torch.cuda.empty_cache()
-        out["pcie_inclusive"] = host_path(L, T, n, args.p, idx_bits)
-    if not args.no_cpu_baseline:
+        out["pcie_inclusive"] = host_path(L, torch, T, n, args.p, idx_bits)
+    if not args.no_cpu_baseline and "cpu_baseline" not in out:
         out["cpu_baseline"] = cpu_baseline(T, min(args.cpu_sample, n), args.p, n)
     print(json.dumps(out))
-    if verify_errors:                       # a wrong result is not a benchmark result
-        raise SystemExit(f"verify_errors = {verify_errors}")
+    host_errors = (out.get("pcie_inclusive") or {}).get("verify_errors") or 0
+    if verify_errors or parity_errors or host_errors:           # a wrong result is not a benchmark result
+        raise SystemExit(f"verify_errors = {verify_errors}, mismatches against the oracle = {parity_errors}, "
+                         f"verify_errors of the host path = {host_errors}")
 
 
-def host_path(L, T_dev, n, p, idx_bits):
+def host_path(L, torch, T_dev, n, p, idx_bits):
     """What construct() callers see: caps_sa_hip_build_* on host buffers (H2D of T, build, D2H of SA and LCP) -- the
     PCIe-inclusive interval.  Never `value`.  Result arrays page-locked (what the class mirror allocates in its
     constructor) and pageable; the entry point keeps its device block between calls, so the first call also pays for it."""
@@ -335,7 +408,22 @@ def host_path(L, T_dev, n, p, idx_bits):
             st = L.build_into(T, SA, LCP, p=p, idx_bits=idx_bits)
             times.append(1e3 * (time.perf_counter() - t0))
         res[label] = {"first_call_ms": times[0], "steady_ms": min(times[1:]), "ms_h2d": st["ms_h2d"], "ms_d2h": st["ms_d2h"],
-                      "ms_build": st["ms_total"], "suffixes_per_s": n / (min(times[1:]) * 1e-3)}
+                      "ms_build": st["ms_total"], "result_waves": st.get("result_waves", 1), "suffixes_per_s": n / (min(times[1:]) * 1e-3)}
+        if pinned:
+            # what came back over the link (in waves, on a second stream, while later groups were sorted) checked ONCE by the exact
+            # device verifier: back up in chunks, no second host copy
+            L.release_cache()
+            dt = torch.int32 if idx_bits == 32 else torch.int64
+            npdt = np.int32 if idx_bits == 32 else np.int64
+            dSA = torch.empty(n, dtype=dt, device=T_dev.device)
+            dLCP = torch.empty(n, dtype=dt, device=T_dev.device)
+            for o in range(0, n, 1 << 28):
+                m = min(1 << 28, n - o)
+                dSA[o:o + m] = torch.from_numpy(SA[o:o + m].view(npdt)).to(T_dev.device)
+                dLCP[o:o + m] = torch.from_numpy(LCP[o:o + m].view(npdt)).to(T_dev.device)
+            res["verify_errors"] = L.verify_device(T_dev.data_ptr(), n, dSA.data_ptr(), dLCP.data_ptr(), idx_bits=idx_bits)
+            del dSA, dLCP
+            torch.cuda.empty_cache()
         del SA, LCP
     L.release_cache()
     return res

@@ -60,6 +60,14 @@ class Stats(ctypes.Structure):
         ("level_a_ms", ctypes.c_double),
         ("direct_key_bits", ctypes.c_uint32),
         ("run_buckets", ctypes.c_uint32),
+        ("result_waves", ctypes.c_uint32),
+        ("n_devices", ctypes.c_uint32),
+        ("ms_upload_max", ctypes.c_double),
+        ("ms_upload_min", ctypes.c_double),
+        ("ms_device_build_max", ctypes.c_double),
+        ("ms_device_build_min", ctypes.c_double),
+        ("ms_download_max", ctypes.c_double),
+        ("ms_download_min", ctypes.c_double),
     ]
 
     def as_dict(self) -> dict:

@@ -231,6 +231,14 @@ int build_host(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context, 
         uint8_t* dT = reinterpret_cast<uint8_t*>(base);
         idx_t* dSA = reinterpret_cast<idx_t*>(base + off_sa);
         idx_t* dLCP = reinterpret_cast<idx_t*>(base + off_lcp);
+        if (std::getenv("CAPS_SA_DEBUG_ALLOC")) {       // where the build's arrays sit (a faulting address can then be placed)
+            const Plan<idx_t> pl = make_plan<idx_t>(n, p_arg, base + off_ws, text_bits);
+            std::fprintf(stderr, "[alloc] block %p + %zu | T %p SA %p LCP %p ws %p | P %p A.key %p A.sa %p A.lcp %p B.key %p B.sa %p B.lcp %p seg1.rec %p SA_.key %p "
+                         "Pm %p desc %p bk.params %p bk.count %p bk.sub.rec %p end %p\n", (void*)hc.base, hc.bytes, (void*)dT, (void*)dSA, (void*)dLCP,
+                         (void*)(base + off_ws), (void*)pl.P, (void*)pl.A.key, (void*)pl.A.sa, (void*)pl.A.lcp, (void*)pl.B.key, (void*)pl.B.sa, (void*)pl.B.lcp,
+                         (void*)pl.seg1.tile_rec, (void*)pl.SA_.key, (void*)pl.Pm, (void*)pl.desc, (void*)pl.bk.params, (void*)pl.bk.count,
+                         (void*)pl.bk.sub.tile_rec, (void*)(base + off_ws + pl.bytes));
+        }
         BackendEvent h0 = be.record();
         be.h2d(dT, T, n);
         BackendEvent h1 = be.record();
@@ -286,6 +294,7 @@ template <typename idx_t> struct MultiRank {
     caps_sa_shard_info info;
     std::vector<uint64_t> sc, rc;
     int sort_code = 0;
+    double ms_upload = 0, ms_build = 0, ms_download = 0;      // host wall clock of this device's stages (caps_sa_stats)
     template <typename T> T* get(size_t count)
     {
         T* q = static_cast<T*>(be->alloc((count ? count : 1) * sizeof(T)));
@@ -347,6 +356,7 @@ int build_multi(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context,
         effective_params(n, p_arg, &p_eff, &ppp);
         if (p_eff < 2) { fallback = CAPS_SA_FB_SHAPE; return CAPS_SA_OK; }
         const int world = n_devices;
+        auto ms = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         std::vector<std::unique_ptr<MultiRank<idx_t>>> ranks;
         for (int r = 0; r < world; ++r) {
             std::unique_ptr<MultiRank<idx_t>> q(new MultiRank<idx_t>);
@@ -355,10 +365,43 @@ int build_multi(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context,
             q->stream = Backend::create_stream();
             q->be.reset(new Backend(q->stream));
             q->dT = q->template get<uint8_t>(n);
-            q->be->h2d(q->dT, T, n);
-            q->sh.reset(new Shard<idx_t>(q->dT, n, p_arg, r, world, q->stream));
-            q->sh->info(&q->info);
             ranks.push_back(std::move(q));
+        }
+        // ---- the text to every device.  ONE upload over PCIe, to ranks[0], in chunks; every chunk goes on from there to the other
+        // devices by peer copies (xGMI: one stream per destination, so the seven links of devices[0] work side by side) while the
+        // next chunk is still coming up -- H2D + one chunk instead of `world` uploads one after the other from pageable memory
+        // (8 x 53 ms at C3-size: more than the sharded build itself).
+        {
+            MultiRank<idx_t>& root = *ranks[0];
+            if (int e = set_device(root.dev)) return e;
+            for (int r = 1; r < world; ++r) Backend::enable_peer(root.dev, ranks[r]->dev);
+            std::vector<decltype(Backend::stream)> fan((size_t)world, nullptr);
+            struct FanGuard { std::vector<decltype(Backend::stream)>& f; ~FanGuard() { for (auto s : f) Backend::destroy_stream(s); } } fan_guard{fan};
+            for (int r = 1; r < world; ++r) fan[r] = Backend::create_stream();
+#ifdef CAPS_EMUL
+            const uint64_t chunk = 1u << 12;                           // small: the CPU tests walk the chunk loop
+#else
+            const uint64_t chunk = 64ull << 20;
+#endif
+            for (uint64_t off = 0; off < n; off += chunk) {
+                const uint64_t len = n - off < chunk ? n - off : chunk;
+                root.be->h2d(root.dT + off, T + off, len);
+                const BackendEvent ev = root.be->record();
+                for (int r = 1; r < world; ++r) {
+                    Backend::stream_wait(fan[r], ev);
+                    Backend::peer_copy_on(fan[r], ranks[r]->dT + off, ranks[r]->dev, root.dT + off, root.dev, len);
+                }
+            }
+            root.be->sync();
+            root.ms_upload = ms(t0, clock::now());
+            for (int r = 1; r < world; ++r) { Backend::sync_stream(fan[r]); ranks[r]->ms_upload = ms(t0, clock::now()); }
+            root.be->release_events();
+        }
+        for (int r = 0; r < world; ++r) {
+            MultiRank<idx_t>& q = *ranks[r];
+            if (int e = set_device(q.dev)) return e;
+            q.sh.reset(new Shard<idx_t>(q.dT, n, p_arg, r, world, q.stream));
+            q.sh->info(&q.info);
         }
         if (ranks[0]->info.direct_fallback != CAPS_SA_FB_NONE) { fallback = (int)ranks[0]->info.direct_fallback; return CAPS_SA_OK; }
         const size_t W = (size_t)ranks[0]->info.n_streams + 2;
@@ -378,7 +421,12 @@ int build_multi(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context,
         auto t2 = t1;
         for (int attempt = 0;; ++attempt) {                       // second attempt: 64-bit keys after a slot overflow under 32
         // ---- level A on every device; the reports; the plan (identical on all ranks)
-        for_each_rank(ranks, [&](MultiRank<idx_t>& q) { q.sh->scatter(q.send_k, q.send_s, q.report); });
+        for_each_rank(ranks, [&](MultiRank<idx_t>& q) {
+            const auto a = clock::now();
+            q.sh->scatter(q.send_k, q.send_s, q.report);
+            q.be->sync();
+            q.ms_build += ms(a, clock::now());
+        });
         std::vector<uint64_t> all(W * world);
         for (int r = 0; r < world; ++r) {
             if (int e = set_device(ranks[r]->dev)) return e;
@@ -416,7 +464,10 @@ int build_multi(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context,
         t2 = clock::now();
         // ---- level B + tile sort of the owned groups; boundary LCPs between the slices
         for_each_rank(ranks, [&](MultiRank<idx_t>& q) {
+            const auto a = clock::now();
             q.sort_code = exchange ? q.sh->sort_owned(q.recv_k, q.recv_s, q.dSA, q.dLCP) : q.sh->sort_owned(q.send_k, q.send_s, q.dSA, q.dLCP);
+            q.be->sync();
+            q.ms_build += ms(a, clock::now());
         });
         int worst = 0;
         for (auto& q : ranks) worst = q->sort_code > worst ? q->sort_code : worst;
@@ -440,14 +491,16 @@ int build_multi(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context,
             covered += q->info.recv_total;
         }
         if (covered != n) throw std::runtime_error("the ranks' slices do not cover the suffix array");
+        // (every device on a host thread and a stream of its own: the slices leave over all the devices' PCIe links at once)
         for_each_rank(ranks, [&](MultiRank<idx_t>& q) {
+            const auto a = clock::now();
             q.be->d2h(SA + q.info.slice_off, q.dSA, q.info.recv_total * sizeof(idx_t));
             q.be->d2h(LCP + q.info.slice_off, q.dLCP, q.info.recv_total * sizeof(idx_t));
             q.be->sync();
+            q.ms_download = ms(a, clock::now());
         });
         const auto t4 = clock::now();
         if (stats) {
-            auto ms = [](clock::time_point a, clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
             *stats = caps_sa_stats();
             stats->n = n;
             stats->idx_bytes = sizeof(idx_t);
@@ -463,6 +516,17 @@ int build_multi(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context,
             stats->ms_d2h = ms(t3, t4);
             stats->ms_total = ms(t1, t3);
             for (auto& q : ranks) { stats->slot_splits += q->info.slot_splits; stats->slot_splits_redone += q->info.slot_splits_redone; }
+            stats->n_devices = (uint32_t)world;
+            stats->result_waves = 1;
+            stats->ms_upload_min = stats->ms_device_build_min = stats->ms_download_min = 1e300;
+            for (auto& q : ranks) {
+                stats->ms_upload_max = std::max(stats->ms_upload_max, q->ms_upload);
+                stats->ms_upload_min = std::min(stats->ms_upload_min, q->ms_upload);
+                stats->ms_device_build_max = std::max(stats->ms_device_build_max, q->ms_build);
+                stats->ms_device_build_min = std::min(stats->ms_device_build_min, q->ms_build);
+                stats->ms_download_max = std::max(stats->ms_download_max, q->ms_download);
+                stats->ms_download_min = std::min(stats->ms_download_min, q->ms_download);
+            }
         }
         return CAPS_SA_OK;
     });
@@ -988,5 +1052,17 @@ extern "C" __attribute__((visibility("default"))) int caps_sa_hip_phase_clock(ui
     for (int i = 0; i < 32; ++i) out32[i] = h[i];
     for (int i = 0; i < 32; ++i) h[i] = 0;
     return hipMemcpyToSymbol(HIP_SYMBOL(caps::caps_phase_clock), h, sizeof(h)) == hipSuccess ? 0 : -1;
+}
+#endif
+
+#if defined(CAPS_EQ_CHECK) && !defined(CAPS_EMUL)
+// debugging builds only (kernels.h EQ_OK): copies the 64 check counters out and clears them
+extern "C" __attribute__((visibility("default"))) int caps_sa_hip_eq_check(uint32_t* out64)
+{
+    unsigned int h[64];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(caps::caps_eq_check), sizeof(h)) != hipSuccess) return -1;
+    for (int i = 0; i < 64; ++i) out64[i] = h[i];
+    for (int i = 0; i < 64; ++i) h[i] = 0;
+    return hipMemcpyToSymbol(HIP_SYMBOL(caps::caps_eq_check), h, sizeof(h)) == hipSuccess ? 0 : -1;
 }
 #endif

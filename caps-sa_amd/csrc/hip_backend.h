@@ -101,6 +101,33 @@ public:
         if (bytes) CAPS_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s));
     }
     static void sync_stream(hipStream_t s) { CAPS_HIP(hipStreamSynchronize(s)); }
+    // the same on any stream of the SOURCE device (build_multi's fan-out of the text: one stream per destination, so the copies
+    // to different peers run side by side, each over its own xGMI link)
+    static void peer_copy_on(hipStream_t s, void* dst, int dst_dev, const void* src, int src_dev, size_t bytes)
+    {
+        if (!bytes) return;
+        if (dst_dev == src_dev) CAPS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s));
+        else CAPS_HIP(hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, s));
+    }
+    static void h2d_on(hipStream_t s, void* d, const void* h, size_t bytes)
+    {
+        if (bytes) CAPS_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, s));
+    }
+    // direct loads / stores and SDMA copies between two devices of one process (xGMI): enabled once per ordered pair; a pair
+    // without peer access keeps working (the runtime stages such copies through the host)
+    static void enable_peer(int dev, int peer)
+    {
+        if (dev == peer) return;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, dev, peer) != hipSuccess || !can) { (void)hipGetLastError(); return; }
+        int prev = -1;
+        if (hipGetDevice(&prev) != hipSuccess) return;
+        if (hipSetDevice(dev) == hipSuccess) {
+            const hipError_t e = hipDeviceEnablePeerAccess(peer, 0);
+            if (e != hipSuccess) (void)hipGetLastError();               // (already enabled: fine)
+        }
+        (void)hipSetDevice(prev);
+    }
     void peer_copy(void* dst, int dst_dev, const void* src, int src_dev, size_t bytes)
     {
         if (!bytes) return;

@@ -47,6 +47,17 @@ static inline uint32_t caps_emul_phase_start() { static uint32_t c = 12345u; c =
 #else
 #define PAR(tid) for (uint32_t tid = 0; tid < kctx_.block_dim; ++tid)
 #endif
+// PAR_FRESH_SET / PAR_SAME (see the product side below): a region that shares the thread index of a group must come behind the
+// region that took it -- here a flag per kernel invocation says so, and a PAR_SAME that runs before any PAR_FRESH_SET aborts
+// (on the GPU it would run all threads as thread 0).
+static inline bool caps_par_same_ok_(bool set, const char* file, int line)
+{
+    if (!set) { std::fprintf(stderr, "%s:%d: PAR_SAME before its PAR_FRESH_SET\n", file, line); std::abort(); }
+    return true;
+}
+#define PAR_TID_DECL bool caps_par_set_ = false
+#define PAR_FRESH_SET(tid) if ((caps_par_set_ = true)) PAR(tid)
+#define PAR_SAME_G(g, tid) if (caps_par_same_ok_(caps_par_set_, __FILE__, __LINE__)) PAR(tid)
 #define SYNC() ((void)0)
 #define SYNC_LDS() ((void)0)
 #define SHARED_ARRAY(type, name, count) std::vector<type> name##_vec_(count); type* name = name##_vec_.data()
@@ -95,6 +106,74 @@ static inline uint32_t caps_bswap32(uint32_t x) { return __builtin_bswap32(x); }
 // (scatters, tile_sort_kernel) lose 2-7 % to it.
 static __device__ __forceinline__ uint32_t caps_tid_fresh() { uint32_t t = threadIdx.x; asm volatile("" : "+v"(t)); return t; }
 #define PAR_FRESH(tid) for (uint32_t tid = caps_tid_fresh(), par_once_ = 1; par_once_; par_once_ = 0)
+// ... and a middle way (-DCAPS_PAR_GROUPS; off in the product build, see DESIGN "the reverted fault"): PAR_FRESH_SET starts a group
+// of regions, PAR_SAME regions behind it share its index (what they derive from it may stay in registers across the group, not
+// across the kernel).  PAR_TID_DECL: once at the head of the kernel.  Without the switch both are PAR.
+// CAPS_PAR_GROUPS is a mask of the groups that share (1: equalisation, 2: tie rounds, 4: pick-up + placement); PAR_SAME_G(g, tid).
+#ifdef CAPS_PAR_GROUPS
+#define PAR_TID_DECL uint32_t caps_par_tid_ = 0
+#define PAR_FRESH_SET(tid) for (uint32_t tid = (caps_par_tid_ = caps_tid_fresh()), par_once_ = 1; par_once_; par_once_ = 0)
+#define PAR_SAME_ON_(tid) for (uint32_t tid = caps_par_tid_, par_once_ = 1; par_once_; par_once_ = 0)
+#if (CAPS_PAR_GROUPS) & 1
+#define PAR_SAME_1(tid) PAR_SAME_ON_(tid)
+#else
+#define PAR_SAME_1(tid) PAR(tid)
+#endif
+#if (CAPS_PAR_GROUPS) & (1 | 8)
+#define PAR_SAME_1a(tid) PAR_SAME_ON_(tid)
+#else
+#define PAR_SAME_1a(tid) PAR(tid)
+#endif
+#if (CAPS_PAR_GROUPS) & (1 | 16)
+#define PAR_SAME_1b(tid) PAR_SAME_ON_(tid)
+#else
+#define PAR_SAME_1b(tid) PAR(tid)
+#endif
+#if (CAPS_PAR_GROUPS) & (1 | 32)
+#define PAR_SAME_1c(tid) PAR_SAME_ON_(tid)
+#else
+#define PAR_SAME_1c(tid) PAR(tid)
+#endif
+#if (CAPS_PAR_GROUPS) & (1 | 64)
+#define PAR_SAME_1d(tid) PAR_SAME_ON_(tid)
+#else
+#define PAR_SAME_1d(tid) PAR(tid)
+#endif
+#if (CAPS_PAR_GROUPS) & (1 | 128)
+#define PAR_SAME_1e(tid) PAR_SAME_ON_(tid)
+#else
+#define PAR_SAME_1e(tid) PAR(tid)
+#endif
+#if (CAPS_PAR_GROUPS) & (1 | 256)
+#define PAR_SAME_1f(tid) PAR_SAME_ON_(tid)
+#else
+#define PAR_SAME_1f(tid) PAR(tid)
+#endif
+#if (CAPS_PAR_GROUPS) & 2
+#define PAR_SAME_2(tid) PAR_SAME_ON_(tid)
+#else
+#define PAR_SAME_2(tid) PAR(tid)
+#endif
+#if (CAPS_PAR_GROUPS) & 4
+#define PAR_SAME_4(tid) PAR_SAME_ON_(tid)
+#else
+#define PAR_SAME_4(tid) PAR(tid)
+#endif
+#else
+#define PAR_TID_DECL ((void)0)
+#define PAR_FRESH_SET(tid) PAR(tid)
+#define PAR_SAME_1(tid) PAR(tid)
+#define PAR_SAME_1a(tid) PAR(tid)
+#define PAR_SAME_1b(tid) PAR(tid)
+#define PAR_SAME_1c(tid) PAR(tid)
+#define PAR_SAME_1d(tid) PAR(tid)
+#define PAR_SAME_1e(tid) PAR(tid)
+#define PAR_SAME_1f(tid) PAR(tid)
+#define PAR_SAME_2(tid) PAR(tid)
+#define PAR_SAME_4(tid) PAR(tid)
+#endif
+#define PAR_SAME_G(g, tid) PAR_SAME_##g(tid)
+// (bits 8 .. 256 of CAPS_PAR_GROUPS switch the six regions of group 1 one by one: PAR_SAME_G(1a .. 1f, tid))
 #define SYNC() __syncthreads()
 // Barrier that orders LDS traffic only: s_waitcnt lgkmcnt(0) + s_barrier.  __syncthreads() also drains the wave's
 // outstanding global stores and returning atomics (vmcnt); where nothing that went to global memory is handed to another

@@ -799,6 +799,18 @@ __device__ unsigned long long caps_phase_clock[32];
 #define PHASE_MARK(i) ((void)0)
 #endif
 
+// Debugging only (make variant VARIANT_DEFS=-DCAPS_EQ_CHECK): every index tile_sort_eq_kernel derives from data it was handed (queue
+// entries, tile records, slots, bins, suffix positions) is range-checked; a failed check is counted in caps_eq_check[id] (read
+// out through caps_sa_hip_eq_check()) and the access is skipped or clamped instead of made -- so a wild index shows up as a
+// number rather than as a memory access fault.  Never in the product build.
+#if defined(CAPS_EQ_CHECK) && !defined(CAPS_EMUL)
+__device__ unsigned int caps_eq_check[64];
+#define EQ_OK(ok, id) ((ok) ? true : (atomicAdd(&caps_eq_check[id], 1u), false))
+#else
+#define EQ_OK(ok, id) (true)
+#endif
+#define EQ_CHK(ok, id) ((void)EQ_OK((ok), (id)))
+
 // Shared pieces of the two tile sort kernels (macros: they use the kernels' TL registers).
 #define TILE_SORT_PROLOGUE                                                                                      \
     const uint32_t b = K_BLOCK_IDX;                                                                             \
@@ -1122,6 +1134,10 @@ DEV_INLINE uint64_t eq_emit_lcp(const uint32_t* __restrict__ P, uint64_t n, uint
 {
     if (TEXT) return pair_lcp<BITS, false>(P, n, ka, (uint64_t)a, kb, (uint64_t)b);
     const uint64_t x = ka ^ kb;
+#ifdef CAPS_EMUL
+    // the invariant the plain build rests on: a lost note would make this return the capped KCH silently
+    if (x == 0) { std::fprintf(stderr, "eq_emit_lcp: neighbours %llu, %llu with equal keys and no lcp from the tie phases\n", (unsigned long long)a, (unsigned long long)b); std::abort(); }
+#endif
     return lcp_capped<idx_t>(x ? (uint32_t)caps_clz64(x) / BITS : TextTraits<BITS>::KCH, n, a, b);
 }
 
@@ -1207,26 +1223,32 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
     // redo == nullptr (PERSIST = false only): every tile is this kernel's and the grid is the tile count -- no queue to read (one
     // dependent round trip to memory less at the head of every tile)
     const uint32_t n_redo = redo ? redo[0] : K_GRID_DIM;
+    PAR_TID_DECL;
     // (fetching the queue entry and the record of the NEXT tile while this one is sorted was tried: no gain, and the record's
     // registers, held across the whole tile, went to scratch)
     uint32_t qi = K_BLOCK_IDX;
     if (qi >= n_redo) return;
     do {
     const uint32_t b = redo ? redo[1 + qi] : qi;
+    if (!EQ_OK(b < sd.tile_off[sd.G], 0)) return;
     const TileInfo t = tile_info(sd, b);
     const uint32_t g = t.g;
     const uint64_t start = t.s0 + (uint64_t)t.tl * TILE_E;
+    if (!EQ_OK(g < sd.G && t.s0 <= start && start < t.s1, 1)) return;
     const uint32_t cnt = (uint32_t)(t.s1 - start < TILE_E ? t.s1 - start : TILE_E);
     const bool with_lcp = lcp_mode != 0 && (t.s1 - t.s0) <= TILE_E;
     const bool direct = with_lcp && fin.sa != nullptr;
     const uint64_t in0 = slot_cap ? (uint64_t)g * slot_cap : start;
     PHASE_T0();
     TILE_SORT_LOAD
+#if defined(CAPS_EQ_CHECK) && !defined(CAPS_EMUL)
+    PAR(tid) { for (uint32_t k = 0; k < TILE_EPT; ++k) if (tid + k * TILE_NT < cnt) EQ_CHK((uint64_t)TL(rs, tid, k) < n || n == 0, 2); }
+#endif
     TILE_SORT_RANGE
     PHASE_MARK(8);                                             // load
     bool fast = cnt > EQ_BIN_LIMIT && tb.range > 0 && tb.B == TILE_BINS;
     if (fast) {
-        PAR(tid) {
+        PAR_FRESH_SET(tid) {
             UNROLL
             for (uint32_t k = 0; k < TILE_EPT; ++k) {
                 const uint32_t e = tid + k * TILE_NT;
@@ -1241,25 +1263,26 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
         const float Kf = (float)TILE_BINS / (float)cnt;
         for (uint32_t round = 0; round < EQ_ROUNDS; ++round) {
             if (round) {
-                PAR(tid) { for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0; }
+                PAR_SAME_G(1a, tid) { for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0; }
                 TILE_SYNC();
             }
-            PAR(tid) {
+            PAR_SAME_G(1b, tid) {
                 UNROLL
                 for (uint32_t k = 0; k < TILE_EPT; ++k) {
                     const uint32_t e = tid + k * TILE_NT;
-                    if (e < cnt) FETCH_ADD_U32(&hist[TL(rb, tid, k) >> EQ_FRAC_BITS], 1u);
+                    if (e < cnt && EQ_OK((TL(rb, tid, k) >> EQ_FRAC_BITS) < TILE_BINS, 3)) FETCH_ADD_U32(&hist[TL(rb, tid, k) >> EQ_FRAC_BITS], 1u);
                 }
             }
             TILE_SYNC();
             block_exclusive_scan_bins(KCTX_PASS hist);
-            PAR(tid) {
+            PAR_SAME_G(1c, tid) {
                 UNROLL
                 for (uint32_t k = 0; k < TILE_EPT; ++k) {
                     const uint32_t e = tid + k * TILE_NT;
                     if (e < cnt) {
                         const uint32_t x = TL(rb, tid, k);
                         const uint32_t bn = x >> EQ_FRAC_BITS, fr = x & ((1u << EQ_FRAC_BITS) - 1u);
+                        EQ_CHK(bn < TILE_BINS, 4);
                         const uint32_t before = hist[bn], here = hist[bn + 1] - before;
                         const uint32_t E = (before << EQ_FRAC_BITS) + here * fr;                          // < cnt * 2^13 <= 2^25 (+ 2^25)
                         const uint32_t y = (uint32_t)((float)E * Kf);                                     // ~ E * TILE_BINS / cnt
@@ -1270,19 +1293,20 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
             TILE_SYNC();
         }
         PHASE_MARK(9);                                         // equalisation rounds
-        PAR(tid) {
+        PAR_SAME_G(1d, tid) {
             for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0;
             if (tid < 8) pcnt[tid] = 0;
             if (tid == 0) flag[1] = 0;
             for (uint32_t i = tid; i < BIG_CAP; i += K_BLOCK_DIM) { bmore[i] = 0; bbest[i] = 0; }
         }
         TILE_SYNC();
-        PAR(tid) {
+        PAR_SAME_G(1e, tid) {
             UNROLL
             for (uint32_t k = 0; k < TILE_EPT; ++k) {
                 const uint32_t e = tid + k * TILE_NT;
                 if (e < cnt) {
                     const uint32_t bin = TL(rb, tid, k) >> EQ_FRAC_BITS;
+                    EQ_CHK(bin < TILE_BINS, 5);
                     const uint32_t r = FETCH_ADD_U32(&hist[bin], 1u);
                     if (r >= EQ_BIN_LIMIT) flag[0] = 1;
                     TL(rb, tid, k) = bin;
@@ -1297,12 +1321,13 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
     if (fast) {                                                // from here on: as in tile_sort_kernel
         block_exclusive_scan_bins(KCTX_PASS hist);
         PHASE_MARK(11);                                        // scan
-        PAR(tid) {
+        PAR_SAME_G(1f, tid) {
             UNROLL
             for (uint32_t k = 0; k < TILE_EPT; ++k) {
                 const uint32_t e = tid + k * TILE_NT;
                 if (e < cnt) {
                     const uint32_t slot = hist[TL(rb, tid, k)] + TL(rd, tid, k);
+                    if (!EQ_OK(slot < cnt, 6)) continue;
                     skey[slot] = TL(rk, tid, k);
                     ssa[slot] = TL(rs, tid, k);
                     if (SLOT_ORDER) sbin[slot] = (uint16_t)TL(rb, tid, k);
@@ -1343,7 +1368,9 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                     // (64-bit indices: no room in LDS for sbin; every thread stays with the elements it loaded)
                     const uint32_t slot = SLOT_ORDER ? e : TL(rd, tid, k), bin = SLOT_ORDER ? (uint32_t)sbin[slot] : TL(rb, tid, k);
                     TL(rd, tid, k) = slot;
+                    EQ_CHK(bin < TILE_BINS && slot < cnt, 7);
                     const uint32_t bs = hist[bin], be = hist[bin + 1];
+                    EQ_CHK(bs <= slot && slot < be && be <= cnt && be - bs <= EQ_BIN_LIMIT, 8);
                     const uint64_t key = skey[slot];
                     uint32_t less = 0, ties = 0, tj = 0;
                     for (uint32_t j = bs; j < be; ++j) {
@@ -1391,6 +1418,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                     const uint32_t i = base + (tid >> lg);
                     if (i < nb) {
                         const uint32_t ent = big[i], slot = ent & 0xFFFu, bs = (ent >> 12) & 0xFFFu, be = bs + (ent >> 24) + 1u;
+                        EQ_CHK(slot < cnt && be <= cnt, 9);
                         const uint64_t key = skey[slot];
                         const uint64_t sa = (uint64_t)ssa[slot];
                         uint32_t more = 0, best = 0;
@@ -1420,7 +1448,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                     const uint32_t n_ent = round ? (pcnt[2] < TIE_DEEP_CAP ? pcnt[2] : TIE_DEEP_CAP) : np + nm;
                     if (round && pcnt[2] > TIE_DEEP_CAP) { PAR(tid) { if (tid == 0) flag[0] = 1; } }
                     for (uint32_t base = 0; base < n_ent; base += TILE_NT / G) {
-                        PAR(tid) {
+                        PAR_FRESH_SET(tid) {
                             const uint32_t vi = base + tid / G, W = W0 + tid % G;
                             TL(twa, tid, 0) = 0;
                             TL(twb, tid, 0) = 0;
@@ -1436,7 +1464,9 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                                 // emulation, tests/test_emul_pipeline.py, found it)
                                 const uint32_t tb = ent >> 24;
                                 if (tb == 0xFFu || (tb >= W0 && tb < W0 + G)) {
+                                    EQ_CHK((ent & 0xFFFu) < cnt && ((ent >> 12) & 0xFFFu) < cnt, 10);
                                     const uint64_t a = (uint64_t)ssa[ent & 0xFFFu], b2 = (uint64_t)ssa[(ent >> 12) & 0xFFFu];
+                                    EQ_CHK(a < n && b2 < n, 11);
                                     const uint64_t maxlen = a < n && b2 < n ? n - (a > b2 ? a : b2) : 0;   // corrupt index: settle at once
                                     const uint64_t l = (uint64_t)KCH_ * (1u + W);
                                     bool hit = l >= maxlen;               // the shorter suffix ends before this window
@@ -1451,7 +1481,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                             }
                         }
                         TILE_SYNC();
-                        PAR(tid) {
+                        PAR_SAME_G(2, tid) {
                             const uint32_t W = W0 + tid % G, tp = TL(tpi, tid, 0);
                             if (tp != ~0u) {
                                 const uint32_t pi = tp & 0xFFFFu, vj = (tp >> 16) & 0x7FFFu;
@@ -1553,7 +1583,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
         }
         TILE_SYNC();
         PHASE_MARK(17);                                        // T: the listed ties
-        PAR(tid) {
+        PAR_FRESH_SET(tid) {
             UNROLL
             for (uint32_t k = 0; k < TILE_EPT; ++k) {
                 const uint32_t e = tid + k * TILE_NT;
@@ -1589,6 +1619,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                     TL(rk, tid, k) = skey[slot];                           // picked up for the final placement (behind the barrier)
                     TL(rs, tid, k) = ssa[slot];
                     TL(rd, tid, k) = bs + (((info & 0xFFu) + more) & 0xFFu);
+                    EQ_CHK(slot < cnt, 12);
                 }
             }
         }
@@ -1596,12 +1627,13 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
         fast = flag[0] == 0 && flag[1] == 0;
         PHASE_MARK(13);                                        // rank inside the bin
         if (fast) {
-            PAR(tid) {
+            PAR_SAME_G(4, tid) {
                 UNROLL
                 for (uint32_t k = 0; k < TILE_EPT; ++k) {
                     const uint32_t e = tid + k * TILE_NT;
                     if (e < cnt) {
                         const uint32_t d = TL(rd, tid, k);
+                        if (!EQ_OK(d < cnt, 13)) continue;
                         skey[d] = TL(rk, tid, k);
                         ssa[d] = TL(rs, tid, k);
                         // = slcp: the lcp with the predecessor, where a tie settled it (the few beyond 15 bits: in vslot / vlcp)

@@ -888,6 +888,17 @@ inline int direct_shape(uint64_t n, uint32_t p, uint64_t m, uint32_t* PG, uint32
 }
 
 
+// Tests only: CAPS_SA_TEST_STREAM_CAP=<per cent> shrinks the regions of level A's streams to that share of the MEAN stream size,
+// so that a stream outgrows its region on any text and the build must take the CAPS_SA_FB_GROUP_OVERFLOW way out (a real text
+// gets there through one key that holds several per cent of it; the regions are 1.33 x the expected sizes otherwise).
+inline uint64_t test_stream_cap(uint64_t cap, uint64_t n_elems, uint64_t n_streams)
+{
+    const char* e = std::getenv("CAPS_SA_TEST_STREAM_CAP");
+    if (!e || std::atof(e) <= 0.0 || n_streams == 0) return cap;
+    const uint64_t c = (uint64_t)((double)n_elems / (double)n_streams * std::atof(e) / 100.0) + 2;
+    return c < cap ? c & ~1ull : cap;
+}
+
 // Consumer of finished slices of the result (capi_impl.h build_host: copies them to the caller's arrays on a second stream while
 // the next groups are still being sorted).  Called on the host when everything that produces SA / LCP[base, base + cnt) has been
 // enqueued on the build's stream.
@@ -960,6 +971,7 @@ private:
     ElemBuf<idx_t> wave_scratch_;
     uint64_t wave_scratch_elems_ = 0;
     bool sink_served_ = false;
+    uint32_t waves_used_ = 1;
     KernelClock merge_clock_;
     KernelClock tile_clock_;
     KernelClock scatter_clock_;
@@ -1218,6 +1230,7 @@ private:
         uint64_t capA = A.region_bytes / ((sizeof(uint64_t) + sizeof(idx_t)) * (uint64_t)n_streams);
         const uint64_t idx_max = (uint64_t)std::numeric_limits<idx_t>::max() - TILE_E;
         if (capA > idx_max / n_streams) capA = idx_max / n_streams;     // region offsets are idx_t in the scatter
+        capA = test_stream_cap(capA, n, n_streams);
         uint64_t* a_key = A.key;
 
         const char* mode_env = std::getenv("CAPS_SA_DIRECT_MODE");
@@ -1420,6 +1433,7 @@ private:
             base += elems_w;
         }
         sink_served_ = sink_ != nullptr;
+        waves_used_ = W;
         e6_ = be_.record();
         e7_ = be_.record();
         return true;
@@ -1501,6 +1515,8 @@ private:
             st->direct_groups = direct_groups_;
             st->direct_quantile = direct_quantile_;
             st->run_buckets = run_buckets_;
+            st->result_waves = sink_served_ ? waves_used_ : 1u;
+            st->n_devices = 1;
             st->direct_key_bits = path_direct_ && direct_k32_ ? 32u : 64u;
             st->direct_max_group = direct_max_group_;
             st->level_a_ms = direct_groups_ ? be_.elapsed_ms(la0_, la1_) : 0.0;

@@ -99,6 +99,7 @@ public:
             const double mean = (double)n / ((double)n_streams_ * tw);
             capA_ = (uint64_t)(mean * 1.10 + 6.0 * std::sqrt(mean) + 2.0 * GA_E / K1_ + 64.0);
             capA_ += capA_ & 1;
+            capA_ = test_stream_cap(capA_, n, (uint64_t)n_streams_ * tw);
             if (n_streams_ * capA_ / (local_ ? world : 1) + TILE_E >= (uint64_t)std::numeric_limits<idx_t>::max()) direct_fb_ = CAPS_SA_FB_SHAPE;
             // quantile mode (pipeline.h Builder::run_direct): NB buckets of BUCKET_Q suffixes, KPG per group, QUANTILE_SPB samples each
             const uint64_t NBt = (n + BUCKET_Q - 1) / BUCKET_Q;

@@ -370,70 +370,80 @@ def bench_main(args, rank: int, local_rank: int, world: int):
     share = allr[:, -1]
     if int(share.sum().item()) != n:
         raise SystemExit(f"the ranks' slices hold {int(share.sum().item())} suffixes, the text has {n}")
+    # rank 0 assembles the line; whatever happens there, EVERY rank reaches the barrier and leaves the process group (an
+    # exception in this block used to leave the other ranks in the barrier, and the CPU baseline -- minutes at --cpu-full sizes --
+    # ran while they waited inside a collective with a time-out).  The baseline is timed after the group is gone.
+    out, failure = None, None
     if rank == 0:
-        info = infos[-1]
-        direct = all(i["path"] == "direct" for i in infos)
-        mine = info["recv_total"]
-        roof = None
-        if not direct:    # samplesort sequence: each phase is two streaming passes (bucket scatter + tile sort) over the rank's share
-            k = len(infos)
-            roof = roofline({"phase1_sort_subarrays": (sum(i["ms_phase1"] for i in infos) / 2, k, sum(i["local_elems"] for i in infos)),
-                             "phase2_sort_partitions": (sum(i["ms_phase2"] for i in infos) / 2, k, sum(i["recv_total"] for i in infos))}, w, "")
-            if roof:
-                roof["scope"] = (f"rank 0 of {world}, samplesort sequence: a phase is two streaming passes (bucket scatter + tile sort) over the "
-                                 "rank's share; avg_launch_ms = half the phase")
-        if direct:        # rank 0's kernels over ITS share of the suffixes, same convention as at N = 1
-            k = len(infos)
-            roof = roofline({"level_a_scatter": (sum(i["ms_level_a"] for i in infos), k, sum(i["level_a_elems"] for i in infos)),
-                             "level_b_scatter": (sum(i["ms_level_b"] for i in infos), k, sum(i["recv_total"] for i in infos)),
-                             "tile_sort_kernel": (sum(i["ms_tile_sort"] for i in infos), k, sum(i["recv_total"] for i in infos)),
-                             "merge_pass_kernel": (sum(i["ms_merge_passes"] for i in infos), k if info["ms_merge_passes"] > 0 else 0,
-                                                   sum(i["recv_total"] for i in infos))}, w, "")
-            if roof:
-                roof["scope"] = f"rank 0 of {world}: its kernels over its {mine} suffixes"
-        ms_x = sum(i["ms_exchange"] for i in infos) / len(infos)
-        sent = info["exchange_elems_sent"] * ((info.get("key_bytes", 8) if direct else 8) + w)
-        keys = ("ms_scatter", "ms_exchange", "ms_sort") if direct else ("ms_phase1", "ms_pivots", "ms_collate", "ms_exchange", "ms_phase2")
-        out = {
-            "metric": "suffixes/sec (SA+LCP build)", "value": n / (elapsed / args.steps), "unit": "suffixes/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": prewarm_steps, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": f"u{idx_bits}",
-            "data": "synthetic",
-            "config": {"workload": desc, "n": n, "subproblems": info["p"], "bits_per_char": info["bits_per_char"],
-                       "construction": ("direct, no exchange (same pivots on every rank; every rank scatters the whole replicated text "
-                                        "into groups and keeps the ones it owns; per-group sort)" if direct and not info.get("exchange", 1)
-                                        else "direct (same pivots on every rank, one scatter of every world-th tile into groups, ONE "
-                                        "all-to-all of (key, sa), per-group sort)" if direct
-                                        else f"samplesort (fallback reason {info.get('direct_fallback')})"),
-                       "groups": info["direct_groups"], "streams_per_group": info["direct_sub"],
-                       "workspace": "preallocated",
-                       "parallelism": (f"{world} GPUs, one process each: text replicated, groups of partitions (slices of the suffix "
-                                       "array) sharded; no data-path collective, only the ranks' reports, the agreement and the "
-                                       "boundary LCPs cross RCCL" if direct and not info.get("exchange", 1) else
-                                       f"{world} GPUs, one process each: text replicated, tiles of the text and groups of partitions "
-                                       "sharded, one RCCL all-to-all over xGMI")},
-            "rank0_ms": {k_: info[k_] for k_ in keys},
-            "ranks_ms": ranks_ms,
-            "suffixes_per_rank": {"max": int(share.max().item()), "min": int(share.min().item())},
-            "shard_mode": "exchange" if info.get("exchange") else "local",
-            "exchange": {"ms": ms_x, "bytes_sent_per_rank": sent, "GBps_per_rank": (sent / 1e9) / (ms_x * 1e-3) if ms_x > 0 and sent else None,
-                         "key_bytes": info.get("key_bytes", 8) if direct else 8, "key_retries": sum(i.get("key_retry", 0) for i in infos),
-                         "note": ("no data-path collective: every rank scatters the whole (replicated) text and keeps the groups it owns"
-                                  if direct and not info.get("exchange", 1) else
-                                  "keys and indices in two all-to-all calls; region gaps (10 %) travel too; 32-bit keys on 2-bit texts")},
-            "rank0_host_profile_ms": info.get("host_profile_ms"),
-            "roofline": roof,
-            "verify_errors": errs,
-            "cpu_baseline": None,
-        }
-        if calib:
-            out["shard_mode_calibration_ms"] = calib
-        if not args.no_cpu_baseline:          # rank 0 times the CPU baseline at every world size; the other ranks wait at the barrier below
-            out["cpu_baseline"] = cpu_baseline(T, min(args.cpu_sample, n), args.p, n)
-        print(json.dumps(out))
+        try:
+            info = infos[-1]
+            direct = all(i["path"] == "direct" for i in infos)
+            mine = info["recv_total"]
+            roof = None
+            if not direct:    # samplesort sequence: each phase is two streaming passes (bucket scatter + tile sort) over the rank's share
+                k = len(infos)
+                roof = roofline({"phase1_sort_subarrays": (sum(i["ms_phase1"] for i in infos) / 2, k, sum(i["local_elems"] for i in infos)),
+                                 "phase2_sort_partitions": (sum(i["ms_phase2"] for i in infos) / 2, k, sum(i["recv_total"] for i in infos))}, w, "")
+                if roof:
+                    roof["scope"] = (f"rank 0 of {world}, samplesort sequence: a phase is two streaming passes (bucket scatter + tile sort) over the "
+                                     "rank's share; avg_launch_ms = half the phase")
+            if direct:        # rank 0's kernels over ITS share of the suffixes, same convention as at N = 1
+                k = len(infos)
+                roof = roofline({"level_a_scatter": (sum(i["ms_level_a"] for i in infos), k, sum(i["level_a_elems"] for i in infos)),
+                                 "level_b_scatter": (sum(i["ms_level_b"] for i in infos), k, sum(i["recv_total"] for i in infos)),
+                                 "tile_sort_kernel": (sum(i["ms_tile_sort"] for i in infos), k, sum(i["recv_total"] for i in infos)),
+                                 "merge_pass_kernel": (sum(i["ms_merge_passes"] for i in infos), k if info["ms_merge_passes"] > 0 else 0,
+                                                       sum(i["recv_total"] for i in infos))}, w, "")
+                if roof:
+                    roof["scope"] = f"rank 0 of {world}: its kernels over its {mine} suffixes"
+            ms_x = sum(i["ms_exchange"] for i in infos) / len(infos)
+            sent = info["exchange_elems_sent"] * ((info.get("key_bytes", 8) if direct else 8) + w)
+            keys = ("ms_scatter", "ms_exchange", "ms_sort") if direct else ("ms_phase1", "ms_pivots", "ms_collate", "ms_exchange", "ms_phase2")
+            out = {
+                "metric": "suffixes/sec (SA+LCP build)", "value": n / (elapsed / args.steps), "unit": "suffixes/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "prewarm_steps": prewarm_steps, "ms_per_step": 1e3 * elapsed / args.steps,
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": f"u{idx_bits}",
+                "data": "synthetic",
+                "config": {"workload": desc, "n": n, "subproblems": info["p"], "bits_per_char": info["bits_per_char"],
+                           "construction": ("direct, no exchange (same pivots on every rank; every rank scatters the whole replicated text "
+                                            "into groups and keeps the ones it owns; per-group sort)" if direct and not info.get("exchange", 1)
+                                            else "direct (same pivots on every rank, one scatter of every world-th tile into groups, ONE "
+                                            "all-to-all of (key, sa), per-group sort)" if direct
+                                            else f"samplesort (fallback reason {info.get('direct_fallback')})"),
+                           "groups": info["direct_groups"], "streams_per_group": info["direct_sub"],
+                           "workspace": "preallocated",
+                           "parallelism": (f"{world} GPUs, one process each: text replicated, groups of partitions (slices of the suffix "
+                                           "array) sharded; no data-path collective, only the ranks' reports, the agreement and the "
+                                           "boundary LCPs cross RCCL" if direct and not info.get("exchange", 1) else
+                                           f"{world} GPUs, one process each: text replicated, tiles of the text and groups of partitions "
+                                           "sharded, one RCCL all-to-all over xGMI")},
+                "rank0_ms": {k_: info[k_] for k_ in keys},
+                "ranks_ms": ranks_ms,
+                "suffixes_per_rank": {"max": int(share.max().item()), "min": int(share.min().item())},
+                "shard_mode": "exchange" if info.get("exchange") else "local",
+                "exchange": {"ms": ms_x, "bytes_sent_per_rank": sent, "GBps_per_rank": (sent / 1e9) / (ms_x * 1e-3) if ms_x > 0 and sent else None,
+                             "key_bytes": info.get("key_bytes", 8) if direct else 8, "key_retries": sum(i.get("key_retry", 0) for i in infos),
+                             "note": ("no data-path collective: every rank scatters the whole (replicated) text and keeps the groups it owns"
+                                      if direct and not info.get("exchange", 1) else
+                                      "keys and indices in two all-to-all calls; region gaps (10 %) travel too; 32-bit keys on 2-bit texts")},
+                "rank0_host_profile_ms": info.get("host_profile_ms"),
+                "roofline": roof,
+                "verify_errors": errs,
+                "cpu_baseline": None,
+            }
+            if calib:
+                out["shard_mode_calibration_ms"] = calib
+        except Exception as e:              # noqa: BLE001 -- reported below, after the other ranks have been released
+            failure = e
     dist.barrier()
     sh.close()
     dist.destroy_process_group()
+    if failure is not None:
+        raise SystemExit(f"rank 0 could not assemble the bench line: {failure!r}")
+    if rank == 0:
+        if not args.no_cpu_baseline:          # rank 0 times the CPU baseline at every world size (the other ranks have left)
+            out["cpu_baseline"] = cpu_baseline(T, min(args.cpu_sample, n), args.p, n)
+        print(json.dumps(out))
     if errs:
         raise SystemExit(f"verify_errors = {errs}")
 

@@ -79,6 +79,13 @@ typedef struct caps_sa_stats {
     uint32_t direct_key_bits;      /* key bits that travelled with every suffix through the direct path's passes: 64, or 32 */
     uint32_t run_buckets;          /* buckets of ONE single-letter key (the suffixes deep inside N-blocks) that were ordered by
                                       (terminator class, rest of the run, text behind it) instead of being compared: csrc/text.h */
+    uint32_t result_waves;         /* host-buffer entry points: slices in which SA / LCP left the device while later groups were still
+                                      being sorted (1: one copy after the build) */
+    uint32_t n_devices;            /* caps_sa_hip_build_multi_*: devices that built (1 elsewhere) */
+    /* caps_sa_hip_build_multi_*: host wall clock of the three stages, the slowest and the fastest device of each (ms) */
+    double ms_upload_max, ms_upload_min;       /* text to the device (page-locked staging, all devices at once) */
+    double ms_device_build_max, ms_device_build_min;   /* level A .. boundary LCPs of the device's slice */
+    double ms_download_max, ms_download_min;   /* the device's slice of SA / LCP to the caller's arrays */
 } caps_sa_stats;
 
 #define CAPS_SA_FB_NONE 0
@@ -134,7 +141,9 @@ int caps_sa_hip_workspace_bytes_ex(uint64_t n, uint64_t subproblem_count, int id
  * T: n bytes, host memory, borrowed.  SA, LCP: n entries each, host memory owned by the
  * caller (the class allocates them in its constructor, src/Suffix_Array.cpp:20-21).
  * subproblem_count 0 -> 8192 (include/Suffix_Array.hpp:42), clamped to n/16 (cpp:24).
- * max_context must be 0 or >= n (unbounded).  device: HIP device ordinal.
+ * max_context 0 or >= n: THE suffix array and LCP array of T.  0 < max_context < n: the reference's bounded-context result
+ * (comparisons stop after max_context chars, ties keep the reference's merge history: csrc/bounded.h; parity unpinned by any
+ * reference-held vector, a compatibility mode that is seconds, not milliseconds).  device: HIP device ordinal.
  */
 int caps_sa_hip_build_u32(const char* T, uint64_t n, uint64_t subproblem_count, uint64_t max_context,
                           uint32_t* SA, uint32_t* LCP, int device, caps_sa_stats* stats);

@@ -59,6 +59,9 @@ public:
     static void d2h_on(void*, void* h, const void* d, size_t bytes) { std::memcpy(h, d, bytes); }
     static void sync_stream(void*) {}
     void peer_copy(void* dst, int, const void* src, int, size_t bytes) { std::memmove(dst, src, bytes); }
+    static void peer_copy_on(void*, void* dst, int, const void* src, int, size_t bytes) { std::memmove(dst, src, bytes); }
+    static void h2d_on(void*, void* d, const void* h, size_t bytes) { std::memcpy(d, h, bytes); }
+    static void enable_peer(int, int) {}
     uint32_t persistent_blocks() { return 3; }     // small on purpose: exercises the tile loop
     void check_launch(const char*) {}
 };

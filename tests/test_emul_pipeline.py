@@ -535,3 +535,79 @@ def test_phases_do_not_depend_on_the_order_of_their_threads(oracle, monkeypatch)
             SAo, LCPo = oracle.build_sa_lcp(T, p=16)
             SA, LCP, st = E.build_multi(T, [0, 0, 0], p=16)
             assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), (small, exchange)
+
+
+def test_a_stream_that_outgrows_its_region_sends_the_build_to_the_samplesort_path(oracle, monkeypatch):
+    """CAPS_SA_FB_GROUP_OVERFLOW (pipeline.h run_direct, shard.h plan()): level A writes every group into a fixed region; a stream
+    that outgrows its region voids the attempt and the samplesort path builds the text.  A real text gets there through one
+    key that holds several per cent of it; CAPS_SA_TEST_STREAM_CAP (regions of 80 % of the mean stream) forces it on any text.
+    One device, and several ranks that must take the way out TOGETHER."""
+    from emul_util import emul_small
+    E = emul_small()
+    rs = np.random.RandomState(23)
+    T = rs.choice(DNA, size=150_000)
+    SAo, LCPo = oracle.build_sa_lcp(T, p=64)
+    assert E.build(T, p=0)[2]["path_direct"] == 1
+    monkeypatch.setenv("CAPS_SA_TEST_STREAM_CAP", "80")
+    for mode in ("linear", "quantile"):
+        monkeypatch.setenv("CAPS_SA_DIRECT_MODE", mode)
+        SA, LCP, st = E.build(T, p=0)
+        assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), mode
+        assert st["path_direct"] == 0 and st["path_fallback"] == 5, (mode, st["path_fallback"])
+    monkeypatch.delenv("CAPS_SA_DIRECT_MODE")
+    for exchange in (None, "1"):
+        if exchange:
+            monkeypatch.setenv("CAPS_SA_SHARD_EXCHANGE", exchange)
+        SA, LCP, st = E.build_multi(T, [0, 0, 0], p=0)
+        assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), exchange
+        assert st["path_direct"] == 0 and st["path_fallback"] == 5, (exchange, st["path_fallback"])
+    monkeypatch.delenv("CAPS_SA_SHARD_EXCHANGE")
+    monkeypatch.delenv("CAPS_SA_TEST_STREAM_CAP")
+    assert E.build(T, p=0)[2]["path_direct"] == 1
+
+
+def test_results_leave_in_waves_on_small_texts(oracle, monkeypatch):
+    """The host-buffer entry point streams finished slices of SA / LCP out while later groups are sorted (capi_impl.h
+    HostCopySink, pipeline.h set_waves): per-wave segment tables, knots offset by the wave's first group, the LCP at every
+    wave's first entry (wave_head_lcp_kernel), work arrays in the scratch + B.  The default only does that from 400 Mi chars on;
+    CAPS_SA_HOST_WAVES forces it here: uniform keys (linear buckets), skewed keys (quantile buckets), N-block stand-ins
+    (letter-run buckets inside a wave), 64-bit indices, and a group larger than the scratch (then: one wave)."""
+    from emul_util import emul_small
+    E = emul_small()
+    rs = np.random.RandomState(31)
+    uni = rs.choice(DNA, size=200_000)
+    skew = _markov(rs, 180_000)
+    runs = rs.choice(DNA, size=300_000)
+    runs[50_000:53_000] = ord("G")
+    runs[200_000:200_700] = ord("G")
+    cases = [("uniform", uni, 32, None), ("skewed", skew, 32, None), ("runs", runs, 32, "1"), ("uniform64", uni[:120_001], 64, None)]
+    for name, T, bits, sub in cases:
+        if sub:
+            monkeypatch.setenv("CAPS_SA_DIRECT_SUB", sub)
+        else:
+            monkeypatch.delenv("CAPS_SA_DIRECT_SUB", raising=False)
+        SAo, LCPo = oracle.build_sa_lcp(T, p=64, idx_bits=bits)
+        for waves in ("2", "3", "5"):
+            monkeypatch.setenv("CAPS_SA_HOST_WAVES", waves)
+            SA, LCP, st = E.build(T, p=0, idx_bits=bits)
+            assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), (name, waves)
+            assert st["path_direct"] == 1 and 2 <= st["result_waves"] <= int(waves) + 1, (name, waves, st["result_waves"])
+        if name == "skewed":
+            assert st["direct_quantile"] == 1
+        if name == "runs":
+            assert st["direct_quantile"] == 1 and st["long_runs"] == 1
+    # one group holds a fifth of the text (a 60,000-char run): more than the scratch of one of twelve waves -> one wave, same result
+    big = rs.choice(DNA, size=300_000)
+    big[100_000:160_000] = ord("G")
+    monkeypatch.setenv("CAPS_SA_DIRECT_SUB", "1")
+    monkeypatch.setenv("CAPS_SA_HOST_WAVES", "12")
+    SA, LCP, st = E.build(big, p=0)
+    SAo, LCPo = oracle.build_sa_lcp(big, p=64)
+    assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo)
+    assert st["path_direct"] == 0 or st["result_waves"] == 1, st["result_waves"]
+    # (the samplesort path streams nothing: one copy after the build)
+    monkeypatch.setenv("CAPS_SA_PATH", "classic")
+    monkeypatch.setenv("CAPS_SA_HOST_WAVES", "4")
+    SA, LCP, st = E.build(uni, p=0)
+    SAo, LCPo = oracle.build_sa_lcp(uni, p=64)
+    assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo) and st["result_waves"] == 1

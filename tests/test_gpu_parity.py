@@ -747,3 +747,71 @@ def test_alphabet_guessed_from_a_sample_is_validated(L, oracle):
     T[:3_000_000] = rs.choice(np.frombuffer(b"AC", dtype=np.uint8), size=3_000_000)       # the sample sees two of the four symbols
     st = _same(L, oracle, T, 300)
     assert st["bits_per_char"] == 2
+
+
+def test_a_stream_that_outgrows_its_region_falls_back_device(L, oracle, monkeypatch):
+    """CAPS_SA_FB_GROUP_OVERFLOW on the real kernels (pipeline.h run_direct: group_scatter_kernel drops what does not fit a
+    region and reports the largest stream; shard.h plan(): every rank takes the samplesort sequence together).
+    CAPS_SA_TEST_STREAM_CAP shrinks the regions to 80 % of the mean stream, so level A overflows on any text."""
+    rs = np.random.RandomState(41)
+    T = rs.choice(DNA, size=6_000_000)
+    SAo, LCPo = oracle.build_sa_lcp(T, p=500)
+    assert L.build(T, p=500)[2]["path_direct"] == 1
+    monkeypatch.setenv("CAPS_SA_TEST_STREAM_CAP", "80")
+    for mode in ("linear", "quantile"):
+        monkeypatch.setenv("CAPS_SA_DIRECT_MODE", mode)
+        SA, LCP, st = L.build(T, p=500)
+        assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), mode
+        assert st["path_direct"] == 0 and st["path_fallback"] == 5, (mode, st["path_fallback"])
+    monkeypatch.delenv("CAPS_SA_DIRECT_MODE")
+    for exchange in (None, "1"):
+        if exchange:
+            monkeypatch.setenv("CAPS_SA_SHARD_EXCHANGE", exchange)
+        SA, LCP, st = L.build_multi(T, [0, 0, 0], p=500)
+        assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), exchange
+        assert st["path_direct"] == 0 and st["path_fallback"] == 5, (exchange, st["path_fallback"])
+
+
+def test_results_leave_in_waves_host_path(L, oracle, monkeypatch):
+    """the wave-streamed host build (capi_impl.h HostCopySink + pipeline.h set_waves) is what every host / CLI build from
+    400 Mi chars on runs; CAPS_SA_HOST_WAVES forces it on texts the oracle checks in seconds.  Real streams here: the copies of
+    a finished slice run on a second stream while the next wave is sorted, into page-locked and into pageable arrays.  Uniform
+    keys (linear buckets), skewed keys (quantile buckets), N-block stand-ins (letter-run buckets inside a wave), 64-bit
+    indices, 8-bit codes, and a group larger than the scratch of one wave (then: one wave)."""
+    import os
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    from genome_like import markov_dna
+    rs = np.random.RandomState(43)
+    uni = rs.choice(DNA, size=6_000_001)
+    skew = markov_dna(5_000_000, seed=17).cpu().numpy()
+    runs = rs.choice(DNA, size=8_000_000)
+    runs[1_000_000:1_060_000] = ord("G")
+    runs[5_000_000:5_009_000] = ord("G")
+    txt = rs.choice(np.frombuffer(b"abcdefghijklmnopqrst", dtype=np.uint8), size=5_000_000, p=np.array([0.75 ** i for i in range(20)]) / sum(0.75 ** i for i in range(20)))
+    cases = [("uniform", uni, 32), ("skewed", skew, 32), ("runs", runs, 32), ("uniform64", uni[:3_000_001], 64), ("text8", txt, 32)]
+    L.release_cache()
+    for name, T, bits in cases:
+        SAo, LCPo = oracle.build_sa_lcp(T, p=1000, idx_bits=bits)
+        for waves, pinned in (("2", True), ("3", False), ("5", True)):
+            monkeypatch.setenv("CAPS_SA_HOST_WAVES", waves)
+            SA, LCP, st = L.build(T, p=1000, idx_bits=bits, pinned=pinned)
+            assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), (name, waves)
+            assert st["path_direct"] == 1 and 2 <= st["result_waves"] <= int(waves) + 1, (name, waves, st["result_waves"])
+        if name in ("skewed", "runs"):
+            assert st["direct_quantile"] == 1, name
+        if name == "runs":
+            assert st["long_runs"] == 1 and st["run_buckets"] >= 1
+        if name == "text8":
+            assert st["bits_per_char"] == 8
+    big = rs.choice(DNA, size=6_000_000)
+    big[2_000_000:3_200_000] = ord("G")                   # one group holds a fifth of the text: more than one of twelve waves' scratch
+    monkeypatch.setenv("CAPS_SA_HOST_WAVES", "12")
+    SA, LCP, st = L.build(big, p=1000)
+    dT = torch.from_numpy(big).cuda()
+    dSA, dLCP = torch.from_numpy(SA.astype(np.int32)).cuda(), torch.from_numpy(LCP.astype(np.int32)).cuda()
+    assert L.verify_device(dT.data_ptr(), big.size, dSA.data_ptr(), dLCP.data_ptr()) == 0
+    assert st["path_direct"] == 0 or st["result_waves"] == 1, st["result_waves"]
+    L.release_cache()
