@@ -1098,6 +1098,35 @@ private:
         SortResult<idx_t> rs = seg_sort<BITS>(pl_.segS, tiles_of(m), m, pl_.SA_, pl_.SB_, m, os, false);
         passesS_ = rs.passes;
         ElemBuf<idx_t> smp = rs.uniform();
+        if (std::getenv("CAPS_SA_DEBUG_CHECK_SORTS")) {       // debugging: the sorted samples back on the host -- non-decreasing keys, positions in range
+            std::vector<uint64_t> hk(m);
+            std::vector<idx_t> hs(m);
+            be_.d2h(hk.data(), smp.key, m * sizeof(uint64_t));
+            be_.d2h(hs.data(), smp.sa, m * sizeof(idx_t));
+            be_.sync();
+            uint64_t bad_order = 0, bad_pos = 0, first_o = ~0ull, first_p = ~0ull;
+            for (uint64_t i = 0; i < m; ++i) {
+                if ((uint64_t)hs[i] >= n) { ++bad_pos; if (first_p == ~0ull) first_p = i; }
+                if (i && hk[i] < hk[i - 1]) { ++bad_order; if (first_o == ~0ull) first_o = i; }
+            }
+            std::fprintf(stderr, "[check] sample sort: m %llu passes %u unified %d | keys out of order %llu (first at %llu) | positions >= n %llu (first at %llu",
+                         (unsigned long long)m, rs.passes, (int)rs.unified, (unsigned long long)bad_order, (unsigned long long)first_o,
+                         (unsigned long long)bad_pos, (unsigned long long)first_p);
+            if (first_p != ~0ull) {
+                std::fprintf(stderr, ":");
+                for (uint64_t i = first_p > 2 ? first_p - 2 : 0; i < first_p + 6 && i < m; ++i) std::fprintf(stderr, " [%llu] %016llx/%llu", (unsigned long long)i, (unsigned long long)hk[i], (unsigned long long)hs[i]);
+            }
+            std::fprintf(stderr, ")\n[check] inversions at:");
+            uint64_t shown = 0;
+            for (uint64_t i = 1; i < m && shown < 200; ++i)
+                if (hk[i] < hk[i - 1]) { std::fprintf(stderr, " %llu", (unsigned long long)i); ++shown; }
+            std::fprintf(stderr, "\n[check] bucket starts:");
+            std::vector<uint64_t> hb(64);
+            be_.d2h(hb.data(), rs.segs.seg_start, 64 * sizeof(uint64_t));
+            be_.sync();
+            for (uint64_t i = 0; i < 64 && (i == 0 || hb[i] > 0) && hb[i] <= m; ++i) std::fprintf(stderr, " %llu", (unsigned long long)hb[i]);
+            std::fprintf(stderr, "\n");
+        }
         CAPS_LAUNCH((pick_pivots_kernel<idx_t>), (p + 255) / 256, 256, be_, (const uint64_t*)smp.key, (const idx_t*)smp.sa,
                     m, p, pl_.pkey, pl_.psa);
         e3_ = be_.record();
