@@ -68,6 +68,10 @@ class Stats(ctypes.Structure):
         ("ms_device_build_min", ctypes.c_double),
         ("ms_download_max", ctypes.c_double),
         ("ms_download_min", ctypes.c_double),
+        ("tie_groups_deferred", ctypes.c_uint64),
+        ("tie_elems_deferred", ctypes.c_uint64),
+        ("tie_levels", ctypes.c_uint32),
+        ("reserved_", ctypes.c_uint32),
     ]
 
     def as_dict(self) -> dict:

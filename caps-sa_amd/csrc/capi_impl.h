@@ -743,18 +743,19 @@ int merge_runs(const char* T, uint64_t n, const idx_t* X, uint64_t len_x, const 
         const SegDesc sd = s.desc();
         const uint32_t nt = tiles_of(cnt), g = (uint32_t)((cnt + 255) / 256);
         const uint32_t pg = nt < be.persistent_blocks() ? nt : be.persistent_blocks();
+        be.memset(desc + nt, 0, sizeof(uint32_t));          // merge_partition_kernel counts the tiles it lists there
         if (t.bits == 2) {
             CAPS_LAUNCH((make_keys_kernel<idx_t, 2>), g, 256, be, (const uint32_t*)t.P, (const idx_t*)a.sa, cnt, a.key);
             CAPS_LAUNCH((merge_partition_kernel<idx_t, 2, true>), (nt + 255) / 256, 256, be, sd, (const uint32_t*)t.P, n, (uint64_t)TILE_E,
-                        len_x, 0u, 1u, (const uint64_t*)a.key, (const idx_t*)a.sa, desc, (uint64_t*)nullptr);
-            CAPS_LAUNCH((merge_pass_kernel<idx_t, 2, true>), pg, TILE_NT, be, (const TileDesc*)desc, nt, (const uint32_t*)t.P, n,
-                        (const uint64_t*)a.key, (const idx_t*)a.sa, b.key, b.sa, b.lcp);
+                        len_x, 0u, 1u, (const uint64_t*)a.key, (const idx_t*)a.sa, desc, (uint64_t*)nullptr, 0u, reinterpret_cast<uint32_t*>(desc + nt));
+            CAPS_LAUNCH((merge_pass_kernel<idx_t, 2, true>), pg, TILE_NT, be, (const TileDesc*)desc, (const uint32_t*)(desc + nt), (const uint32_t*)t.P, n,
+                        (const uint64_t*)a.key, (const idx_t*)a.sa, b.key, b.sa, b.lcp, (uint64_t*)nullptr);
         } else {
             CAPS_LAUNCH((make_keys_kernel<idx_t, 8>), g, 256, be, (const uint32_t*)t.P, (const idx_t*)a.sa, cnt, a.key);
             CAPS_LAUNCH((merge_partition_kernel<idx_t, 8, true>), (nt + 255) / 256, 256, be, sd, (const uint32_t*)t.P, n, (uint64_t)TILE_E,
-                        len_x, 0u, 1u, (const uint64_t*)a.key, (const idx_t*)a.sa, desc, (uint64_t*)nullptr);
-            CAPS_LAUNCH((merge_pass_kernel<idx_t, 8, true>), pg, TILE_NT, be, (const TileDesc*)desc, nt, (const uint32_t*)t.P, n,
-                        (const uint64_t*)a.key, (const idx_t*)a.sa, b.key, b.sa, b.lcp);
+                        len_x, 0u, 1u, (const uint64_t*)a.key, (const idx_t*)a.sa, desc, (uint64_t*)nullptr, 0u, reinterpret_cast<uint32_t*>(desc + nt));
+            CAPS_LAUNCH((merge_pass_kernel<idx_t, 8, true>), pg, TILE_NT, be, (const TileDesc*)desc, (const uint32_t*)(desc + nt), (const uint32_t*)t.P, n,
+                        (const uint64_t*)a.key, (const idx_t*)a.sa, b.key, b.sa, b.lcp, (uint64_t*)nullptr);
         }
         be.d2h(Z, b.sa, cnt * sizeof(idx_t));
         be.d2h(LZ, b.lcp, cnt * sizeof(idx_t));

@@ -611,6 +611,28 @@ DEV_INLINE void multi_lower_bound(const uint32_t* __restrict__ P, uint64_t n, co
     }
 }
 
+// Deferred ties (pipeline.h SortOpts::defer_ties; msd_* kernels below).  A sort that completes segments of THE suffix array may leave
+// the order inside a group of EQUAL keys open: the comparison sort of a tile orders such a group by position (descending: as if
+// the text ended behind the key), the merge passes merge by key alone (stably: run A before run B), and the pass that emits the
+// LCPs writes TIE_SENTINEL (all ones: no LCP has that value) for every element whose key equals its predecessor's.  The groups
+// are then ordered by re-keying them KCH chars deeper, level by level (msd_refine, pipeline.h) -- one window per suffix and level
+// instead of a walk through the text per comparison (thousands of suffixes of a tandem array share their first 32 bases and
+// agree with their neighbours for ~850 chars: 50 of the 142 ms of the GRCh38-shaped workload were such comparisons).
+// K bounds over LDS-resident sorted keys, by key only: lower bound (#{< key}) or upper bound (#{<= key}) per search.
+template <int K>
+DEV_INLINE void multi_key_bound(const uint64_t* skey, const uint64_t (&key)[K], const bool (&upper)[K], uint32_t (&lo)[K],
+                                const uint32_t (&hi)[K], uint32_t top)
+{
+    for (uint32_t s = top >> 1; s >= 1; s >>= 1) {
+        UNROLL
+        for (int k = 0; k < K; ++k) {
+            const uint32_t idx = lo[k] + s - 1;
+            const uint64_t mk = skey[idx < TILE_E ? idx : TILE_E - 1];
+            if (idx < hi[k] && (upper[k] ? mk <= key[k] : mk < key[k])) lo[k] += s;
+        }
+    }
+}
+
 // smallest power of two strictly greater than x (x < 2^31)
 HD uint32_t pow2_above(uint32_t x) { return 1u << (32 - (x ? __builtin_clz(x) : 32)); }
 
@@ -785,6 +807,16 @@ template <int BITS, bool RUNS, typename idx_t>
 DEV_INLINE uint64_t tile_pair_lcp(const uint32_t* __restrict__ P, uint64_t n, uint32_t ka, idx_t a, uint32_t kb, idx_t b, uint32_t cs)
 {
     return pair_lcp32<BITS, RUNS>(P, n, ka, (uint64_t)a, kb, (uint64_t)b, cs);
+}
+
+// ... or TIE_SENTINEL for a pair of equal keys when ties are deferred (bflag != null: "Deferred ties" above)
+template <typename idx_t> HD idx_t tie_sentinel() { return (idx_t)~(idx_t)0; }
+template <int BITS, bool RUNS, typename idx_t>
+DEV_INLINE uint64_t deferring_pair_lcp(const uint32_t* __restrict__ P, uint64_t n, uint64_t* __restrict__ bflag, uint32_t g, uint64_t ka, idx_t a,
+                                       uint64_t kb, idx_t b)
+{
+    if (bflag && ka == kb) { bflag[g] = 1; return (uint64_t)tie_sentinel<idx_t>(); }       // (benign race: every writer stores 1)
+    return tile_pair_lcp<BITS, RUNS>(P, n, ka, a, kb, b, 0u);
 }
 
 // Measurement only (make variant VARIANT_DEFS=-DCAPS_PHASE_CLOCK; never in the product build): thread 0 of every workgroup
@@ -1693,9 +1725,14 @@ template <typename idx_t, int BITS, bool FROM_TEXT, bool RUNS, bool PERSIST = tr
 GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_general_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
                                                           uint64_t text_base, uint32_t lcp_mode, uint32_t slot_cap, const uint64_t* in_key,
                                                           const idx_t* in_sa, uint64_t* out_key, idx_t* out_sa, idx_t* out_lcp,
-                                                          FinalOut<idx_t> fin, const uint32_t* __restrict__ redo, uint32_t keys_from_text)
+                                                          FinalOut<idx_t> fin, const uint32_t* __restrict__ redo, uint32_t keys_from_text,
+                                                          uint64_t* __restrict__ bflag)
 {
+    // bflag != null: ties are deferred ("Deferred ties" above) -- equal keys are ordered by position, descending (the comparators
+    // run as if the text had length 0: text.h), their LCPs are TIE_SENTINEL, and bflag[segment] says that the segment holds some
+    const uint64_t n_cmp = bflag ? 0 : n;
     const uint32_t TILE_KEY_SHIFT = 0;
+    (void)TILE_KEY_SHIFT;
     SHARED_ARRAY(uint64_t, skey, TILE_E);
     SHARED_ARRAY(idx_t, ssa, TILE_E);
     SHARED_ARRAY(uint64_t, smk, 2 * TILE_NT);       // samples (2x: the fixed-depth search may probe past the end)
@@ -1774,7 +1811,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_general_kernel(
                     hi1[0] = sib + R < S ? sib + R : S;
                     dbase = (run & ~1u) * R + (tid - run * R) - sib;
                 }
-                multi_lower_bound<idx_t, BITS, 1, RUNS>(P, n, smk, sms, key1, sa1, lo1, hi1, 2 * R);
+                multi_lower_bound<idx_t, BITS, 1, RUNS>(P, n_cmp, smk, sms, key1, sa1, lo1, hi1, 2 * R);
                 TL(sk1, tid, 0) = key1[0];
                 TL(ss1, tid, 0) = sa1[0];
                 TL(sd1, tid, 0) = dbase + lo1[0];
@@ -1801,7 +1838,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_general_kernel(
                     lo[k] = 0;
                     hi[k] = e < cnt ? S : 0u;
                 }
-                multi_lower_bound<idx_t, BITS, LOCK_K, RUNS>(P, n, smk, sms, key, sa, lo, hi, top);
+                multi_lower_bound<idx_t, BITS, LOCK_K, RUNS>(P, n_cmp, smk, sms, key, sa, lo, hi, top);
                 UNROLL
                 for (uint32_t k = 0; k < LOCK_K; ++k) {
                     const uint32_t e = tid + (gg + k) * TILE_NT;
@@ -1841,7 +1878,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_general_kernel(
                         const uint64_t sa = (uint64_t)TL(rs, tid, k);
                         uint32_t less = 0;                        // members of my bin that sort before me
                         for (uint32_t j = bs; j < be; ++j)
-                            if (j != slot && suffix_less<BITS, RUNS>(P, n, skey[j], (uint64_t)ssa[j], key, sa)) ++less;
+                            if (j != slot && suffix_less<BITS, RUNS>(P, n_cmp, skey[j], (uint64_t)ssa[j], key, sa)) ++less;
                         TL(rd, tid, k) = bs + less;
                     }
                 }
@@ -1889,7 +1926,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_general_kernel(
                         dbase[k] = (run & ~1u) * R + (e - run * R) - sib_start;
                     }
                 }
-                multi_lower_bound<idx_t, BITS, LOCK_K, RUNS>(P, n, skey, ssa, key, sa, lo, hi, 2 * R);
+                multi_lower_bound<idx_t, BITS, LOCK_K, RUNS>(P, n_cmp, skey, ssa, key, sa, lo, hi, 2 * R);
                 UNROLL
                 for (uint32_t k = 0; k < LOCK_K; ++k) {
                     TL(rk, tid, gg + k) = key[k];
@@ -1901,7 +1938,11 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_general_kernel(
         SYNC();
         TILE_SORT_PLACE_FINAL
     }
+#undef TILE_EMIT_LCP_
+#define TILE_EMIT_LCP_(ka, a, kb, b) deferring_pair_lcp<BITS, TILE_RUNS, idx_t>(P, n, bflag, g, ka, a, kb, b)
     TILE_SORT_EMIT
+#undef TILE_EMIT_LCP_
+#define TILE_EMIT_LCP_(ka, a, kb, b) tile_pair_lcp<BITS, TILE_RUNS>(P, n, ka, a, kb, b, TILE_KEY_SHIFT)
     SYNC();                                        // before the next queued tile re-uses the LDS
     qi += K_GRID_DIM;
     } while (PERSIST && qi < n_redo);
@@ -1939,7 +1980,7 @@ struct TileDesc {
     uint64_t srcA, srcB, dst;   // element offsets of the two input pieces and of the output
     uint32_t na, nb;            // piece lengths (na + nb <= TILE_E; 0/0 = inactive tile)
     uint32_t flags;             // TD_*
-    uint32_t pad;
+    uint32_t pad;               // the tile's segment
 };
 constexpr uint32_t TD_HALO_A = 1, TD_HALO_B = 2, TD_FINAL = 4;
 
@@ -1950,16 +1991,19 @@ HD uint32_t passes_for(uint64_t len)
     return tiles <= 1 ? 0u : (uint32_t)(64 - caps_clz64(tiles - 1));
 }
 
+// stable: by key alone, an element of A before an element of B with the same key (deferred ties)
 template <typename idx_t, int BITS, bool RUNS = true>
 DEV_INLINE uint64_t merge_path_split(const uint32_t* __restrict__ P, uint64_t n, const uint64_t* __restrict__ key,
-                                     const idx_t* __restrict__ sa, uint64_t A, uint64_t la, uint64_t B, uint64_t lb, uint64_t d)
+                                     const idx_t* __restrict__ sa, uint64_t A, uint64_t la, uint64_t B, uint64_t lb, uint64_t d,
+                                     bool stable = false)
 {
     uint64_t lo = d > lb ? d - lb : 0;
     uint64_t hi = d < la ? d : la;
     while (lo < hi) {                                      // #elements of A among the first d outputs
         const uint64_t mid = (lo + hi) >> 1;
         const uint64_t ia = A + mid, ib = B + (d - 1 - mid);
-        if (suffix_less<BITS, RUNS>(P, n, key[ia], (uint64_t)sa[ia], key[ib], (uint64_t)sa[ib])) lo = mid + 1;
+        const bool a_first = stable ? key[ia] <= key[ib] : suffix_less<BITS, RUNS>(P, n, key[ia], (uint64_t)sa[ia], key[ib], (uint64_t)sa[ib]);
+        if (a_first) lo = mid + 1;
         else hi = mid;
     }
     return lo;
@@ -1969,9 +2013,12 @@ template <typename idx_t, int BITS, bool RUNS>
 GLOBAL_FN LAUNCH_BOUNDS(256) merge_partition_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n,
                                                     uint64_t R, uint64_t single_la, uint32_t skip_finished, uint32_t need_lcp,
                                                     const uint64_t* __restrict__ key, const idx_t* __restrict__ sa,
-                                                    TileDesc* __restrict__ desc, uint64_t* __restrict__ moved)
+                                                    TileDesc* __restrict__ desc, uint64_t* __restrict__ moved, uint32_t defer,
+                                                    uint32_t* __restrict__ n_active)
 {
+    // n_active (zeroed by the caller): counts the descriptors written -- desc[0 .. *n_active) is what merge_pass_kernel walks
     // moved (optional): += elements this pass really merges, one global atomic per workgroup
+    // defer: the runs are merged by key alone, stably ("Deferred ties")
     SHARED_ARRAY(uint64_t, acc, 1);
     PAR(tid) { if (tid == 0) acc[0] = 0; }
     SYNC();
@@ -1988,8 +2035,8 @@ GLOBAL_FN LAUNCH_BOUNDS(256) merge_partition_kernel(KCTX SegDesc sd, const uint3
                 const uint64_t tot = pr.la + pr.lb;
                 const uint64_t d1 = pr.d0 + TILE_E < tot ? pr.d0 + TILE_E : tot;
                 const uint64_t A = pr.a0, B = pr.a0 + pr.la;
-                const uint64_t i0 = merge_path_split<idx_t, BITS, RUNS>(P, n, key, sa, A, pr.la, B, pr.lb, pr.d0);
-                const uint64_t i1 = d1 < tot ? merge_path_split<idx_t, BITS, RUNS>(P, n, key, sa, A, pr.la, B, pr.lb, d1) : pr.la;
+                const uint64_t i0 = merge_path_split<idx_t, BITS, RUNS>(P, n, key, sa, A, pr.la, B, pr.lb, pr.d0, defer != 0);
+                const uint64_t i1 = d1 < tot ? merge_path_split<idx_t, BITS, RUNS>(P, n, key, sa, A, pr.la, B, pr.lb, d1, defer != 0) : pr.la;
                 const uint64_t j0 = pr.d0 - i0, j1 = d1 - i1;
                 d.srcA = A + i0;
                 d.srcB = B + j0;
@@ -1998,8 +2045,11 @@ GLOBAL_FN LAUNCH_BOUNDS(256) merge_partition_kernel(KCTX SegDesc sd, const uint3
                 d.nb = (uint32_t)(j1 - j0);
                 d.flags = (i0 > 0 ? TD_HALO_A : 0u) | (j0 > 0 ? TD_HALO_B : 0u);
                 if (need_lcp && (single_la != ~0ull || 2 * R >= seglen)) d.flags |= TD_FINAL;
+                d.pad = t.g;                              // the segment (merge_pass_kernel flags it when it defers ties)
             }
-            desc[b] = d;
+            // only the tiles that merge something are listed (in any order: they are independent) -- a pass over a text whose
+            // buckets nearly all fit a tile used to walk a million empty descriptors (3 of the 3.7 ms of a pass at 3e9)
+            if (d.na + d.nb) desc[FETCH_ADD_U32(n_active, 1u)] = d;
             if (moved && (d.na + d.nb)) ATOMIC_ADD_LDS_U64(&acc[0], (uint64_t)(d.na + d.nb));
         }
     }
@@ -2008,12 +2058,13 @@ GLOBAL_FN LAUNCH_BOUNDS(256) merge_partition_kernel(KCTX SegDesc sd, const uint3
 }
 
 template <typename idx_t, int BITS, bool RUNS>
-GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) merge_pass_kernel(KCTX const TileDesc* __restrict__ desc, uint32_t n_tiles,
+GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) merge_pass_kernel(KCTX const TileDesc* __restrict__ desc, const uint32_t* __restrict__ n_active,
                                                    const uint32_t* __restrict__ P, uint64_t n,
                                                    const uint64_t* __restrict__ in_key, const idx_t* __restrict__ in_sa,
                                                    uint64_t* __restrict__ out_key, idx_t* __restrict__ out_sa,
-                                                   idx_t* __restrict__ out_lcp)
+                                                   idx_t* __restrict__ out_lcp, uint64_t* __restrict__ bflag)
 {
+    // bflag != null: deferred ties -- stable merge by key, TIE_SENTINEL for equal neighbours, bflag[segment] = 1 where one was written
     SHARED_ARRAY(uint64_t, skey, TILE_E);
     SHARED_ARRAY(idx_t, ssa, TILE_E);
     TL_DECL(uint64_t, pk, TILE_EPT);      // prefetched (next tile)
@@ -2022,6 +2073,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) merge_pass_kernel(KCTX co
     TL_DECL(idx_t, rs, TILE_EPT);
     TL_DECL(uint32_t, rd, TILE_EPT);
 
+    const uint32_t n_tiles = n_active[0];              // the listed tiles (merge_partition_kernel)
     uint32_t t = K_BLOCK_IDX;
     if (t >= n_tiles) return;
     TileDesc d = desc[t];
@@ -2070,21 +2122,25 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) merge_pass_kernel(KCTX co
                 uint64_t key[LOCK_K];
                 idx_t sa[LOCK_K];
                 uint32_t lo[LOCK_K], hi[LOCK_K];
+                bool up[LOCK_K];
                 UNROLL
                 for (uint32_t k = 0; k < LOCK_K; ++k) {
                     const uint32_t x = tid + (g + k) * TILE_NT;
                     key[k] = 0;
                     sa[k] = 0;
                     lo[k] = hi[k] = 0;
+                    up[k] = false;
                     if (x < cnt) {
                         key[k] = skey[x];
                         sa[k] = ssa[x];
                         const bool fromA = x < na;
                         lo[k] = fromA ? na : 0u;                         // #elements of the other piece < (key, sa)
                         hi[k] = fromA ? cnt : na;
+                        up[k] = !fromA;                                  // (deferred ties: B's elements behind A's equal keys)
                     }
                 }
-                multi_lower_bound<idx_t, BITS, LOCK_K, RUNS>(P, n, skey, ssa, key, sa, lo, hi, top);
+                if (bflag) multi_key_bound<LOCK_K>(skey, key, up, lo, hi, top);
+                else multi_lower_bound<idx_t, BITS, LOCK_K, RUNS>(P, n, skey, ssa, key, sa, lo, hi, top);
                 UNROLL
                 for (uint32_t k = 0; k < LOCK_K; ++k) {
                     // slot = own rank + rank in the other piece = (x - na) + lo for both pieces
@@ -2121,6 +2177,16 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) merge_pass_kernel(KCTX co
                         const uint64_t key = skey[x];
                         const uint64_t sa = (uint64_t)ssa[x];
                         uint64_t l = 0;
+                        if (bflag) {
+                            // equal keys anywhere before me = an equal key right before me (the pieces are sorted by key)
+                            const bool tie = x ? skey[x - 1] == key : (hA && hAk == key) || (hB && hBk == key);
+                            if (tie) { l = (uint64_t)tie_sentinel<idx_t>(); bflag[d.pad] = 1; }
+                            else if (x) l = pair_lcp<BITS, false>(P, n, skey[x - 1], (uint64_t)ssa[x - 1], key, sa);
+                            else {
+                                if (hA) l = pair_lcp<BITS, false>(P, n, hAk, hAs, key, sa);
+                                if (hB) { const uint64_t l2 = pair_lcp<BITS, false>(P, n, hBk, hBs, key, sa); l = l2 > l ? l2 : l; }
+                            }
+                        } else
                         if (x) l = pair_lcp<BITS, RUNS>(P, n, skey[x - 1], (uint64_t)ssa[x - 1], key, sa);
                         else {
                             if (hA) l = pair_lcp<BITS, RUNS>(P, n, hAk, hAs, key, sa);
@@ -3751,6 +3817,370 @@ GLOBAL_FN LAUNCH_BOUNDS(256) lcp_pairs_kernel(KCTX const uint32_t* __restrict__ 
             const uint64_t x = a[i], y = b[i];
             out[i] = (idx_t)(x == y ? n - x : deep_lcp<BITS>(P, n, x, y, 0));
         }
+    }
+}
+
+// ----------------------------------------------------------------------------------
+// Deferred ties, resolved (pipeline.h msd_refine): MSD refinement of the groups of equal keys a sort has left open.
+//
+// A group = a maximal run of entries of the finished arrays whose LCPs are TIE_SENTINEL, plus the entry before the run (its
+// head, whose LCP with ITS predecessor is already right): suffixes that share their first D = KCH chars, at positions
+// [pos, pos + len) of SA that are theirs whatever their order turns out to be.  The members are copied to compact work arrays
+// (wsa; seg_start / gpos: where a group starts there and in SA), and then, level by level:
+//   re-key      key = the KCH chars behind the D known-equal ones: one window of the text per member
+//   sort        every group by (key, position descending) -- the ordinary segmented sort, text-free (SortOpts::keys_only)
+//   classify    neighbours with different keys are settled: LCP = D + what the two keys share.  Equal keys: still open, unless
+//               the upper one's suffix ends inside this window -- then it is a prefix of the lower one (the pad behind the
+//               text is the smallest code), sorts first (it has the larger position) and the LCP is its length
+//   compact     what is still open (runs of >= 2) moves on, D += KCH
+// Groups of at most MSD_FIN_MAX members leave the loop at once: one wave ranks them by direct comparison from depth D on
+// (deep_scan: run-table aware, any depth).  The reference settles every one of these pairs by scanning both suffixes from
+// their known common prefix (src/Suffix_Array.cpp:69-80 through LCP<8>, include/Suffix_Array.hpp:195-241).
+// ----------------------------------------------------------------------------------
+#ifndef CAPS_MSD_FIN_MAX
+#define CAPS_MSD_FIN_MAX 32
+#endif
+#ifndef CAPS_MSD_RANK_MAX
+#define CAPS_MSD_RANK_MAX 256
+#endif
+constexpr uint32_t MSD_FIN_MAX = CAPS_MSD_FIN_MAX;
+constexpr uint64_t MSD_TILE_BIT = 1ull << 40;             // tile counts: elements in the low 40 bits, tiles above
+constexpr uint64_t MSD_ELEM_MASK = MSD_TILE_BIT - 1;
+
+// tcnt[b] = (elements of tile b) | MSD_TILE_BIT if the tile's segment holds deferred ties, else 0
+GLOBAL_FN LAUNCH_BOUNDS(256) msd_tile_counts_kernel(KCTX SegDesc sd, const uint64_t* __restrict__ bflag, uint64_t* __restrict__ tcnt)
+{
+    PAR(tid) {
+        const uint64_t b = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (b < sd.tile_off[sd.G]) {
+            const TileInfo t = tile_info(sd, (uint32_t)b);
+            const uint64_t start = t.s0 + (uint64_t)t.tl * TILE_E;
+            const uint64_t cnt = t.s1 - start < TILE_E ? t.s1 - start : TILE_E;
+            tcnt[b] = bflag[t.g] ? (cnt | MSD_TILE_BIT) : 0;
+        }
+    }
+}
+
+// ftile[j] = the j-th flagged tile (toff = exclusive scan of tcnt)
+GLOBAL_FN LAUNCH_BOUNDS(256) msd_tile_list_kernel(KCTX const uint64_t* __restrict__ tcnt, const uint64_t* __restrict__ toff, uint32_t n_tiles,
+                                                  uint32_t* __restrict__ ftile)
+{
+    PAR(tid) {
+        const uint64_t b = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (b < n_tiles && tcnt[b]) ftile[toff[b] >> 40] = (uint32_t)b;
+    }
+}
+
+// suffix `sa` ends inside (or before) the window of chars [D, D + KCH) of the group's members
+template <int BITS> HD bool msd_ending(uint64_t n, uint64_t sa, uint64_t D) { return n - sa <= D + TextTraits<BITS>::KCH; }
+
+// Level 0: the members of the flagged tiles.  flags[toff(tile) + e] = member | head << 32 for entry e of the tile: an entry is
+// tied to its predecessor when its LCP is the sentinel.  SA / LCP: the slice the sort wrote (segment offsets).
+// (A suffix that ends inside the key is a member like any other -- the merge passes may have left it anywhere in its group;
+// it is a prefix of the other members, and the levels / the comparisons below place it first.)
+template <typename idx_t>
+GLOBAL_FN LAUNCH_BOUNDS(256) msd_flags0_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ ftile, const uint64_t* __restrict__ toff,
+                                               const idx_t* __restrict__ LCP, uint64_t* __restrict__ flags)
+{
+    const uint32_t b = ftile[K_BLOCK_IDX];
+    const TileInfo t = tile_info(sd, b);
+    const uint64_t start = t.s0 + (uint64_t)t.tl * TILE_E;
+    const uint32_t cnt = (uint32_t)(t.s1 - start < TILE_E ? t.s1 - start : TILE_E);
+    const uint64_t f0 = toff[b] & MSD_ELEM_MASK;
+    const idx_t SENT = tie_sentinel<idx_t>();
+    PAR(tid) {
+        for (uint32_t e = tid; e < cnt; e += K_BLOCK_DIM) {
+            const uint64_t p = start + e;
+            const bool tp = LCP[p] == SENT;                  // (a segment head never carries the sentinel)
+            const bool tn = p + 1 < t.s1 && LCP[p + 1] == SENT;
+            const bool member = tp || tn;
+            flags[f0 + e] = (member ? 1ull : 0ull) | (member && !tp ? 1ull << 32 : 0ull);
+        }
+    }
+}
+
+// ... and their copy into the work arrays: wsa[c] = SA[p], a head opens group g': seg_start[g'] = c, gpos[g'] = p
+// (offs = exclusive scan of flags: members before in the low word, heads before in the high one)
+template <typename idx_t>
+GLOBAL_FN LAUNCH_BOUNDS(256) msd_compact0_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ ftile, const uint64_t* __restrict__ toff,
+                                                 const idx_t* __restrict__ SA, const uint64_t* __restrict__ flags,
+                                                 const uint64_t* __restrict__ offs, idx_t* __restrict__ wsa,
+                                                 uint64_t* __restrict__ seg_start, uint64_t* __restrict__ gpos, uint32_t* __restrict__ wgid)
+{
+    // wgid[c] = the member's group (heads before it, itself included)
+    const uint32_t b = ftile[K_BLOCK_IDX];
+    const TileInfo t = tile_info(sd, b);
+    const uint64_t start = t.s0 + (uint64_t)t.tl * TILE_E;
+    const uint32_t cnt = (uint32_t)(t.s1 - start < TILE_E ? t.s1 - start : TILE_E);
+    const uint64_t f0 = toff[b] & MSD_ELEM_MASK;
+    PAR(tid) {
+        for (uint32_t e = tid; e < cnt; e += K_BLOCK_DIM) {
+            const uint64_t f = flags[f0 + e];
+            if (f & 1u) {
+                const uint64_t o = offs[f0 + e], c = o & 0xFFFFFFFFull;
+                wsa[c] = SA[start + e];
+                wgid[c] = (uint32_t)((o >> 32) + (f >> 32)) - 1u;
+                if (f >> 32) { seg_start[o >> 32] = c; gpos[o >> 32] = start + e; }
+            }
+        }
+    }
+}
+
+// closes a group table: seg_start[G] = m, out3 = {G, m, 0, 0, 0} (total = offs[count]: members | groups << 32)
+GLOBAL_FN LAUNCH_BOUNDS(64) msd_close_kernel(KCTX const uint64_t* __restrict__ total, uint64_t* __restrict__ seg_start, uint64_t* __restrict__ out3)
+{
+    PAR(tid) {
+        if (tid == 0 && K_BLOCK_IDX == 0) {
+            const uint64_t m = total[0] & 0xFFFFFFFFull, G = total[0] >> 32;
+            seg_start[G] = m;
+            out3[0] = G;
+            out3[1] = m;
+            out3[2] = 0;                               // groups larger than MSD_FIN_MAX (msd_finish_kernel counts them),
+            out3[3] = 0;                               //   the largest of them,
+            out3[4] = 0;                               //   those above MSD_RANK_MAX (sorted tile by tile),
+            out3[5] = 0;                               //   members listed for msd_finish_kernel
+        }
+    }
+}
+
+// ---- one level.  Everything below is one THREAD per member of the work array (wgid: its group; skip[g] != 0: the group is
+// finished -- its members are dead weight until the next compaction drops them).
+constexpr uint32_t MSD_RANK_MAX = CAPS_MSD_RANK_MAX;        // groups up to this size are sorted by counting (msd_ranksort_kernel), larger ones tile by tile
+
+// key = the KCH chars behind the D known-equal ones
+template <typename idx_t, int BITS>
+GLOBAL_FN LAUNCH_BOUNDS(256) msd_rekey_kernel(KCTX const uint32_t* __restrict__ P, uint64_t n, uint64_t D, uint64_t m,
+                                              const uint32_t* __restrict__ wgid, const uint8_t* __restrict__ skip,
+                                              const idx_t* __restrict__ wsa, uint64_t* __restrict__ wkey)
+{
+    PAR(tid) {
+        const uint64_t i = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (i < m && !skip[wgid[i]]) {
+            const uint64_t pos = (uint64_t)wsa[i] + D;
+            wkey[i] = pos < n ? window64<BITS>(P, pos) : 0;       // (a suffix that has ended: the pad, the smallest key)
+        }
+    }
+}
+
+// groups of at most MSD_RANK_MAX members, sorted by (key, position descending): every member counts the smaller ones of its group
+// (late levels hold thousands of groups of a few dozen members: a workgroup per group would be all overhead)
+template <typename idx_t>
+GLOBAL_FN LAUNCH_BOUNDS(256) msd_ranksort_kernel(KCTX uint64_t m, const uint64_t* __restrict__ seg_start, const uint32_t* __restrict__ wgid,
+                                                 const uint8_t* __restrict__ skip, const uint64_t* __restrict__ wkey,
+                                                 const idx_t* __restrict__ wsa, uint64_t* __restrict__ okey, idx_t* __restrict__ osa)
+{
+    PAR(tid) {
+        const uint64_t i = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (i < m) {
+            const uint32_t g = wgid[i];
+            const uint64_t s0 = seg_start[g], s1 = seg_start[g + 1];
+            if (!skip[g] && s1 - s0 <= MSD_RANK_MAX) {
+                const uint64_t k = wkey[i];
+                const idx_t a = wsa[i];
+                uint32_t rank = 0;
+                for (uint64_t j = s0; j < s1; ++j) {
+                    const uint64_t kj = wkey[j];
+                    rank += (kj < k || (kj == k && wsa[j] > a)) ? 1u : 0u;
+                }
+                okey[s0 + rank] = k;
+                osa[s0 + rank] = a;
+            }
+        }
+    }
+}
+
+// The groups sorted by (key, position descending): what is settled goes to SA / LCP, what is not is flagged for the next level.
+template <typename idx_t, int BITS>
+GLOBAL_FN LAUNCH_BOUNDS(256) msd_classify_kernel(KCTX uint64_t n, uint64_t D, uint64_t m, const uint64_t* __restrict__ seg_start,
+                                                 const uint32_t* __restrict__ wgid, const uint8_t* __restrict__ skip,
+                                                 const uint64_t* __restrict__ key, const idx_t* __restrict__ sa,
+                                                 const uint64_t* __restrict__ gpos, idx_t* __restrict__ SA, idx_t* __restrict__ LCP,
+                                                 uint64_t* __restrict__ flags)
+{
+    PAR(tid) {
+        const uint64_t i = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (i < m) {
+            const uint32_t g = wgid[i];
+            uint64_t f = 0;
+            if (!skip[g]) {
+                const uint64_t s0 = seg_start[g], s1 = seg_start[g + 1];
+                const uint64_t k = key[i], a = (uint64_t)sa[i];
+                const uint64_t pos = gpos[g] + (i - s0);
+                bool tp = false;
+                SA[pos] = (idx_t)a;
+                if (i > s0) {
+                    const uint64_t kp = key[i - 1], ap = (uint64_t)sa[i - 1];
+                    if (kp != k) {
+                        const uint64_t l = D + (uint32_t)caps_clz64(kp ^ k) / BITS, room = n - (a > ap ? a : ap);
+                        LCP[pos] = (idx_t)(l < room ? l : room);
+                    } else if (msd_ending<BITS>(n, ap, D)) LCP[pos] = (idx_t)(n - ap);     // the upper one is a prefix of this one
+                    else tp = true;
+                }
+                const bool tn = i + 1 < s1 && key[i + 1] == k && !msd_ending<BITS>(n, a, D);
+                const bool member = tp || tn;
+                f = (member ? 1ull : 0ull) | (member && !tp ? 1ull << 32 : 0ull);
+            }
+            flags[i] = f;
+        }
+    }
+}
+
+// ... and its members move on (as msd_compact0_kernel, from the sorted work arrays; wgid_out may not alias wgid)
+template <typename idx_t>
+GLOBAL_FN LAUNCH_BOUNDS(256) msd_compact_kernel(KCTX uint64_t m, const uint64_t* __restrict__ seg_in, const uint32_t* __restrict__ wgid,
+                                                const idx_t* __restrict__ sa, const uint64_t* __restrict__ flags,
+                                                const uint64_t* __restrict__ offs, const uint64_t* __restrict__ gpos_in,
+                                                idx_t* __restrict__ wsa, uint64_t* __restrict__ seg_start, uint64_t* __restrict__ gpos,
+                                                uint32_t* __restrict__ wgid_out)
+{
+    PAR(tid) {
+        const uint64_t i = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (i < m) {
+            const uint64_t f = flags[i];
+            if (f & 1u) {
+                const uint32_t g = wgid[i];
+                const uint64_t o = offs[i], c = o & 0xFFFFFFFFull;
+                wsa[c] = sa[i];
+                wgid_out[c] = (uint32_t)((o >> 32) + (f >> 32)) - 1u;
+                if (f >> 32) { seg_start[o >> 32] = c; gpos[o >> 32] = gpos_in[g] + (i - seg_in[g]); }
+            }
+        }
+    }
+}
+
+// The two ends of every level-0 group.  The LCP at a group's head (with the suffix before the group) and the LCP of the suffix
+// behind the group were emitted by the sort from the members that stood there THEN; they depend on the member only through its
+// length (all members share the key) -- but a member whose suffix ends inside the key is shorter than that, and the stable merges
+// may have left it anywhere.  edges[2g], edges[2g + 1] = the group's first position and the one behind it; once every group is
+// in its final order both LCPs are taken from the text again (two suffixes with different keys: one window).
+GLOBAL_FN LAUNCH_BOUNDS(256) msd_edges_kernel(KCTX const uint64_t* __restrict__ seg_start, const uint64_t* __restrict__ gpos,
+                                              const uint64_t* __restrict__ out3, uint64_t* __restrict__ edges)
+{
+    const uint64_t G = out3[0];
+    PAR(tid) {
+        for (uint64_t g = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid; g < G; g += (uint64_t)K_GRID_DIM * K_BLOCK_DIM) {
+            edges[2 * g] = gpos[g];
+            edges[2 * g + 1] = gpos[g] + (seg_start[g + 1] - seg_start[g]);
+        }
+    }
+}
+template <typename idx_t, int BITS>
+GLOBAL_FN LAUNCH_BOUNDS(256) msd_fix_edges_kernel(KCTX const uint32_t* __restrict__ P, uint64_t n, const uint64_t* __restrict__ edges, uint64_t count,
+                                                  uint64_t total, const idx_t* __restrict__ SA, idx_t* __restrict__ LCP)
+{
+    PAR(tid) {
+        const uint64_t i = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (i < count) {
+            const uint64_t p = edges[i];
+            if (p > 0 && p < total) LCP[p] = (idx_t)deep_lcp<BITS, false>(P, n, (uint64_t)SA[p - 1], (uint64_t)SA[p], 0);
+        }
+    }
+}
+
+// The groups of a level, one thread each: a group of at most MSD_FIN_MAX members is listed for msd_finish_kernel (flist: the
+// indices of its members, out3[5] of them in all) and taken out (skip[g] = 1); larger ones are counted: out3[2] above MSD_FIN_MAX,
+// the largest in out3[3], out3[4] above MSD_RANK_MAX (skip_tiles[g] = 0: sorted tile by tile in the next level).
+GLOBAL_FN LAUNCH_BOUNDS(256) msd_groups_kernel(KCTX const uint64_t* __restrict__ seg_start, uint8_t* __restrict__ skip, uint8_t* __restrict__ skip_tiles,
+                                               uint32_t* __restrict__ flist, uint64_t* __restrict__ out3)
+{
+    // (a workgroup reserves its share of the list and adds its counts with ONE global atomic each: a million groups bumping four
+    // counters one by one took longer than finishing them)
+    SHARED_ARRAY(uint32_t, acc, 4);            // [0] members listed by this workgroup, [1] groups above FIN_MAX, [2] above RANK_MAX, [3] largest
+    SHARED_ARRAY(uint64_t, at0, 1);
+    const uint64_t G = out3[0];
+    for (uint64_t gb = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM; gb < G; gb += (uint64_t)K_GRID_DIM * K_BLOCK_DIM) {
+        TL_DECL(uint32_t, mine, 1);
+        PAR(tid) { if (tid < 4) acc[tid] = 0; }
+        SYNC();
+        PAR(tid) {
+            const uint64_t g = gb + tid;
+            TL(mine, tid, 0) = ~0u;
+            if (g < G) {
+                const uint64_t len = seg_start[g + 1] - seg_start[g];
+                if (len <= MSD_FIN_MAX) {
+                    TL(mine, tid, 0) = FETCH_ADD_U32(&acc[0], (uint32_t)len);
+                    skip[g] = 1;
+                    skip_tiles[g] = 1;
+                } else {
+                    skip[g] = 0;
+                    skip_tiles[g] = len > MSD_RANK_MAX ? 0 : 1;
+                    FETCH_ADD_U32(&acc[1], 1u);
+                    if (len > MSD_RANK_MAX) FETCH_ADD_U32(&acc[2], 1u);
+                    ATOMIC_MAX_U32(&acc[3], (uint32_t)(len < 0xFFFFFFFFull ? len : 0xFFFFFFFFull));
+                }
+            }
+        }
+        SYNC();
+        PAR(tid) {
+            if (tid == 0) {
+                at0[0] = acc[0] ? FETCH_ADD_U64(&out3[5], (uint64_t)acc[0]) : 0;
+                if (acc[1]) ATOMIC_ADD_U64(&out3[2], (uint64_t)acc[1]);
+                if (acc[2]) ATOMIC_ADD_U64(&out3[4], (uint64_t)acc[2]);
+                if (acc[3]) ATOMIC_MAX_U64(&out3[3], (uint64_t)acc[3]);
+            }
+        }
+        SYNC();
+        PAR(tid) {
+            const uint64_t g = gb + tid;
+            if (g < G && TL(mine, tid, 0) != ~0u) {
+                const uint64_t s0 = seg_start[g], len = seg_start[g + 1] - s0, at = at0[0] + TL(mine, tid, 0);
+                for (uint64_t k = 0; k < len; ++k) flist[at + k] = (uint32_t)(s0 + k);
+            }
+        }
+        SYNC();
+    }
+}
+
+// The listed groups are finished by direct comparison: MSD_FIN_LANES threads per member share the other members of its group (the
+// comparisons of a member in flight together: a compare is a chain of dependent reads of the text), each compares from depth D
+// on (deep_scan: run-table aware, any depth); the member's rank is the number of smaller ones, its LCP the largest one it shares
+// with a smaller one (the predecessor's).  The head's LCP with ITS predecessor stands.
+constexpr uint32_t MSD_FIN_LANES = 8;
+constexpr uint32_t MSD_FIN_NT = 256, MSD_FIN_MEMBERS = MSD_FIN_NT / MSD_FIN_LANES;
+template <typename idx_t, int BITS, bool RUNS>
+GLOBAL_FN LAUNCH_BOUNDS(MSD_FIN_NT) msd_finish_kernel(KCTX const uint32_t* __restrict__ P, uint64_t n, uint64_t D, const uint64_t* __restrict__ seg_start,
+                                               const uint64_t* __restrict__ gpos, const idx_t* __restrict__ wsa, const uint32_t* __restrict__ wgid,
+                                               const uint32_t* __restrict__ flist, idx_t* __restrict__ SA, idx_t* __restrict__ LCP,
+                                               const uint64_t* __restrict__ out3)
+{
+    SHARED_ARRAY(uint32_t, rk, MSD_FIN_MEMBERS);
+    SHARED_ARRAY(uint64_t, best, MSD_FIN_MEMBERS);
+    const uint64_t m = out3[5];
+    for (uint64_t base = (uint64_t)K_BLOCK_IDX * MSD_FIN_MEMBERS; base < m; base += (uint64_t)K_GRID_DIM * MSD_FIN_MEMBERS) {
+        PAR(tid) { if (tid < MSD_FIN_MEMBERS) { rk[tid] = 0; best[tid] = 0; } }
+        SYNC();
+        PAR(tid) {
+            const uint32_t q = tid / MSD_FIN_LANES, lane = tid % MSD_FIN_LANES;
+            if (base + q < m) {
+                const uint64_t i = flist[base + q];
+                const uint32_t g = wgid[i];
+                const uint64_t s0 = seg_start[g], len = seg_start[g + 1] - s0;
+                const uint64_t a = (uint64_t)wsa[i];
+                uint32_t cnt = 0;
+                uint64_t bl = 0;
+                for (uint64_t j = s0 + lane; j < s0 + len; j += MSD_FIN_LANES) {
+                    if (j == i) continue;
+                    const uint64_t c = (uint64_t)wsa[j];
+                    const uint64_t maxlen = n - (a > c ? a : c);
+                    uint64_t wa = 0, wc = 0;
+                    uint64_t l = deep_scan<BITS, RUNS>(P, n, c, a, D, maxlen, wc, wa);
+                    const bool c_first = l < maxlen ? wc < wa : c > a;         // (one a prefix of the other: the shorter first)
+                    l = l < maxlen ? l : maxlen;
+                    if (c_first) { ++cnt; bl = l > bl ? l : bl; }
+                }
+                if (cnt) { FETCH_ADD_U32(&rk[q], cnt); ATOMIC_MAX_LDS_U64(&best[q], bl); }
+            }
+        }
+        SYNC();
+        PAR(tid) {
+            if (tid < MSD_FIN_MEMBERS && base + tid < m) {
+                const uint64_t i = flist[base + tid];
+                const uint64_t p = gpos[wgid[i]] + rk[tid];
+                SA[p] = wsa[i];
+                if (rk[tid]) LCP[p] = (idx_t)best[tid];
+            }
+        }
+        SYNC();                                        // rk / best are free for the next batch
     }
 }
 

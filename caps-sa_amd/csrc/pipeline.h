@@ -417,6 +417,14 @@ template <typename idx_t> struct SortResult {
     const BucketBufs* run_bk = nullptr;
     TileDesc* run_desc = nullptr;
     uint64_t total = 0;                                               // elements of the whole sort (= end of the result arrays)
+    // deferred ties (kernels.h "Deferred ties"): flags of the sorted segments that hold sentinel LCPs; finalize() orders those
+    // groups by re-keying them deeper (msd_refine) in the idle work buffers.  msd_failed: the groups did not fit there (finalize())
+    uint64_t* defer_flags = nullptr;
+    TileDesc* defer_desc = nullptr;
+    uint64_t cap = 0;                                                 // elements buf[0] / buf[1] hold
+    mutable bool msd_failed = false;
+    mutable uint64_t msd_groups = 0, msd_elems = 0;
+    mutable uint32_t msd_levels = 0;
     uint32_t n_tiles = 0;
     FinalOut<idx_t> fin;                                              // direct final output (may be empty)
     ElemBuf<idx_t> uniform() const { return unified ? buf[0] : buf[passes & 1]; }   // valid when unified or !skip_finished
@@ -452,6 +460,7 @@ struct SortOpts {
                                         //   path: only their keys are used -- pivots, knots -- and a text with long N-blocks has
                                         //   millions of samples with one key).  Done by sorting as if the text had length 0: every
                                         //   comparator settles a pair with an index beyond the text at once, by index (text.h)
+    bool comparison_only = false;       // every tile straight to the comparison sort (tile_sort_general_kernel): the levels of msd_refine
     bool skewed_keys = false;           // the keys are far from uniform inside the buckets (skew probe): every tile goes to
                                         //   tile_sort_eq_kernel straight away, tile_sort_kernel's linear map is not tried
     const uint64_t* knots = nullptr;    // non-null (quantile mode): parent q's buckets are (knots[q * KPG + i - 1], knots[q * KPG + i]],
@@ -460,6 +469,11 @@ struct SortOpts {
     uint64_t in_extent = 0;             // one past the largest element index of in_key / in_sa (0: unknown).  Quantile splits then
                                         //   keep every element's bucket id between the count pass and the scatter (u16 per element, in
                                         //   the idle LCP array of the scatter's destination) instead of searching the knots twice
+    const SegBufs* run_tables = nullptr;   // segment tables (one segment, tiles of the largest bucket) for the sorts of letter-run buckets
+    uint64_t* defer_flags = nullptr;    // non-null (final sorts with direct output only): ties are DEFERRED (kernels.h "Deferred ties") --
+                                        //   the comparison sort of a tile and the merge passes order equal keys without reading the
+                                        //   text, the LCPs of such neighbours are sentinels, defer_flags[sorted segment] = 1 where
+                                        //   there are some (u64 per sorted segment), and finalize() settles the groups (msd_refine)
     const void* runs = nullptr;   // RunSrc<idx_t>*: the segments are partitions still spread over the sorted subarrays in
                                   //   `cur` (requires the bucket split: bk != null and max_len > TILE_E)
     bool unify = false;           // gather the result into buf[0] (consumers that index whole segments)
@@ -593,8 +607,10 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
                 for (uint64_t j = 0; j < cnt; ++j) r.run_buckets.push_back({rl[2 + 4 * j], rl[3 + 4 * j], rl[4 + 4 * j]});
                 std::sort(r.run_buckets.begin(), r.run_buckets.end(),
                           [](const typename SortResult<idx_t>::RunBucket& a, const typename SortResult<idx_t>::RunBucket& b) { return a.s0 < b.s0; });
-                r.run_tables = bk.sub;               // (idle once finalize() has gathered the sorted buckets; the parents' tables may
-                                                     //  belong to a wave whose neighbours are still to be sorted)
+                // tables for the sort of every such bucket: the caller's (o.run_tables), else the buckets' own -- idle once finalize()
+                // has gathered the sorted buckets, but then nothing may read the bucket tables after the run buckets have been
+                // sorted (msd_refine does: sorts that defer ties pass tables of their own)
+                r.run_tables = o.run_tables ? *o.run_tables : bk.sub;
                 r.run_bk = &bk;
                 r.run_desc = desc;
                 r.total = n_elems;
@@ -729,6 +745,15 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
     const uint32_t ggrid = n_tiles < 4 * be.persistent_blocks() ? n_tiles : 4 * be.persistent_blocks();
     const bool eq_tiles = !std::getenv("CAPS_SA_NO_EQ_TILES");        // measurement: skip tile_sort_eq_kernel
     if (!eq_tiles) redo3 = redo2 = redo;
+    // deferred ties: only where the sort writes THE arrays (sentinels must not reach a consumer that reads LCPs as numbers)
+    uint64_t* bflag = o.defer_flags && o.need_lcp && o.final_sa && !o.keys_only && !(o.k32 && slot_cap) ? o.defer_flags : nullptr;
+    if (bflag) {
+        be.memset(bflag, 0, (size_t)segs.G * sizeof(uint64_t));
+        r.defer_flags = bflag;
+        r.defer_desc = desc;
+    }
+    r.total = n_elems;
+    r.cap = n_elems;
     BackendEvent t0 = be.record();
     if (o.seg_ends && segs.seg_start == s.seg_start)
         throw std::invalid_argument("segments in fixed-capacity regions must be bucketed (results are written compactly)");
@@ -744,7 +769,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, true, true>), ggrid, TILE_NT, be, sd, P, n, o.text_base, lcp_mode, 0u,
                     (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo2, redo3, 0u, (uint32_t*)nullptr);
         CAPS_LAUNCH_RUNS(tile_sort_general_kernel, (idx_t, BITS, true), ggrid, TILE_NT, be, sd, P, n, o.text_base, lcp_mode, 0u,
-                    (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo3, 0u);
+                    (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo3, 0u, bflag);
     } else if (r.k32) {
         // 32-bit keys in the slots; the tiles the first kernel cannot finish are re-sorted from 64-bit keys cut from the text
         CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, false, uint32_t>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
@@ -754,12 +779,17 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false, true>), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
                     (const uint64_t*)nullptr, in_sa, cur.key, cur.sa, cur.lcp, fin, (const BucketParams*)nullptr, (const uint32_t*)redo2, redo3, 1u, (uint32_t*)nullptr);
         CAPS_LAUNCH_RUNS(tile_sort_general_kernel, (idx_t, BITS, false), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
-                    (const uint64_t*)nullptr, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo3, 1u);
+                    (const uint64_t*)nullptr, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo3, 1u, bflag);
     } else {
         // every tile queued (skewed keys): one workgroup per tile -- the build of tile_sort_eq_kernel without the loop over
         // the queue (kernels.h PERSIST); otherwise the queue is short (often empty) and a fixed grid walks it
-        const bool all_queued = o.skewed_keys && eq_tiles;
+        const bool all_queued = o.skewed_keys && eq_tiles && !o.comparison_only;
         const bool per_tile = all_queued && (uint64_t)n_tiles * TILE_NT <= 0xFFFFFFFFull && !std::getenv("CAPS_SA_EQ_PERSISTENT");
+        if (o.comparison_only) {
+            CAPS_LAUNCH(queue_all_tiles_kernel, (n_tiles + 255) / 256, 256, be, sd, redo3);
+            CAPS_LAUNCH_RUNS(tile_sort_general_kernel, (idx_t, BITS, false), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
+                        in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo3, 0u, bflag);
+        } else {
         if (all_queued && !per_tile) CAPS_LAUNCH(queue_all_tiles_kernel, (n_tiles + 255) / 256, 256, be, sd, redo);
         else if (!all_queued) CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
                     in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, redo, no_shift);
@@ -779,17 +809,18 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
             const uint32_t ng = qn[0] + qn[1];           // (the third stage may pass entries on: a bound)
             if (ng && be.long_runs)
                 CAPS_LAUNCH((tile_sort_general_kernel<idx_t, BITS, false, true, false>), ng, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
-                            in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo3, 0u);
+                            in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo3, 0u, bflag);
             else if (ng)
                 CAPS_LAUNCH((tile_sort_general_kernel<idx_t, BITS, false, false, false>), ng, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
-                            in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo3, 0u);
+                            in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo3, 0u, bflag);
         } else {
             if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false>), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
                         in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo, redo3, 0u, redo2);
             if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false, true>), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
                         in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo2, redo3, 0u, (uint32_t*)nullptr);
             CAPS_LAUNCH_RUNS(tile_sort_general_kernel, (idx_t, BITS, false), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
-                        in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo3, 0u);
+                        in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo3, 0u, bflag);
+        }
         }
     }
     BackendEvent t1 = be.record();
@@ -797,13 +828,15 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
     if (o.tile_clock) { o.tile_clock->spans.push_back({t0, t1}); o.tile_clock->elems.push_back(n_elems); }
     const uint32_t grid = n_tiles < be.persistent_blocks() ? n_tiles : be.persistent_blocks();
     ElemBuf<idx_t> a = cur, b = oth;
+    uint32_t* n_active = reinterpret_cast<uint32_t*>(desc + n_tiles);     // (the descriptor array has an entry to spare)
     for (uint64_t R = TILE_E; R < max_len; R *= 2) {
+        be.memset(n_active, 0, sizeof(uint32_t));
         CAPS_LAUNCH_RUNS(merge_partition_kernel, (idx_t, BITS), (n_tiles + 255) / 256, 256, be, sd, P, n, R, ~0ull, skip ? 1u : 0u,
                     lcp_mode, (const uint64_t*)a.key, (const idx_t*)a.sa, desc,
-                    o.pass_counters ? o.pass_counters + r.passes : (uint64_t*)nullptr);
+                    o.pass_counters ? o.pass_counters + r.passes : (uint64_t*)nullptr, bflag ? 1u : 0u, n_active);
         BackendEvent m0 = be.record();
-        CAPS_LAUNCH_RUNS(merge_pass_kernel, (idx_t, BITS), grid, TILE_NT, be, (const TileDesc*)desc, n_tiles, P, n,
-                    (const uint64_t*)a.key, (const idx_t*)a.sa, b.key, b.sa, b.lcp);
+        CAPS_LAUNCH_RUNS(merge_pass_kernel, (idx_t, BITS), grid, TILE_NT, be, (const TileDesc*)desc, (const uint32_t*)n_active, P, n,
+                    (const uint64_t*)a.key, (const idx_t*)a.sa, b.key, b.sa, b.lcp, bflag);
         BackendEvent m1 = be.record();
         if (o.merge_clock) { o.merge_clock->spans.push_back({m0, m1}); o.merge_clock->elems.push_back(n_elems); }
         std::swap(a, b);
@@ -846,6 +879,194 @@ void sort_run_buckets(Backend& be, const uint32_t* P, uint64_t n, const SortResu
     }
 }
 
+// ---- deferred ties, resolved (kernels.h "Deferred ties, resolved") --------------------------------------------------
+// Work memory: the two element buffers of the sort, idle once its result is in SA / LCP -- two chunks of 16 (24) bytes per element.
+struct MsdArena {
+    char* lo[2] = {nullptr, nullptr};
+    char* hi[2] = {nullptr, nullptr};
+    bool failed = false;
+    static char* up(char* p) { return reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p) + 255) & ~uintptr_t(255)); }
+    template <typename T> T* head(size_t count, int pref = 0)
+    {
+        for (int k = 0; k < 2; ++k) {
+            const int c = (pref + k) & 1;
+            char* p = up(lo[c]);
+            if (p && p + count * sizeof(T) <= hi[c]) { lo[c] = p + count * sizeof(T); return reinterpret_cast<T*>(p); }
+        }
+        failed = true;
+        return nullptr;
+    }
+    template <typename T> T* tail(size_t count)
+    {
+        for (int c = 1; c >= 0; --c) {
+            if (!hi[c]) continue;
+            char* p = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(hi[c]) - count * sizeof(T)) & ~uintptr_t(255));
+            if (p >= lo[c] && hi[c] - lo[c] >= (ptrdiff_t)(count * sizeof(T))) { hi[c] = p; return reinterpret_cast<T*>(p); }
+        }
+        failed = true;
+        return nullptr;
+    }
+};
+
+// Orders the groups of equal keys a sort with deferred ties has left open (r.defer_flags) in place in SA / LCP (the slice the sort
+// wrote).  False: the groups do not fit the work memory -- nothing of the result may be used, the caller sorts again without
+// deferring (a text in which most suffixes sit in large groups of equal keys; never seen outside constructed inputs).
+template <typename idx_t, int BITS>
+bool msd_refine(Backend& be, const uint32_t* P, uint64_t n, const SortResult<idx_t>& r, idx_t* SA, idx_t* LCP)
+{
+    constexpr uint32_t KCH = TextTraits<BITS>::KCH;
+    const SegDesc sd = r.segs.desc();
+    const uint32_t n_tiles = r.n_tiles;
+    const bool dbg = std::getenv("CAPS_SA_DEBUG") != nullptr;
+    if (!r.buf[0].region_bytes || !r.buf[1].region_bytes || !r.defer_desc) return false;
+    // ---- level 0: which tiles hold sentinels (tables in the idle tile descriptors: 48 bytes per tile)
+    char* dm = reinterpret_cast<char*>(r.defer_desc);
+    uint64_t* tcnt = reinterpret_cast<uint64_t*>(dm);
+    uint64_t* toff = tcnt + n_tiles;                                      // [n_tiles + 1]
+    uint32_t* ftile = reinterpret_cast<uint32_t*>(toff + n_tiles + 1);    // [n_tiles]
+    uint64_t* ttmp = reinterpret_cast<uint64_t*>(ftile + n_tiles + (n_tiles & 1));
+    static_assert(sizeof(TileDesc) >= 8 + 8 + 4 + 8, "level-0 tables fit the tile descriptors");
+    if ((size_t)n_tiles * 20 + 16 + 16 * ((size_t)n_tiles / SCAN_CHUNK + 3) > (size_t)(n_tiles + 1) * sizeof(TileDesc)) return false;   // (a handful of tiles)
+    CAPS_LAUNCH(msd_tile_counts_kernel, (n_tiles + 255) / 256, 256, be, sd, (const uint64_t*)r.defer_flags, tcnt);
+    device_exclusive_scan<uint64_t>(be, tcnt, n_tiles, toff, ttmp);
+    CAPS_LAUNCH(msd_tile_list_kernel, (n_tiles + 255) / 256, 256, be, (const uint64_t*)tcnt, (const uint64_t*)toff, n_tiles, ftile);
+    uint64_t tot0 = 0;
+    be.d2h(&tot0, toff + n_tiles, sizeof tot0);
+    be.sync();
+    const uint64_t M0 = tot0 & MSD_ELEM_MASK, NF = tot0 >> 40;
+    if (NF == 0) return true;
+    if (M0 >= (1ull << 32) - 2 || NF > 0x7FFFFFFFull) return false;       // (member counts travel in 32 bits)
+    MsdArena ar;
+    const size_t per = sizeof(uint64_t) + 2 * sizeof(idx_t);
+    for (int c = 0; c < 2; ++c) {
+        ar.lo[c] = reinterpret_cast<char*>(r.buf[c].key);
+        ar.hi[c] = ar.lo[c] + std::min<size_t>(r.buf[c].region_bytes, (size_t)r.cap * per);
+    }
+    uint64_t* flags0 = ar.head<uint64_t>(M0, 0);
+    uint64_t* offs0 = ar.head<uint64_t>(M0 + 1, 1);
+    uint64_t* stmp = ar.head<uint64_t>(2 * (M0 / SCAN_CHUNK + 3), 1);
+    idx_t* wsa0 = ar.tail<idx_t>(M0);
+    uint64_t* segX = ar.tail<uint64_t>(M0 / 2 + 2);
+    uint64_t* gposX = ar.tail<uint64_t>(M0 / 2 + 2);
+    uint8_t* skip = ar.tail<uint8_t>(M0 / 2 + 2);
+    uint8_t* skip_tiles = ar.tail<uint8_t>(M0 / 2 + 2);
+    uint32_t* wgid = ar.tail<uint32_t>(M0);
+    uint32_t* flist = ar.tail<uint32_t>(M0);
+    uint64_t* edges = ar.tail<uint64_t>(M0 + 4);
+    uint64_t* out3 = ar.tail<uint64_t>(8);
+    if (ar.failed) return false;
+    CAPS_LAUNCH((msd_flags0_kernel<idx_t>), (uint32_t)NF, 256, be, sd, (const uint32_t*)ftile, (const uint64_t*)toff, (const idx_t*)LCP, flags0);
+    device_exclusive_scan<uint64_t>(be, flags0, (uint32_t)M0, offs0, stmp);
+    CAPS_LAUNCH((msd_compact0_kernel<idx_t>), (uint32_t)NF, 256, be, sd, (const uint32_t*)ftile, (const uint64_t*)toff, (const idx_t*)SA,
+                (const uint64_t*)flags0, (const uint64_t*)offs0, wsa0, segX, gposX, wgid);
+    CAPS_LAUNCH(msd_close_kernel, 1, 64, be, (const uint64_t*)(offs0 + M0), segX, out3);
+    uint64_t D = KCH;
+    auto finish = [&](const uint64_t* seg, const uint64_t* gpos, const idx_t* wsa, const uint32_t* gid, uint64_t m_bound) {
+        const uint32_t ggrid = (uint32_t)std::min<uint64_t>((m_bound / 2 + 255) / 256 + 1, 4ull * be.persistent_blocks());
+        CAPS_LAUNCH(msd_groups_kernel, ggrid, 256, be, seg, skip, skip_tiles, flist, out3);
+        const uint32_t grid = (uint32_t)std::min<uint64_t>((m_bound + MSD_FIN_MEMBERS - 1) / MSD_FIN_MEMBERS, 32ull * be.persistent_blocks());
+        if (be.long_runs) CAPS_LAUNCH((msd_finish_kernel<idx_t, BITS, true>), grid ? grid : 1, 256, be, P, n, D, seg, gpos, wsa, gid, (const uint32_t*)flist, SA, LCP, (const uint64_t*)out3);
+        else CAPS_LAUNCH((msd_finish_kernel<idx_t, BITS, false>), grid ? grid : 1, 256, be, P, n, D, seg, gpos, wsa, gid, (const uint32_t*)flist, SA, LCP, (const uint64_t*)out3);
+    };
+    CAPS_LAUNCH(msd_edges_kernel, (uint32_t)std::min<uint64_t>((M0 / 2 + 255) / 256 + 1, 4ull * be.persistent_blocks()), 256, be, (const uint64_t*)segX,
+                (const uint64_t*)gposX, (const uint64_t*)out3, edges);
+    finish(segX, gposX, wsa0, wgid, M0);
+    uint64_t h3[5] = {0, 0, 0, 0, 0};
+    be.d2h(h3, out3, sizeof h3);
+    be.sync();
+    uint64_t G = h3[0], m = h3[1], nopen = h3[2], gmax = h3[3], ntiled = h3[4];
+    r.msd_groups = G;
+    r.msd_elems = m;
+    // (when every group is in its final order: the LCPs at its two ends, see msd_edges_kernel)
+    const uint64_t n_edges = 2 * G;
+    auto fix_edges = [&]() {
+        if (n_edges) CAPS_LAUNCH((msd_fix_edges_kernel<idx_t, BITS>), (uint32_t)((n_edges + 255) / 256), 256, be, P, n, (const uint64_t*)edges, n_edges,
+                                 r.total, (const idx_t*)SA, LCP);
+    };
+    if (dbg) std::fprintf(stderr, "[msd] level 0: %llu flagged tiles, %llu elements in them, %llu groups of %llu members, %llu above %u (%llu above %u, largest %llu)\n",
+                          (unsigned long long)NF, (unsigned long long)M0, (unsigned long long)G, (unsigned long long)m, (unsigned long long)nopen, MSD_FIN_MAX,
+                          (unsigned long long)ntiled, MSD_RANK_MAX, (unsigned long long)gmax);
+    if (nopen == 0) { fix_edges(); return true; }
+    // ---- the levels: work arrays for m members in at most m / 2 groups; level 0's outputs stay where they are (chunk tails)
+    ar.lo[0] = reinterpret_cast<char*>(r.buf[0].key);                   // (flags0 / offs0 / stmp are dead)
+    ar.lo[1] = reinterpret_cast<char*>(r.buf[1].key);
+    const uint64_t cap2 = m + 2, Gm = m / 2 + 2, tiles_max = m / TILE_E + m / (MSD_RANK_MAX + 1) + 4;
+    ElemBuf<idx_t> E0, E1;
+    for (ElemBuf<idx_t>* e : {&E0, &E1}) {
+        char* base = reinterpret_cast<char*>(ar.head<uint64_t>(cap2 * per / sizeof(uint64_t) + 1, e == &E0 ? 0 : 1));
+        if (!base) return false;
+        e->key = reinterpret_cast<uint64_t*>(base);
+        e->sa = reinterpret_cast<idx_t*>(base + cap2 * sizeof(uint64_t));
+        e->lcp = e->sa + cap2;                                          // (sa | lcp contiguous: together they hold the scan of the flags)
+    }
+    uint64_t* segY = ar.head<uint64_t>(Gm);
+    uint64_t* gposY = ar.head<uint64_t>(Gm);
+    uint32_t* wgidY = ar.head<uint32_t>(cap2);
+    SegBufs ls;
+    ls.tile_off = ar.head<uint32_t>(Gm);
+    ls.tile_rec = ar.head<TileInfo>(tiles_max);
+    ls.out2 = ar.head<uint64_t>(2);
+    TileDesc* ldesc = ar.head<TileDesc>(tiles_max + 1);
+    uint64_t* big_cnt = ar.head<uint64_t>(Gm);
+    uint64_t* big_tmp = ar.head<uint64_t>(2 * (Gm / SCAN_CHUNK + 3));
+    uint64_t* ltmp = ar.head<uint64_t>(2 * (cap2 / SCAN_CHUNK + 3));
+    if (ar.failed) return false;
+    uint64_t *seg = segX, *gpos = gposX, *seg_n = segY, *gpos_n = gposY;
+    uint32_t *gid = wgid, *gid_n = wgidY;
+    const idx_t* in_sa = wsa0;
+    uint64_t* kin = E1.key;                                             // the level's keys before the sort; the flags after it
+    uint64_t* flags = E1.key;
+    uint64_t* offs = reinterpret_cast<uint64_t*>(E1.sa);
+    while (nopen > 0) {
+        const uint32_t mg = (uint32_t)((m + 255) / 256);
+        CAPS_LAUNCH((msd_rekey_kernel<idx_t, BITS>), mg, 256, be, P, n, D, m, (const uint32_t*)gid, (const uint8_t*)skip, in_sa, kin);
+        CAPS_LAUNCH((msd_ranksort_kernel<idx_t>), mg, 256, be, m, (const uint64_t*)seg, (const uint32_t*)gid, (const uint8_t*)skip, (const uint64_t*)kin,
+                    in_sa, E0.key, E0.sa);
+        if (ntiled) {                                   // groups above MSD_RANK_MAX: the segmented sort, tile by tile (+ merge passes above a tile)
+            ls.seg_start = seg;
+            ls.G = (uint32_t)G;
+            // (no read-back of the tile count: such groups have at most this many tiles, the kernels return on the rest)
+            const uint32_t lt = (uint32_t)std::min<uint64_t>(tiles_max, m / TILE_E + ntiled + 1);
+            prepare_segments(be, ls, lt, big_tmp, big_cnt, false, skip_tiles);
+            SortOpts o;
+            o.keys_only = true;                        // (key, position descending): no comparison reads the text
+            o.comparison_only = true;                  // few distinct keys per group: the bin sorts would pass every tile on
+            o.skip_finished = true;
+            o.unify = true;                            // everything ends in E0
+            o.in_key = kin;
+            o.in_sa = in_sa;
+            const SortResult<idx_t> rr = segmented_sort<idx_t, BITS>(be, P, n, ldesc, ls, lt, gmax, E0, E1, m, o);
+            if (rr.uniform().key != E0.key) return false;
+        }
+        CAPS_LAUNCH((msd_classify_kernel<idx_t, BITS>), mg, 256, be, n, D, m, (const uint64_t*)seg, (const uint32_t*)gid, (const uint8_t*)skip,
+                    (const uint64_t*)E0.key, (const idx_t*)E0.sa, (const uint64_t*)gpos, SA, LCP, flags);
+        device_exclusive_scan<uint64_t>(be, flags, (uint32_t)m, offs, ltmp);
+        CAPS_LAUNCH((msd_compact_kernel<idx_t>), mg, 256, be, m, (const uint64_t*)seg, (const uint32_t*)gid, (const idx_t*)E0.sa, (const uint64_t*)flags,
+                    (const uint64_t*)offs, (const uint64_t*)gpos, E0.lcp, seg_n, gpos_n, gid_n);
+        CAPS_LAUNCH(msd_close_kernel, 1, 64, be, (const uint64_t*)(offs + m), seg_n, out3);
+        D += KCH;
+        ++r.msd_levels;
+        std::swap(seg, seg_n);
+        std::swap(gpos, gpos_n);
+        std::swap(gid, gid_n);
+        in_sa = E0.lcp;
+        finish(seg, gpos, in_sa, gid, m);
+        be.d2h(h3, out3, sizeof h3);
+        be.sync();
+        G = h3[0];
+        m = h3[1];
+        nopen = h3[2];
+        gmax = h3[3];
+        ntiled = h3[4];
+        if (dbg) std::fprintf(stderr, "[msd] depth %llu: %llu groups of %llu members still open, %llu above %u (%llu above %u, largest %llu)\n", (unsigned long long)D,
+                              (unsigned long long)G, (unsigned long long)m, (unsigned long long)nopen, MSD_FIN_MAX, (unsigned long long)ntiled,
+                              MSD_RANK_MAX, (unsigned long long)gmax);
+        if (G > Gm - 1 || m > cap2 - 2) return false;                   // (cannot happen: both only shrink)
+    }
+    fix_edges();
+    return true;
+}
+
 // Gather SA/LCP of a sorted segment set into the caller's arrays + segment-head LCPs (a11).
 // With boundary records (r.fin) only the segments that needed merge passes are still to be
 // copied; the heads are then fixed from the records.
@@ -860,6 +1081,9 @@ void finalize(Backend& be, const uint32_t* P, uint64_t n, const SortResult<idx_t
         CAPS_LAUNCH((head_lcp_kernel<idx_t, BITS>), (r.segs.G + 255) / 256, 256, be, P, n, (const uint64_t*)r.segs.seg_start, r.segs.G,
                     r.fin, r.k32 ? 1u : 0u);
     if (!r.run_buckets.empty()) sort_run_buckets<idx_t, BITS>(be, P, n, r, dSA, dLCP);
+    // deferred ties last: the neighbours of a group never change their LCP with it (all members share the key, and a member
+    // whose suffix ends inside the key is placed -- first -- by the sort itself), so the head LCPs above stand
+    if (r.defer_flags && !std::getenv("CAPS_SA_DEBUG_NO_MSD") && !msd_refine<idx_t, BITS>(be, P, n, r, dSA, dLCP)) r.msd_failed = true;
 }
 
 // Shape of the direct path's two-level distribution: PG consecutive partitions per group, K1 groups.  Level A
@@ -985,6 +1209,8 @@ private:
     uint64_t max_part_ = 0;
     uint32_t path_direct_ = 0, path_fallback_ = 0, direct_groups_ = 0, direct_quantile_ = 0, direct_k32_ = 0, run_buckets_ = 0;
     uint64_t direct_max_group_ = 0;
+    uint64_t tie_groups_ = 0, tie_elems_ = 0;
+    uint32_t tie_levels_ = 0;
 
     // timed: the full-size sorts (phase 1, phase 2) feed the kernel clocks of caps_sa_stats;
     // their passes count the elements they really move in pl_.pass_elems[pass_base_ ...]
@@ -1218,7 +1444,7 @@ private:
     // Returns false (nothing of the result written) when the keys cannot balance the groups: two pivots with one key
     // or an overflowing group -- long repeats; the samplesort path then does the build.
     template <int BITS>
-    bool run_direct(idx_t* dSA, idx_t* dLCP, uint32_t PG, uint32_t K1, BackendEvent e1, bool allow_k32 = true)
+    bool run_direct(idx_t* dSA, idx_t* dLCP, uint32_t PG, uint32_t K1, BackendEvent e1, bool allow_k32 = true, bool defer = true)
     {
         const uint64_t n = pl_.n, m = pl_.m;
         const uint32_t p = pl_.p;
@@ -1402,8 +1628,14 @@ private:
         if (k32) { o2.k32 = true; o2.range_mode = 2; o2.gshift = pl_.gshift; }
         o2.in_key = a_key;
         o2.in_sa = a_sa;
+        // large groups of equal keys (tandem arrays, repeat families) are not compared through the text but re-keyed deeper after
+        // the sort (kernels.h "Deferred ties"); the flags live in the fine-count table, idle outside the equalised split
+        if (defer && !k32 && !std::getenv("CAPS_SA_NO_DEFER")) o2.defer_flags = pl_.bk.fcount;
+        o2.run_tables = &pl_.seg1;                    // (level A's one-segment tables: idle by now; the bucket tables stay intact)
         passes2_ = 0;
         run_buckets_ = 0;
+        tie_groups_ = tie_elems_ = 0;
+        tie_levels_ = 0;
         // wave boundaries: consecutive groups, about n / W suffixes each, never more than the scratch arrays hold
         std::vector<uint32_t> wave_end;
         if (W > 1) {
@@ -1452,10 +1684,16 @@ private:
             set_final(ow, dSA + base, dLCP + base);
             if (elems_w) {
                 SortResult<idx_t> r2 = seg_sort<BITS>(gw, n_tiles_w, max_len_w, W > 1 ? wave_scratch_ : pl_.A, pl_.B, elems_w, ow, true);
-                if (r2.failed) return run_direct<BITS>(dSA, dLCP, PG, K1, e1, false);      // a slot overflowed under 32-bit keys: again with 64
+                if (r2.failed) return run_direct<BITS>(dSA, dLCP, PG, K1, e1, false, defer);      // a slot overflowed under 32-bit keys: again with 64
                 passes2_ = std::max(passes2_, r2.passes);
                 run_buckets_ += (uint32_t)r2.run_buckets.size();
                 finalize<idx_t, BITS>(be_, pl_.P, n, r2, dSA + base, dLCP + base);
+                // the deferred groups did not fit the work memory (most of the text in large groups of equal keys): the whole
+                // build again, every tie settled by comparison as before
+                if (r2.msd_failed) return run_direct<BITS>(dSA, dLCP, PG, K1, e1, allow_k32, false);
+                tie_groups_ += r2.msd_groups;
+                tie_elems_ += r2.msd_elems;
+                tie_levels_ = std::max(tie_levels_, r2.msd_levels);
                 if (base) CAPS_LAUNCH((wave_head_lcp_kernel<idx_t, BITS>), 1, 64, be_, (const uint32_t*)pl_.P, n, (const idx_t*)dSA, dLCP, base);
             }
             if (sink_ && elems_w) sink_->wave_done(be_, base, elems_w);
@@ -1544,6 +1782,9 @@ private:
             st->direct_groups = direct_groups_;
             st->direct_quantile = direct_quantile_;
             st->run_buckets = run_buckets_;
+            st->tie_groups_deferred = tie_groups_;
+            st->tie_elems_deferred = tie_elems_;
+            st->tie_levels = tie_levels_;
             st->result_waves = sink_served_ ? waves_used_ : 1u;
             st->n_devices = 1;
             st->direct_key_bits = path_direct_ && direct_k32_ ? 32u : 64u;

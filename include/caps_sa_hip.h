@@ -86,6 +86,11 @@ typedef struct caps_sa_stats {
     double ms_upload_max, ms_upload_min;       /* text to the device (page-locked staging, all devices at once) */
     double ms_device_build_max, ms_device_build_min;   /* level A .. boundary LCPs of the device's slice */
     double ms_download_max, ms_download_min;   /* the device's slice of SA / LCP to the caller's arrays */
+    /* Groups of suffixes with one and the same key (64 / bits_per_char chars) that the sort did not settle by comparison but by
+     * re-keying them deeper, level by level, afterwards (csrc/kernels.h "Deferred ties": tandem arrays, repeat families), their
+     * members, and the deepest level (each 64 / bits_per_char chars). */
+    uint64_t tie_groups_deferred, tie_elems_deferred;
+    uint32_t tie_levels, reserved_;
 } caps_sa_stats;
 
 #define CAPS_SA_FB_NONE 0

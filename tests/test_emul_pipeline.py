@@ -611,3 +611,80 @@ def test_results_leave_in_waves_on_small_texts(oracle, monkeypatch):
     SA, LCP, st = E.build(uni, p=0)
     SAo, LCPo = oracle.build_sa_lcp(uni, p=64)
     assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo) and st["result_waves"] == 1
+
+
+def _repeat_rich(rs, n, alphabet=DNA):
+    """GRCh38-shaped repeat content in small (tools/genome_like.py plant_genome_repeats): a tandem array of a 57-char monomer with
+    2 % divergence, a higher-order array (unit of 5 monomers 20 % apart, units 0.7 % apart), 300 copies of a 60-char family at
+    10 %, one exact long duplicate, and the end of the text inside a repeat."""
+    T = rs.choice(alphabet, size=n)
+
+    def mutate(seg, rate):
+        seg = seg.copy()
+        m = rs.rand(seg.size) < rate
+        seg[m] = rs.choice(alphabet, size=int(m.sum()))
+        return seg
+    mono = rs.choice(alphabet, size=57)
+    a0, half = n // 10, n // 12
+    T[a0:a0 + half] = mutate(np.tile(mono, half // 57 + 1)[:half], 0.02)
+    unit = np.concatenate([mutate(mono, 0.2) for _ in range(5)])
+    T[a0 + half:a0 + 2 * half] = mutate(np.tile(unit, half // unit.size + 1)[:half], 0.007)
+    cons = rs.choice(alphabet, size=60)
+    for pos in rs.randint(n // 3, n - n // 8, size=300):
+        T[pos:pos + 60] = mutate(cons, 0.10)
+    T[n - n // 16:n - n // 16 + 3000] = T[n // 50:n // 50 + 3000]          # an exact duplicate
+    T[n - 700:] = np.tile(mono, 13)[:700]                                  # the text ends inside the tandem array's content
+    return T
+
+
+def test_large_groups_of_equal_keys_are_rekeyed_not_compared(monkeypatch):
+    """Deferred ties (kernels.h "Deferred ties", pipeline.h msd_refine): the tiles the equalised tile sort cannot finish and the
+    buckets larger than a tile order equal keys without reading the text and leave sentinel LCPs; the groups are then ordered
+    by re-keying them 32 chars deeper per level, small ones by direct comparison.  Tandem arrays, a repeat family, an exact
+    duplicate and a text that ends inside a repeat, 2-bit and 8-bit codes, both index widths; against the independent
+    construction of tests/sa_check.py (the oracle is quadratic on such texts), and against the build with CAPS_SA_NO_DEFER."""
+    from emul_util import emul_small
+    from sa_check import sa_lcp
+    E = emul_small()
+    rs = np.random.RandomState(47)
+    seen_levels = 0
+    for n, alphabet, bits in [(150_000, DNA, 32), (90_000, DNA, 64), (120_000, np.frombuffer(b"acgtn\x80\xfe", dtype=np.uint8), 32)]:
+        T = _repeat_rich(rs, n, alphabet)
+        SAo, LCPo = sa_lcp(T, idx_bits=bits)
+        for mode in (None, "quantile", "linear"):
+            if mode:
+                monkeypatch.setenv("CAPS_SA_DIRECT_MODE", mode)
+            else:
+                monkeypatch.delenv("CAPS_SA_DIRECT_MODE", raising=False)
+            SA, LCP, st = E.build(T, p=0, idx_bits=bits)
+            assert np.array_equal(SA, SAo), (n, bits, mode, st["path_direct"], st["tie_groups_deferred"])
+            assert np.array_equal(LCP, LCPo), (n, bits, mode)
+            if st["path_direct"]:
+                assert st["tie_groups_deferred"] > 0 and st["tie_elems_deferred"] >= 2 * st["tie_groups_deferred"], (n, mode, st)
+                seen_levels = max(seen_levels, st["tie_levels"])
+        monkeypatch.setenv("CAPS_SA_NO_DEFER", "1")
+        SA, LCP, st = E.build(T, p=0, idx_bits=bits)
+        monkeypatch.delenv("CAPS_SA_NO_DEFER")
+        assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo) and st["tie_groups_deferred"] == 0
+    assert seen_levels >= 2, seen_levels
+
+
+def test_a_suffix_that_ends_inside_the_key_of_a_deferred_group(oracle):
+    """Found by the -m gpu suite (test_skewed_and_texty_inputs_device): in a text of 70 % A's some suffix near the end of the text
+    has -- padded -- the key of a longer one; the stable merges of a sort that defers ties can leave it BEHIND the longer one, and
+    the LCP the sort emitted for the suffix after the pair was capped by its length.  The LCPs at both ends of every group are
+    taken from the text again once the groups are in order (msd_fix_edges_kernel)."""
+    from emul_util import emul_small
+    rs = np.random.RandomState(21)
+    T = rs.choice(DNA, size=3_000_000, p=[0.7, 0.1, 0.1, 0.1])
+    SAo, LCPo = oracle.build_sa_lcp(T, p=50)
+    SA, LCP, st = emul().build(T, p=50)
+    assert st["path_direct"] == 1 and st["tie_groups_deferred"] > 0
+    assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo)
+    for seed in range(6):                                   # the same shape at the 256-element tiles: many more group edges per suffix
+        rs = np.random.RandomState(100 + seed)
+        T = rs.choice(DNA, size=150_000 + seed, p=[0.72, 0.1, 0.1, 0.08])
+        T[-40:] = ord("A")                                  # the text ends in a run: every one of its suffixes ends inside a key
+        SAo, LCPo = oracle.build_sa_lcp(T, p=20)
+        SA, LCP, st = emul_small().build(T, p=20)
+        assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), seed

@@ -277,6 +277,8 @@ def test_genome_like_256mi_with_grch38_shaped_repeats_device(L, sa_path):
     assert L.verify_device(T.data_ptr(), n, SA.data_ptr(), LCP.data_ptr()) == 0
     assert st["path_direct"] == (0 if sa_path == "classic" else 1), st
     assert int(LCP.max().item()) >= 49_999
+    if sa_path != "classic":                         # the cluster tiles' ties were deferred and re-keyed, many levels deep
+        assert st["tie_groups_deferred"] > 1000 and st["tie_levels"] >= 8, (st["tie_groups_deferred"], st["tie_levels"])
 
 
 def test_sharded_driver_single_rank_rccl(L, sa_path):
@@ -815,3 +817,51 @@ def test_results_leave_in_waves_host_path(L, oracle, monkeypatch):
     assert L.verify_device(dT.data_ptr(), big.size, dSA.data_ptr(), dLCP.data_ptr()) == 0
     assert st["path_direct"] == 0 or st["result_waves"] == 1, st["result_waves"]
     L.release_cache()
+
+
+def _repeat_rich(rs, n, alphabet=DNA):
+    """GRCh38-shaped repeat content at oracle-checkable size (tools/genome_like.py plant_genome_repeats in small): a tandem array of
+    a 171-char monomer at 2 %, a higher-order array (12 monomers 20 % apart, units 0.7 % apart), 3000 copies of a 300-char family
+    at 10 %, one exact 20-kb duplicate, and a text that ends inside the tandem array's content."""
+    T = rs.choice(alphabet, size=n)
+
+    def mutate(seg, rate):
+        seg = seg.copy()
+        m = rs.rand(seg.size) < rate
+        seg[m] = rs.choice(alphabet, size=int(m.sum()))
+        return seg
+    mono = rs.choice(alphabet, size=171)
+    a0, half = n // 10, n // 12
+    T[a0:a0 + half] = mutate(np.tile(mono, half // 171 + 1)[:half], 0.02)
+    unit = np.concatenate([mutate(mono, 0.2) for _ in range(12)])
+    T[a0 + half:a0 + 2 * half] = mutate(np.tile(unit, half // unit.size + 1)[:half], 0.007)
+    cons = rs.choice(alphabet, size=300)
+    for pos in rs.randint(n // 3, n - n // 8, size=3000):
+        T[pos:pos + 300] = mutate(cons, 0.10)
+    T[n - n // 16:n - n // 16 + 20_000] = T[n // 50:n // 50 + 20_000]
+    T[n - 2000:] = np.tile(mono, 12)[:2000]
+    return T
+
+
+def test_large_groups_of_equal_keys_are_rekeyed_not_compared_device(L, oracle, monkeypatch):
+    """Deferred ties on the real kernels (kernels.h "Deferred ties", pipeline.h msd_refine) against the oracle: tandem arrays, a
+    repeat family, an exact duplicate and a text that ends inside a repeat -- thousands of suffixes share their key, the tiles that
+    hold them and the buckets larger than a tile leave sentinel LCPs, msd_refine orders the groups level by level.  2-bit and
+    8-bit codes, both index widths, both level-B modes; and the same arrays with CAPS_SA_NO_DEFER (every tie compared)."""
+    rs = np.random.RandomState(53)
+    for n, alphabet, bits in [(4_000_000, DNA, 32), (3_000_001, DNA, 64), (3_000_000, np.frombuffer(b"acgtn\x80\xfe", dtype=np.uint8), 32)]:
+        T = _repeat_rich(rs, n, alphabet)
+        SAo, LCPo = oracle.build_sa_lcp(T, p=800, idx_bits=bits)
+        for mode in (None, "quantile", "linear"):
+            if mode:
+                monkeypatch.setenv("CAPS_SA_DIRECT_MODE", mode)
+            else:
+                monkeypatch.delenv("CAPS_SA_DIRECT_MODE", raising=False)
+            SA, LCP, st = L.build(T, p=800, idx_bits=bits)
+            assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), (n, bits, mode)
+            assert st["path_direct"] == 1 and st["tie_groups_deferred"] > 0 and st["tie_levels"] >= 2, (n, mode, st["tie_groups_deferred"], st["tie_levels"])
+        monkeypatch.delenv("CAPS_SA_DIRECT_MODE", raising=False)
+        monkeypatch.setenv("CAPS_SA_NO_DEFER", "1")
+        SA, LCP, st = L.build(T, p=800, idx_bits=bits)
+        monkeypatch.delenv("CAPS_SA_NO_DEFER")
+        assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo) and st["tie_groups_deferred"] == 0
