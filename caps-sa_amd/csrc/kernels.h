@@ -3905,9 +3905,11 @@ template <typename idx_t>
 GLOBAL_FN LAUNCH_BOUNDS(256) msd_compact0_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ ftile, const uint64_t* __restrict__ toff,
                                                  const idx_t* __restrict__ SA, const uint64_t* __restrict__ flags,
                                                  const uint64_t* __restrict__ offs, idx_t* __restrict__ wsa,
-                                                 uint64_t* __restrict__ seg_start, uint64_t* __restrict__ gpos, uint32_t* __restrict__ wgid)
+                                                 uint64_t* __restrict__ seg_start, uint64_t* __restrict__ gpos, uint32_t* __restrict__ wgid,
+                                                 uint64_t* __restrict__ gdepth, uint64_t D0, uint64_t* __restrict__ gplen)
 {
-    // wgid[c] = the member's group (heads before it, itself included)
+    // gplen[g] = the size of the group this one was split off from (0: none): a group as large as its parent made no progress
+    // wgid[c] = the member's group (heads before it, itself included); gdepth[g] = D0: the chars the group's members are known to share
     const uint32_t b = ftile[K_BLOCK_IDX];
     const TileInfo t = tile_info(sd, b);
     const uint64_t start = t.s0 + (uint64_t)t.tl * TILE_E;
@@ -3920,7 +3922,7 @@ GLOBAL_FN LAUNCH_BOUNDS(256) msd_compact0_kernel(KCTX SegDesc sd, const uint32_t
                 const uint64_t o = offs[f0 + e], c = o & 0xFFFFFFFFull;
                 wsa[c] = SA[start + e];
                 wgid[c] = (uint32_t)((o >> 32) + (f >> 32)) - 1u;
-                if (f >> 32) { seg_start[o >> 32] = c; gpos[o >> 32] = start + e; }
+                if (f >> 32) { seg_start[o >> 32] = c; gpos[o >> 32] = start + e; gdepth[o >> 32] = D0; gplen[o >> 32] = 0; }
             }
         }
     }
@@ -3949,14 +3951,14 @@ constexpr uint32_t MSD_RANK_MAX = CAPS_MSD_RANK_MAX;        // groups up to this
 
 // key = the KCH chars behind the D known-equal ones
 template <typename idx_t, int BITS>
-GLOBAL_FN LAUNCH_BOUNDS(256) msd_rekey_kernel(KCTX const uint32_t* __restrict__ P, uint64_t n, uint64_t D, uint64_t m,
+GLOBAL_FN LAUNCH_BOUNDS(256) msd_rekey_kernel(KCTX const uint32_t* __restrict__ P, uint64_t n, const uint64_t* __restrict__ gdepth, uint64_t m,
                                               const uint32_t* __restrict__ wgid, const uint8_t* __restrict__ skip,
                                               const idx_t* __restrict__ wsa, uint64_t* __restrict__ wkey)
 {
     PAR(tid) {
         const uint64_t i = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
         if (i < m && !skip[wgid[i]]) {
-            const uint64_t pos = (uint64_t)wsa[i] + D;
+            const uint64_t pos = (uint64_t)wsa[i] + gdepth[wgid[i]];
             wkey[i] = pos < n ? window64<BITS>(P, pos) : 0;       // (a suffix that has ended: the pad, the smallest key)
         }
     }
@@ -3991,7 +3993,7 @@ GLOBAL_FN LAUNCH_BOUNDS(256) msd_ranksort_kernel(KCTX uint64_t m, const uint64_t
 
 // The groups sorted by (key, position descending): what is settled goes to SA / LCP, what is not is flagged for the next level.
 template <typename idx_t, int BITS>
-GLOBAL_FN LAUNCH_BOUNDS(256) msd_classify_kernel(KCTX uint64_t n, uint64_t D, uint64_t m, const uint64_t* __restrict__ seg_start,
+GLOBAL_FN LAUNCH_BOUNDS(256) msd_classify_kernel(KCTX uint64_t n, const uint64_t* __restrict__ gdepth, uint64_t m, const uint64_t* __restrict__ seg_start,
                                                  const uint32_t* __restrict__ wgid, const uint8_t* __restrict__ skip,
                                                  const uint64_t* __restrict__ key, const idx_t* __restrict__ sa,
                                                  const uint64_t* __restrict__ gpos, idx_t* __restrict__ SA, idx_t* __restrict__ LCP,
@@ -4003,7 +4005,7 @@ GLOBAL_FN LAUNCH_BOUNDS(256) msd_classify_kernel(KCTX uint64_t n, uint64_t D, ui
             const uint32_t g = wgid[i];
             uint64_t f = 0;
             if (!skip[g]) {
-                const uint64_t s0 = seg_start[g], s1 = seg_start[g + 1];
+                const uint64_t s0 = seg_start[g], s1 = seg_start[g + 1], D = gdepth[g];
                 const uint64_t k = key[i], a = (uint64_t)sa[i];
                 const uint64_t pos = gpos[g] + (i - s0);
                 bool tp = false;
@@ -4031,7 +4033,8 @@ GLOBAL_FN LAUNCH_BOUNDS(256) msd_compact_kernel(KCTX uint64_t m, const uint64_t*
                                                 const idx_t* __restrict__ sa, const uint64_t* __restrict__ flags,
                                                 const uint64_t* __restrict__ offs, const uint64_t* __restrict__ gpos_in,
                                                 idx_t* __restrict__ wsa, uint64_t* __restrict__ seg_start, uint64_t* __restrict__ gpos,
-                                                uint32_t* __restrict__ wgid_out)
+                                                uint32_t* __restrict__ wgid_out, const uint64_t* __restrict__ gdepth_in,
+                                                uint64_t* __restrict__ gdepth, uint32_t kch, uint64_t* __restrict__ gplen)
 {
     PAR(tid) {
         const uint64_t i = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
@@ -4042,7 +4045,43 @@ GLOBAL_FN LAUNCH_BOUNDS(256) msd_compact_kernel(KCTX uint64_t m, const uint64_t*
                 const uint64_t o = offs[i], c = o & 0xFFFFFFFFull;
                 wsa[c] = sa[i];
                 wgid_out[c] = (uint32_t)((o >> 32) + (f >> 32)) - 1u;
-                if (f >> 32) { seg_start[o >> 32] = c; gpos[o >> 32] = gpos_in[g] + (i - seg_in[g]); }
+                if (f >> 32) { seg_start[o >> 32] = c; gpos[o >> 32] = gpos_in[g] + (i - seg_in[g]); gdepth[o >> 32] = gdepth_in[g] + kch; gplen[o >> 32] = seg_in[g + 1] - seg_in[g]; }
+            }
+        }
+    }
+}
+
+// A group that came out of a level as large as it went in: its members agree far beyond the next window (copies of a long exact
+// repeat, suffixes at one offset of equally long letter runs: 32 chars per level would take thousands of levels).  Its depth jumps to
+// what ALL its members share: msd_jump_kernel -- one thread per member, its common prefix with the group's first member from the
+// known depth on (deep_scan: a periodic stretch costs one step), the minimum per group in gmin (stored inverted: an atomic
+// max; preset to 0) -- then msd_jump_apply_kernel rounds it down to whole windows.
+template <typename idx_t, int BITS, bool RUNS>
+GLOBAL_FN LAUNCH_BOUNDS(256) msd_jump_kernel(KCTX const uint32_t* __restrict__ P, uint64_t n, uint64_t m, const uint64_t* __restrict__ seg_start,
+                                             const uint32_t* __restrict__ wgid, const uint8_t* __restrict__ skip, const idx_t* __restrict__ wsa,
+                                             const uint64_t* __restrict__ gdepth, const uint64_t* __restrict__ gplen, uint64_t* __restrict__ gmin)
+{
+    PAR(tid) {
+        const uint64_t i = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (i < m) {
+            const uint32_t g = wgid[i];
+            const uint64_t s0 = seg_start[g];
+            if (!skip[g] && i != s0 && seg_start[g + 1] - s0 == gplen[g]) {
+                const uint64_t l = deep_lcp<BITS, RUNS>(P, n, (uint64_t)wsa[s0], (uint64_t)wsa[i], gdepth[g]);
+                ATOMIC_MAX_U64(&gmin[g], ~l);
+            }
+        }
+    }
+}
+GLOBAL_FN LAUNCH_BOUNDS(256) msd_jump_apply_kernel(KCTX const uint64_t* __restrict__ out3, const uint8_t* __restrict__ skip,
+                                                   const uint64_t* __restrict__ gmin, uint32_t kch, uint64_t* __restrict__ gdepth)
+{
+    const uint64_t G = out3[0];
+    PAR(tid) {
+        for (uint64_t g = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid; g < G; g += (uint64_t)K_GRID_DIM * K_BLOCK_DIM) {
+            if (!skip[g] && gmin[g]) {
+                const uint64_t d = (~gmin[g] / kch) * kch;
+                if (d > gdepth[g]) gdepth[g] = d;
             }
         }
     }
@@ -4138,7 +4177,7 @@ GLOBAL_FN LAUNCH_BOUNDS(256) msd_groups_kernel(KCTX const uint64_t* __restrict__
 constexpr uint32_t MSD_FIN_LANES = 8;
 constexpr uint32_t MSD_FIN_NT = 256, MSD_FIN_MEMBERS = MSD_FIN_NT / MSD_FIN_LANES;
 template <typename idx_t, int BITS, bool RUNS>
-GLOBAL_FN LAUNCH_BOUNDS(MSD_FIN_NT) msd_finish_kernel(KCTX const uint32_t* __restrict__ P, uint64_t n, uint64_t D, const uint64_t* __restrict__ seg_start,
+GLOBAL_FN LAUNCH_BOUNDS(MSD_FIN_NT) msd_finish_kernel(KCTX const uint32_t* __restrict__ P, uint64_t n, const uint64_t* __restrict__ gdepth, const uint64_t* __restrict__ seg_start,
                                                const uint64_t* __restrict__ gpos, const idx_t* __restrict__ wsa, const uint32_t* __restrict__ wgid,
                                                const uint32_t* __restrict__ flist, idx_t* __restrict__ SA, idx_t* __restrict__ LCP,
                                                const uint64_t* __restrict__ out3)
@@ -4154,7 +4193,7 @@ GLOBAL_FN LAUNCH_BOUNDS(MSD_FIN_NT) msd_finish_kernel(KCTX const uint32_t* __res
             if (base + q < m) {
                 const uint64_t i = flist[base + q];
                 const uint32_t g = wgid[i];
-                const uint64_t s0 = seg_start[g], len = seg_start[g + 1] - s0;
+                const uint64_t s0 = seg_start[g], len = seg_start[g + 1] - s0, D = gdepth[g];
                 const uint64_t a = (uint64_t)wsa[i];
                 uint32_t cnt = 0;
                 uint64_t bl = 0;

@@ -754,6 +754,12 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
     }
     r.total = n_elems;
     r.cap = n_elems;
+    // Deferring pays when the tiles the comparison sort gets are the exception (repeat families, tandem arrays in a genome).  A text
+    // in which they are the rule -- byte alphabets, whose 8-char keys tie all the time -- would flood the refinement (its work
+    // memory is the sort's own buffers): there every tie is compared, as before.  Decided before the comparison sort runs.
+    auto defer_check = [&](uint32_t tiles_to_compare) {
+        if (bflag && (uint64_t)tiles_to_compare * TILE_E > n_elems / 2) { bflag = nullptr; r.defer_flags = nullptr; }
+    };
     BackendEvent t0 = be.record();
     if (o.seg_ends && segs.seg_start == s.seg_start)
         throw std::invalid_argument("segments in fixed-capacity regions must be bucketed (results are written compactly)");
@@ -807,6 +813,12 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
             if (qn[0]) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false, true, false>), qn[0], TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
                         in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo2, redo3, 0u, (uint32_t*)nullptr);
             const uint32_t ng = qn[0] + qn[1];           // (the third stage may pass entries on: a bound)
+            if (bflag && qn[0]) {                        // ... the exact count for the decision to defer
+                uint32_t q3 = 0;
+                be.d2h(&q3, redo3, sizeof q3);
+                be.sync();
+                defer_check(q3);
+            } else defer_check(qn[1]);
             if (ng && be.long_runs)
                 CAPS_LAUNCH((tile_sort_general_kernel<idx_t, BITS, false, true, false>), ng, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
                             in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo3, 0u, bflag);
@@ -818,6 +830,12 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
                         in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo, redo3, 0u, redo2);
             if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false, true>), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
                         in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo2, redo3, 0u, (uint32_t*)nullptr);
+            if (bflag) {                                  // (one round trip, only where ties may be deferred)
+                uint32_t ng = 0;
+                be.d2h(&ng, redo3, sizeof ng);
+                be.sync();
+                defer_check(ng);
+            }
             CAPS_LAUNCH_RUNS(tile_sort_general_kernel, (idx_t, BITS, false), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
                         in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo3, 0u, bflag);
         }
@@ -825,6 +843,12 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
     }
     BackendEvent t1 = be.record();
     mark("tile sort");
+    if (dbg) {
+        uint32_t q[3] = {0, 0, 0};
+        be.d2h(&q[0], redo, 4); be.d2h(&q[1], redo2, 4); be.d2h(&q[2], redo3, 4);
+        be.sync();
+        std::fprintf(stderr, "[sort] queues after the tile sorts: %u %u %u of %u tiles, deferring %d\n", q[0], q[1], q[2], n_tiles, bflag ? 1 : 0);
+    }
     if (o.tile_clock) { o.tile_clock->spans.push_back({t0, t1}); o.tile_clock->elems.push_back(n_elems); }
     const uint32_t grid = n_tiles < be.persistent_blocks() ? n_tiles : be.persistent_blocks();
     ElemBuf<idx_t> a = cur, b = oth;
@@ -919,6 +943,7 @@ bool msd_refine(Backend& be, const uint32_t* P, uint64_t n, const SortResult<idx
     const uint32_t n_tiles = r.n_tiles;
     const bool dbg = std::getenv("CAPS_SA_DEBUG") != nullptr;
     if (!r.buf[0].region_bytes || !r.buf[1].region_bytes || !r.defer_desc) return false;
+    if (std::getenv("CAPS_SA_TEST_MSD_FAIL")) return false;             // tests: "the groups do not fit the work memory"
     // ---- level 0: which tiles hold sentinels (tables in the idle tile descriptors: 48 bytes per tile)
     char* dm = reinterpret_cast<char*>(r.defer_desc);
     uint64_t* tcnt = reinterpret_cast<uint64_t*>(dm);
@@ -945,32 +970,40 @@ bool msd_refine(Backend& be, const uint32_t* P, uint64_t n, const SortResult<idx
     uint64_t* flags0 = ar.head<uint64_t>(M0, 0);
     uint64_t* offs0 = ar.head<uint64_t>(M0 + 1, 1);
     uint64_t* stmp = ar.head<uint64_t>(2 * (M0 / SCAN_CHUNK + 3), 1);
-    idx_t* wsa0 = ar.tail<idx_t>(M0);
-    uint64_t* segX = ar.tail<uint64_t>(M0 / 2 + 2);
-    uint64_t* gposX = ar.tail<uint64_t>(M0 / 2 + 2);
-    uint8_t* skip = ar.tail<uint8_t>(M0 / 2 + 2);
-    uint8_t* skip_tiles = ar.tail<uint8_t>(M0 / 2 + 2);
-    uint32_t* wgid = ar.tail<uint32_t>(M0);
-    uint32_t* flist = ar.tail<uint32_t>(M0);
-    uint64_t* edges = ar.tail<uint64_t>(M0 + 4);
-    uint64_t* out3 = ar.tail<uint64_t>(8);
     if (ar.failed) return false;
     CAPS_LAUNCH((msd_flags0_kernel<idx_t>), (uint32_t)NF, 256, be, sd, (const uint32_t*)ftile, (const uint64_t*)toff, (const idx_t*)LCP, flags0);
     device_exclusive_scan<uint64_t>(be, flags0, (uint32_t)M0, offs0, stmp);
+    uint64_t tot1 = 0;
+    be.d2h(&tot1, offs0 + M0, sizeof tot1);
+    be.sync();                                         // members and groups: the rest of the work memory is sized by them, not by M0
+    const uint64_t m0 = tot1 & 0xFFFFFFFFull, G0 = tot1 >> 32;
+    if (m0 == 0) return true;
+    idx_t* wsa0 = ar.tail<idx_t>(m0 + 2);
+    uint64_t* segX = ar.tail<uint64_t>(m0 / 2 + 2);              // (later generations of the group table live here too: a group may split)
+    uint64_t* gposX = ar.tail<uint64_t>(m0 / 2 + 2);
+    uint64_t* gdepX = ar.tail<uint64_t>(m0 / 2 + 2);
+    uint64_t* gplX = ar.tail<uint64_t>(m0 / 2 + 2);
+    uint8_t* skip = ar.tail<uint8_t>(m0 / 2 + 2);
+    uint8_t* skip_tiles = ar.tail<uint8_t>(m0 / 2 + 2);
+    uint32_t* wgid = ar.tail<uint32_t>(m0 + 2);
+    uint32_t* flist = ar.tail<uint32_t>(m0 + 2);
+    uint64_t* edges = ar.tail<uint64_t>(2 * G0 + 4);
+    uint64_t* out3 = ar.tail<uint64_t>(8);
+    if (ar.failed) return false;
     CAPS_LAUNCH((msd_compact0_kernel<idx_t>), (uint32_t)NF, 256, be, sd, (const uint32_t*)ftile, (const uint64_t*)toff, (const idx_t*)SA,
-                (const uint64_t*)flags0, (const uint64_t*)offs0, wsa0, segX, gposX, wgid);
+                (const uint64_t*)flags0, (const uint64_t*)offs0, wsa0, segX, gposX, wgid, gdepX, (uint64_t)KCH, gplX);
     CAPS_LAUNCH(msd_close_kernel, 1, 64, be, (const uint64_t*)(offs0 + M0), segX, out3);
-    uint64_t D = KCH;
-    auto finish = [&](const uint64_t* seg, const uint64_t* gpos, const idx_t* wsa, const uint32_t* gid, uint64_t m_bound) {
+    uint64_t D = KCH;                                  // (the depth of the groups that never jumped: for the log)
+    auto finish = [&](const uint64_t* seg, const uint64_t* gpos, const uint64_t* gdep, const idx_t* wsa, const uint32_t* gid, uint64_t m_bound) {
         const uint32_t ggrid = (uint32_t)std::min<uint64_t>((m_bound / 2 + 255) / 256 + 1, 4ull * be.persistent_blocks());
         CAPS_LAUNCH(msd_groups_kernel, ggrid, 256, be, seg, skip, skip_tiles, flist, out3);
         const uint32_t grid = (uint32_t)std::min<uint64_t>((m_bound + MSD_FIN_MEMBERS - 1) / MSD_FIN_MEMBERS, 32ull * be.persistent_blocks());
-        if (be.long_runs) CAPS_LAUNCH((msd_finish_kernel<idx_t, BITS, true>), grid ? grid : 1, 256, be, P, n, D, seg, gpos, wsa, gid, (const uint32_t*)flist, SA, LCP, (const uint64_t*)out3);
-        else CAPS_LAUNCH((msd_finish_kernel<idx_t, BITS, false>), grid ? grid : 1, 256, be, P, n, D, seg, gpos, wsa, gid, (const uint32_t*)flist, SA, LCP, (const uint64_t*)out3);
+        if (be.long_runs) CAPS_LAUNCH((msd_finish_kernel<idx_t, BITS, true>), grid ? grid : 1, 256, be, P, n, gdep, seg, gpos, wsa, gid, (const uint32_t*)flist, SA, LCP, (const uint64_t*)out3);
+        else CAPS_LAUNCH((msd_finish_kernel<idx_t, BITS, false>), grid ? grid : 1, 256, be, P, n, gdep, seg, gpos, wsa, gid, (const uint32_t*)flist, SA, LCP, (const uint64_t*)out3);
     };
-    CAPS_LAUNCH(msd_edges_kernel, (uint32_t)std::min<uint64_t>((M0 / 2 + 255) / 256 + 1, 4ull * be.persistent_blocks()), 256, be, (const uint64_t*)segX,
+    CAPS_LAUNCH(msd_edges_kernel, (uint32_t)std::min<uint64_t>((G0 + 255) / 256 + 1, 4ull * be.persistent_blocks()), 256, be, (const uint64_t*)segX,
                 (const uint64_t*)gposX, (const uint64_t*)out3, edges);
-    finish(segX, gposX, wsa0, wgid, M0);
+    finish(segX, gposX, gdepX, wsa0, wgid, m0);
     uint64_t h3[5] = {0, 0, 0, 0, 0};
     be.d2h(h3, out3, sizeof h3);
     be.sync();
@@ -1001,6 +1034,9 @@ bool msd_refine(Backend& be, const uint32_t* P, uint64_t n, const SortResult<idx
     }
     uint64_t* segY = ar.head<uint64_t>(Gm);
     uint64_t* gposY = ar.head<uint64_t>(Gm);
+    uint64_t* gdepY = ar.head<uint64_t>(Gm);
+    uint64_t* gmin = ar.head<uint64_t>(Gm);
+    uint64_t* gplY = ar.head<uint64_t>(Gm);
     uint32_t* wgidY = ar.head<uint32_t>(cap2);
     SegBufs ls;
     ls.tile_off = ar.head<uint32_t>(Gm);
@@ -1011,7 +1047,7 @@ bool msd_refine(Backend& be, const uint32_t* P, uint64_t n, const SortResult<idx
     uint64_t* big_tmp = ar.head<uint64_t>(2 * (Gm / SCAN_CHUNK + 3));
     uint64_t* ltmp = ar.head<uint64_t>(2 * (cap2 / SCAN_CHUNK + 3));
     if (ar.failed) return false;
-    uint64_t *seg = segX, *gpos = gposX, *seg_n = segY, *gpos_n = gposY;
+    uint64_t *seg = segX, *gpos = gposX, *seg_n = segY, *gpos_n = gposY, *gdep = gdepX, *gdep_n = gdepY, *gpl = gplX, *gpl_n = gplY;
     uint32_t *gid = wgid, *gid_n = wgidY;
     const idx_t* in_sa = wsa0;
     uint64_t* kin = E1.key;                                             // the level's keys before the sort; the flags after it
@@ -1019,7 +1055,14 @@ bool msd_refine(Backend& be, const uint32_t* P, uint64_t n, const SortResult<idx
     uint64_t* offs = reinterpret_cast<uint64_t*>(E1.sa);
     while (nopen > 0) {
         const uint32_t mg = (uint32_t)((m + 255) / 256);
-        CAPS_LAUNCH((msd_rekey_kernel<idx_t, BITS>), mg, 256, be, P, n, D, m, (const uint32_t*)gid, (const uint8_t*)skip, in_sa, kin);
+        if (r.msd_levels) {                             // a group the last level left as it was jumps to what all its members share
+            const uint32_t gg = (uint32_t)std::min<uint64_t>((G + 255) / 256 + 1, 4ull * be.persistent_blocks());
+            be.memset(gmin, 0, (size_t)G * sizeof(uint64_t));
+            if (be.long_runs) CAPS_LAUNCH((msd_jump_kernel<idx_t, BITS, true>), mg, 256, be, P, n, m, (const uint64_t*)seg, (const uint32_t*)gid, (const uint8_t*)skip, in_sa, (const uint64_t*)gdep, (const uint64_t*)gpl, gmin);
+            else CAPS_LAUNCH((msd_jump_kernel<idx_t, BITS, false>), mg, 256, be, P, n, m, (const uint64_t*)seg, (const uint32_t*)gid, (const uint8_t*)skip, in_sa, (const uint64_t*)gdep, (const uint64_t*)gpl, gmin);
+            CAPS_LAUNCH(msd_jump_apply_kernel, gg, 256, be, (const uint64_t*)out3, (const uint8_t*)skip, (const uint64_t*)gmin, KCH, gdep);
+        }
+        CAPS_LAUNCH((msd_rekey_kernel<idx_t, BITS>), mg, 256, be, P, n, (const uint64_t*)gdep, m, (const uint32_t*)gid, (const uint8_t*)skip, in_sa, kin);
         CAPS_LAUNCH((msd_ranksort_kernel<idx_t>), mg, 256, be, m, (const uint64_t*)seg, (const uint32_t*)gid, (const uint8_t*)skip, (const uint64_t*)kin,
                     in_sa, E0.key, E0.sa);
         if (ntiled) {                                   // groups above MSD_RANK_MAX: the segmented sort, tile by tile (+ merge passes above a tile)
@@ -1038,19 +1081,21 @@ bool msd_refine(Backend& be, const uint32_t* P, uint64_t n, const SortResult<idx
             const SortResult<idx_t> rr = segmented_sort<idx_t, BITS>(be, P, n, ldesc, ls, lt, gmax, E0, E1, m, o);
             if (rr.uniform().key != E0.key) return false;
         }
-        CAPS_LAUNCH((msd_classify_kernel<idx_t, BITS>), mg, 256, be, n, D, m, (const uint64_t*)seg, (const uint32_t*)gid, (const uint8_t*)skip,
+        CAPS_LAUNCH((msd_classify_kernel<idx_t, BITS>), mg, 256, be, n, (const uint64_t*)gdep, m, (const uint64_t*)seg, (const uint32_t*)gid, (const uint8_t*)skip,
                     (const uint64_t*)E0.key, (const idx_t*)E0.sa, (const uint64_t*)gpos, SA, LCP, flags);
         device_exclusive_scan<uint64_t>(be, flags, (uint32_t)m, offs, ltmp);
         CAPS_LAUNCH((msd_compact_kernel<idx_t>), mg, 256, be, m, (const uint64_t*)seg, (const uint32_t*)gid, (const idx_t*)E0.sa, (const uint64_t*)flags,
-                    (const uint64_t*)offs, (const uint64_t*)gpos, E0.lcp, seg_n, gpos_n, gid_n);
+                    (const uint64_t*)offs, (const uint64_t*)gpos, E0.lcp, seg_n, gpos_n, gid_n, (const uint64_t*)gdep, gdep_n, KCH, gpl_n);
         CAPS_LAUNCH(msd_close_kernel, 1, 64, be, (const uint64_t*)(offs + m), seg_n, out3);
         D += KCH;
         ++r.msd_levels;
         std::swap(seg, seg_n);
         std::swap(gpos, gpos_n);
         std::swap(gid, gid_n);
+        std::swap(gdep, gdep_n);
+        std::swap(gpl, gpl_n);
         in_sa = E0.lcp;
-        finish(seg, gpos, in_sa, gid, m);
+        finish(seg, gpos, gdep, in_sa, gid, m);
         be.d2h(h3, out3, sizeof h3);
         be.sync();
         G = h3[0];

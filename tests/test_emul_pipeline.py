@@ -625,12 +625,12 @@ def _repeat_rich(rs, n, alphabet=DNA):
         seg[m] = rs.choice(alphabet, size=int(m.sum()))
         return seg
     mono = rs.choice(alphabet, size=57)
-    a0, half = n // 10, n // 12
+    a0, half = n // 10, n // 30
     T[a0:a0 + half] = mutate(np.tile(mono, half // 57 + 1)[:half], 0.02)
     unit = np.concatenate([mutate(mono, 0.2) for _ in range(5)])
     T[a0 + half:a0 + 2 * half] = mutate(np.tile(unit, half // unit.size + 1)[:half], 0.007)
     cons = rs.choice(alphabet, size=60)
-    for pos in rs.randint(n // 3, n - n // 8, size=300):
+    for pos in rs.randint(n // 3, n - n // 8, size=100):
         T[pos:pos + 60] = mutate(cons, 0.10)
     T[n - n // 16:n - n // 16 + 3000] = T[n // 50:n // 50 + 3000]          # an exact duplicate
     T[n - 700:] = np.tile(mono, 13)[:700]                                  # the text ends inside the tandem array's content
@@ -666,7 +666,46 @@ def test_large_groups_of_equal_keys_are_rekeyed_not_compared(monkeypatch):
         SA, LCP, st = E.build(T, p=0, idx_bits=bits)
         monkeypatch.delenv("CAPS_SA_NO_DEFER")
         assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo) and st["tie_groups_deferred"] == 0
+        # the groups do not fit the work memory (forced): the build is done again with every tie compared
+        monkeypatch.delenv("CAPS_SA_DIRECT_MODE", raising=False)
+        monkeypatch.setenv("CAPS_SA_TEST_MSD_FAIL", "1")
+        for waves in (None, "3"):
+            if waves:
+                monkeypatch.setenv("CAPS_SA_HOST_WAVES", waves)
+            SA, LCP, st = E.build(T, p=0, idx_bits=bits)
+            assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo) and st["tie_groups_deferred"] == 0 and st["path_direct"] == 1
+        monkeypatch.delenv("CAPS_SA_TEST_MSD_FAIL")
+        # ... and results that leave in waves: every wave settles its own groups before its slice is copied out
+        SA, LCP, st = E.build(T, p=0, idx_bits=bits)
+        monkeypatch.delenv("CAPS_SA_HOST_WAVES")
+        assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo) and st["tie_groups_deferred"] > 0 and st["result_waves"] >= 2
     assert seen_levels >= 2, seen_levels
+
+
+def test_deferred_groups_that_agree_for_thousands_of_chars_jump(monkeypatch):
+    """Found on the genome-like text with N-block stand-ins (bench g3n: 100 single-letter runs of 50,000): the suffixes that start one
+    char before such a run -- 45 of them with the same char -- share 50,001 chars; 32 chars per level were 1,500 levels (98 -> 181 ms).
+    A level that settles nothing makes every open group jump to what all its members share (msd_jump_kernel; the run table makes a
+    periodic stretch one step).  Here: 40 runs of 1,200 G's behind an A, 36 exact copies of a 2,500-char segment, and both at once."""
+    from emul_util import emul_small
+    from sa_check import sa_lcp
+    E = emul_small()
+    rs = np.random.RandomState(61)
+    n = 400_000
+    T = rs.choice(DNA, size=n)
+    for k in range(40):
+        a = 5_000 + k * 9_000
+        T[a] = ord("A")
+        T[a + 1:a + 1_201] = ord("G")
+        T[a + 1_201] = DNA[k % 3 if k % 3 != 2 else 3]          # terminators A / C / T
+    seg = rs.choice(DNA, size=2_500)
+    for k in range(36):
+        a = 9_500 + k * 9_000
+        T[a:a + 2_500] = seg
+    SAo, LCPo = sa_lcp(T)
+    SA, LCP, st = E.build(T, p=0)
+    assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo)
+    assert st["path_direct"] == 1 and st["tie_groups_deferred"] > 0 and st["tie_levels"] <= 4, (st["tie_groups_deferred"], st["tie_levels"])
 
 
 def test_a_suffix_that_ends_inside_the_key_of_a_deferred_group(oracle):

@@ -831,12 +831,12 @@ def _repeat_rich(rs, n, alphabet=DNA):
         seg[m] = rs.choice(alphabet, size=int(m.sum()))
         return seg
     mono = rs.choice(alphabet, size=171)
-    a0, half = n // 10, n // 12
+    a0, half = n // 10, n // 80
     T[a0:a0 + half] = mutate(np.tile(mono, half // 171 + 1)[:half], 0.02)
     unit = np.concatenate([mutate(mono, 0.2) for _ in range(12)])
     T[a0 + half:a0 + 2 * half] = mutate(np.tile(unit, half // unit.size + 1)[:half], 0.007)
     cons = rs.choice(alphabet, size=300)
-    for pos in rs.randint(n // 3, n - n // 8, size=3000):
+    for pos in rs.randint(n // 3, n - n // 8, size=400):
         T[pos:pos + 300] = mutate(cons, 0.10)
     T[n - n // 16:n - n // 16 + 20_000] = T[n // 50:n // 50 + 20_000]
     T[n - 2000:] = np.tile(mono, 12)[:2000]
@@ -859,7 +859,9 @@ def test_large_groups_of_equal_keys_are_rekeyed_not_compared_device(L, oracle, m
                 monkeypatch.delenv("CAPS_SA_DIRECT_MODE", raising=False)
             SA, LCP, st = L.build(T, p=800, idx_bits=bits)
             assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), (n, bits, mode)
-            assert st["path_direct"] == 1 and st["tie_groups_deferred"] > 0 and st["tie_levels"] >= 2, (n, mode, st["tie_groups_deferred"], st["tie_levels"])
+            assert st["path_direct"] == 1
+            if alphabet is DNA:     # (8-char keys of a byte alphabet tie all the time: most tiles would be deferred, so none is -- segmented_sort defer_check)
+                assert st["tie_groups_deferred"] > 0 and st["tie_levels"] >= 2, (n, mode, st["tie_groups_deferred"], st["tie_levels"])
         monkeypatch.delenv("CAPS_SA_DIRECT_MODE", raising=False)
         monkeypatch.setenv("CAPS_SA_NO_DEFER", "1")
         SA, LCP, st = L.build(T, p=800, idx_bits=bits)
