@@ -48,3 +48,50 @@ def sa_lcp(T, idx_bits: int = 32):
         else:
             h = 0
     return sa.astype(dt), np.array(lcp, dtype=dt)
+
+
+def check_bounded(T, SA, LCP, ctx: int) -> dict:
+    """Independent check of a BOUNDED-CONTEXT result (0 < ctx < n; reference src/Suffix_Array.cpp:57-95 with max_context): shares no
+    code with csrc/bounded.h or the oracle.  What the reference's merges guarantee whatever their history:
+      * SA is a permutation of 0 .. n-1;
+      * neighbours are in order under the comparison the merge makes -- the first ctx chars, then the char behind them
+        (cpp:76-77 reads T[x + n] with n = ctx), a suffix that ends first sorting first -- i.e. non-decreasing in their
+        first ctx + 1 chars; ties (ctx + 1 equal chars) may stand in any order: the merge history decides, this check cannot;
+      * LCP[0] = 0 and min(lcp, ctx) <= LCP[i] <= lcp for the true lcp of the neighbours (the boundary LCPs of
+        compute_partition_boundary_lcp, cpp:431-447, are not cut at ctx).
+    Returns counts of violations (all zero = passed).  numpy, O(n * ctx)."""
+    T = np.ascontiguousarray(np.asarray(T, dtype=np.uint8))
+    n = T.size
+    SA = np.asarray(SA).astype(np.int64)
+    LCP = np.asarray(LCP).astype(np.int64)
+    res = {"not_a_permutation": 0, "order": 0, "lcp_low": 0, "lcp_high": 0, "lcp0": int(n > 0 and LCP[0] != 0)}
+    if n == 0:
+        return res
+    seen = np.zeros(n, dtype=bool)
+    ok = (SA >= 0) & (SA < n)
+    seen[SA[ok]] = True
+    res["not_a_permutation"] = int(n - seen.sum()) + int((~ok).sum())
+    if res["not_a_permutation"] or n == 1:
+        return res
+    t = np.concatenate([T.view(np.int8).astype(np.int16), np.full(ctx + 2, -1000, dtype=np.int16)])   # past the end: smaller than any char
+    a, b = SA[:-1], SA[1:]
+    l = np.zeros(n - 1, dtype=np.int64)
+    live = np.ones(n - 1, dtype=bool)
+    for k in range(ctx + 1):                       # lcp of the neighbours, capped at ctx + 1
+        same = live & (t[a + k] == t[b + k]) & (a + k < n) & (b + k < n)
+        l += same
+        live = same
+    tied = l >= ctx + 1
+    ca, cb = t[a + l], t[b + l]                    # first differing char (or the end marker of the one that ended)
+    res["order"] = int((~tied & ~(ca < cb)).sum())
+    got = LCP[1:]
+    res["lcp_low"] = int((got < np.minimum(l, ctx)).sum())
+    # the upper bound needs the full lcp only where the reported value exceeds the capped one
+    over = np.nonzero(got > np.minimum(l, ctx))[0]
+    for i in over.tolist():
+        x, y, full = int(a[i]), int(b[i]), 0
+        while x + full < n and y + full < n and T[x + full] == T[y + full]:
+            full += 1
+        if got[i] > full:
+            res["lcp_high"] += 1
+    return res

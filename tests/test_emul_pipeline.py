@@ -111,6 +111,34 @@ def test_bounded_context_follows_the_reference_merge_history(oracle):
         E.build(T[:20], max_context=3)
 
 
+def test_bounded_context_passes_an_independent_check(oracle):
+    """tests/sa_check.py check_bounded shares no code with csrc/bounded.h or the oracle -- permutation,
+    neighbours in order on their first ctx + 1 chars (the char behind the context decides, src/Suffix_Array.cpp:76-77), LCPs between
+    min(lcp, ctx) and lcp.  It accepts what the oracle and the kernels produce and catches a swapped pair and a wrong LCP; the
+    order of TIES (ctx + 1 equal chars) is the merge history's, which only the oracle comparison above pins."""
+    from sa_check import check_bounded
+    E = emul()
+    rs = np.random.RandomState(9)
+    S = rs.choice(DNA, size=2000)
+    for T, p, ctx in [(rs.choice(DNA, size=12000), 11, 5), (rs.choice(DNA, size=5000), 0, 1), (np.concatenate([S, S, S]), 6, 40),
+                      (np.full(3000, ord("A"), np.uint8), 4, 7), (rs.choice(np.frombuffer(b"ab\x80\xff", dtype=np.uint8), size=9000), 5, 3)]:
+        for SA, LCP in (oracle.build_sa_lcp(T, p=p, max_context=ctx)[:2], E.build(T, p=p, max_context=ctx)[:2]):
+            r = check_bounded(T, SA, LCP, ctx)
+            assert not any(r.values()), (T.size, p, ctx, r)
+        j = next((j for j in range(T.size // 3, T.size - 1) if LCP[j + 1] < ctx), None)
+        if j is not None:
+            S2 = SA.copy()
+            S2[j], S2[j + 1] = S2[j + 1], S2[j]
+            assert check_bounded(T, S2, LCP, ctx)["order"] >= 1
+        L2 = LCP.copy()
+        k = int(np.argmax(LCP > 0))
+        L2[k] -= 1
+        assert check_bounded(T, SA, L2, ctx)["lcp_low"] == 1
+        S3 = SA.copy()
+        S3[5] = S3[6]
+        assert check_bounded(T, S3, LCP, ctx)["not_a_permutation"] >= 1
+
+
 def test_kernel_level_entry_points(oracle):
     E = emul()
     rs = np.random.RandomState(7)

@@ -144,6 +144,10 @@ def test_bounded_context_follows_the_reference_merge_history(L, oracle):
         SAo, LCPo = oracle.build_sa_lcp(T, p=p, max_context=ctx, idx_bits=bits)[:2]
         assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), (T.size, p, ctx, bits)
         assert st["path_fallback"] == 7                      # CAPS_SA_FB_BOUNDED
+        # ... and the check that shares no code with bounded.h or the oracle (tests/sa_check.py check_bounded: permutation, neighbours
+        # in order on their first ctx + 1 chars, LCPs between min(lcp, ctx) and lcp; it cannot pin the order of ties)
+        from sa_check import check_bounded
+        assert not any(check_bounded(T, SA, LCP, ctx).values()), (T.size, p, ctx, check_bounded(T, SA, LCP, ctx))
     T = rs.choice(DNA, size=1000)
     a, b = L.build(T, max_context=1000), L.build(T)          # >= n is unbounded
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
