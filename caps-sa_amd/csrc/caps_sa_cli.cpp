@@ -54,6 +54,12 @@ template <typename idx_t>
 static int run(const std::string& text, const std::string& out_path, size_t p, size_t ctx, bool pretty, const std::vector<int>& devices)
 {
     if (p > std::numeric_limits<idx_t>::max()) { std::cerr << "subproblem-count does not fit the index type\n"; return EXIT_FAILURE; }
+    // the bounded-context mode replays the reference's merge history, one GPU thread per merge node -- the top levels
+    // of its trees are sequential merges of O(n) elements (9.5 s at 64 Mi chars; the reference itself: 67 s on one thread there).
+    // Say so before a genome-sized run looks like a hang.
+    if (ctx != 0 && ctx < text.size() && text.size() >= (size_t(64) << 20))
+        std::cerr << "bounded-context " << ctx << ": compatibility mode (csrc/bounded.h), about " << (text.size() >> 20) * 0.15
+                  << " seconds for " << (text.size() >> 20) << " Mi chars; the unbounded construction takes milliseconds.\n";
     CaPS_SA::Suffix_Array<idx_t> suf_arr(text.c_str(), static_cast<idx_t>(text.size()), static_cast<idx_t>(p),
                                          static_cast<idx_t>(ctx >= text.size() ? 0 : ctx), devices);
     suf_arr.construct();
