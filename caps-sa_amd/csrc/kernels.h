@@ -3840,9 +3840,6 @@ GLOBAL_FN LAUNCH_BOUNDS(256) lcp_pairs_kernel(KCTX const uint32_t* __restrict__ 
 #ifndef CAPS_MSD_FIN_MAX
 #define CAPS_MSD_FIN_MAX 32
 #endif
-#ifndef CAPS_MSD_RANK_MAX
-#define CAPS_MSD_RANK_MAX 256
-#endif
 constexpr uint32_t MSD_FIN_MAX = CAPS_MSD_FIN_MAX;
 constexpr uint64_t MSD_TILE_BIT = 1ull << 40;             // tile counts: elements in the low 40 bits, tiles above
 constexpr uint64_t MSD_ELEM_MASK = MSD_TILE_BIT - 1;
@@ -3939,15 +3936,16 @@ GLOBAL_FN LAUNCH_BOUNDS(64) msd_close_kernel(KCTX const uint64_t* __restrict__ t
             out3[1] = m;
             out3[2] = 0;                               // groups larger than MSD_FIN_MAX (msd_finish_kernel counts them),
             out3[3] = 0;                               //   the largest of them,
-            out3[4] = 0;                               //   those above MSD_RANK_MAX (sorted tile by tile),
-            out3[5] = 0;                               //   members listed for msd_finish_kernel
+            out3[4] = 0;                               //   (the same count: they are sorted tile by tile),
+            out3[5] = 0;                               //   members listed for msd_finish_kernel,
+            out3[6] = 0;                               //   groups listed for msd_quick_kernel
         }
     }
 }
 
 // ---- one level.  Everything below is one THREAD per member of the work array (wgid: its group; skip[g] != 0: the group is
 // finished -- its members are dead weight until the next compaction drops them).
-constexpr uint32_t MSD_RANK_MAX = CAPS_MSD_RANK_MAX;        // groups up to this size are sorted by counting (msd_ranksort_kernel), larger ones tile by tile
+constexpr uint32_t MSD_QK_MAX = TILE_E;       // groups up to this size are finished in LDS (msd_quick_kernel); only larger ones see another level
 
 // key = the KCH chars behind the D known-equal ones
 template <typename idx_t, int BITS>
@@ -3960,33 +3958,6 @@ GLOBAL_FN LAUNCH_BOUNDS(256) msd_rekey_kernel(KCTX const uint32_t* __restrict__ 
         if (i < m && !skip[wgid[i]]) {
             const uint64_t pos = (uint64_t)wsa[i] + gdepth[wgid[i]];
             wkey[i] = pos < n ? window64<BITS>(P, pos) : 0;       // (a suffix that has ended: the pad, the smallest key)
-        }
-    }
-}
-
-// groups of at most MSD_RANK_MAX members, sorted by (key, position descending): every member counts the smaller ones of its group
-// (late levels hold thousands of groups of a few dozen members: a workgroup per group would be all overhead)
-template <typename idx_t>
-GLOBAL_FN LAUNCH_BOUNDS(256) msd_ranksort_kernel(KCTX uint64_t m, const uint64_t* __restrict__ seg_start, const uint32_t* __restrict__ wgid,
-                                                 const uint8_t* __restrict__ skip, const uint64_t* __restrict__ wkey,
-                                                 const idx_t* __restrict__ wsa, uint64_t* __restrict__ okey, idx_t* __restrict__ osa)
-{
-    PAR(tid) {
-        const uint64_t i = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid;
-        if (i < m) {
-            const uint32_t g = wgid[i];
-            const uint64_t s0 = seg_start[g], s1 = seg_start[g + 1];
-            if (!skip[g] && s1 - s0 <= MSD_RANK_MAX) {
-                const uint64_t k = wkey[i];
-                const idx_t a = wsa[i];
-                uint32_t rank = 0;
-                for (uint64_t j = s0; j < s1; ++j) {
-                    const uint64_t kj = wkey[j];
-                    rank += (kj < k || (kj == k && wsa[j] > a)) ? 1u : 0u;
-                }
-                okey[s0 + rank] = k;
-                osa[s0 + rank] = a;
-            }
         }
     }
 }
@@ -4116,35 +4087,37 @@ GLOBAL_FN LAUNCH_BOUNDS(256) msd_fix_edges_kernel(KCTX const uint32_t* __restric
     }
 }
 
-// The groups of a level, one thread each: a group of at most MSD_FIN_MAX members is listed for msd_finish_kernel (flist: the
-// indices of its members, out3[5] of them in all) and taken out (skip[g] = 1); larger ones are counted: out3[2] above MSD_FIN_MAX,
-// the largest in out3[3], out3[4] above MSD_RANK_MAX (skip_tiles[g] = 0: sorted tile by tile in the next level).
+// The groups of a level, one thread each.  At most MSD_FIN_MAX members: listed for msd_finish_kernel (flist: the indices of its
+// members, out3[5] of them in all).  At most MSD_QK_MAX: listed for msd_quick_kernel (qlist: the group, out3[6] of them).  Both are
+// taken out (skip[g] = skip_tiles[g] = 1).  Larger ones go through another level: out3[2] = out3[4] counts them, out3[3] = the largest.
 GLOBAL_FN LAUNCH_BOUNDS(256) msd_groups_kernel(KCTX const uint64_t* __restrict__ seg_start, uint8_t* __restrict__ skip, uint8_t* __restrict__ skip_tiles,
-                                               uint32_t* __restrict__ flist, uint64_t* __restrict__ out3)
+                                               uint32_t* __restrict__ flist, uint32_t* __restrict__ qlist, uint64_t* __restrict__ out3)
 {
-    // (a workgroup reserves its share of the list and adds its counts with ONE global atomic each: a million groups bumping four
+    // (a workgroup reserves its share of the lists and adds its counts with ONE global atomic each: a million groups bumping the
     // counters one by one took longer than finishing them)
-    SHARED_ARRAY(uint32_t, acc, 4);            // [0] members listed by this workgroup, [1] groups above FIN_MAX, [2] above RANK_MAX, [3] largest
-    SHARED_ARRAY(uint64_t, at0, 1);
+    SHARED_ARRAY(uint32_t, acc, 4);            // [0] members listed by this workgroup, [1] groups for the quick kernel, [2] larger ones, [3] largest
+    SHARED_ARRAY(uint64_t, at0, 2);
     const uint64_t G = out3[0];
     for (uint64_t gb = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM; gb < G; gb += (uint64_t)K_GRID_DIM * K_BLOCK_DIM) {
         TL_DECL(uint32_t, mine, 1);
+        TL_DECL(uint32_t, mineq, 1);
         PAR(tid) { if (tid < 4) acc[tid] = 0; }
         SYNC();
         PAR(tid) {
             const uint64_t g = gb + tid;
             TL(mine, tid, 0) = ~0u;
+            TL(mineq, tid, 0) = ~0u;
             if (g < G) {
                 const uint64_t len = seg_start[g + 1] - seg_start[g];
-                if (len <= MSD_FIN_MAX) {
-                    TL(mine, tid, 0) = FETCH_ADD_U32(&acc[0], (uint32_t)len);
+                if (len <= MSD_QK_MAX) {
+                    if (len <= MSD_FIN_MAX) TL(mine, tid, 0) = FETCH_ADD_U32(&acc[0], (uint32_t)len);
+                    else TL(mineq, tid, 0) = FETCH_ADD_U32(&acc[1], 1u);
                     skip[g] = 1;
                     skip_tiles[g] = 1;
                 } else {
                     skip[g] = 0;
-                    skip_tiles[g] = len > MSD_RANK_MAX ? 0 : 1;
-                    FETCH_ADD_U32(&acc[1], 1u);
-                    if (len > MSD_RANK_MAX) FETCH_ADD_U32(&acc[2], 1u);
+                    skip_tiles[g] = 0;
+                    FETCH_ADD_U32(&acc[2], 1u);
                     ATOMIC_MAX_U32(&acc[3], (uint32_t)(len < 0xFFFFFFFFull ? len : 0xFFFFFFFFull));
                 }
             }
@@ -4153,8 +4126,8 @@ GLOBAL_FN LAUNCH_BOUNDS(256) msd_groups_kernel(KCTX const uint64_t* __restrict__
         PAR(tid) {
             if (tid == 0) {
                 at0[0] = acc[0] ? FETCH_ADD_U64(&out3[5], (uint64_t)acc[0]) : 0;
-                if (acc[1]) ATOMIC_ADD_U64(&out3[2], (uint64_t)acc[1]);
-                if (acc[2]) ATOMIC_ADD_U64(&out3[4], (uint64_t)acc[2]);
+                at0[1] = acc[1] ? FETCH_ADD_U64(&out3[6], (uint64_t)acc[1]) : 0;
+                if (acc[2]) { ATOMIC_ADD_U64(&out3[2], (uint64_t)acc[2]); ATOMIC_ADD_U64(&out3[4], (uint64_t)acc[2]); }
                 if (acc[3]) ATOMIC_MAX_U64(&out3[3], (uint64_t)acc[3]);
             }
         }
@@ -4165,6 +4138,7 @@ GLOBAL_FN LAUNCH_BOUNDS(256) msd_groups_kernel(KCTX const uint64_t* __restrict__
                 const uint64_t s0 = seg_start[g], len = seg_start[g + 1] - s0, at = at0[0] + TL(mine, tid, 0);
                 for (uint64_t k = 0; k < len; ++k) flist[at + k] = (uint32_t)(s0 + k);
             }
+            if (g < G && TL(mineq, tid, 0) != ~0u) qlist[at0[1] + TL(mineq, tid, 0)] = (uint32_t)g;
         }
         SYNC();
     }
@@ -4220,6 +4194,158 @@ GLOBAL_FN LAUNCH_BOUNDS(MSD_FIN_NT) msd_finish_kernel(KCTX const uint32_t* __res
             }
         }
         SYNC();                                        // rk / best are free for the next batch
+    }
+}
+
+// A group of at most MSD_QK_MAX members, finished in ONE launch: multikey quicksort in LDS, every level of the refinement without a
+// trip through global memory but the windows of the text.  The workgroup holds the group's positions; a SUBSEGMENT is a run of
+// them known to share D0 + lvl windows (at first: the whole group, lvl 0).  Every round, every open subsegment is split three
+// ways around its first member's window at that depth: smaller | equal | larger (a member whose suffix ends inside the window is
+// a prefix of the others: by position, the shorter first).  The equal part moves on to the next window, the other two are
+// split again at the same depth; a part of one member is settled.  A subsegment that comes out whole (all windows equal) jumps
+// to what all its members share (deep_lcp: a periodic stretch is one step).  The LCP of a member with its predecessor follows
+// from the round that separated the two: the depth of that round + what their windows there share (sep[i]: its level).
+// Replaces ~45 launches-and-syncs deep level loops over the thousands of groups of a tandem array (25 of 119 ms on the
+// GRCh38-shaped workload) by one kernel.  LDS: 128 KB (32-bit indices), one workgroup per CU.
+constexpr uint32_t MSD_QK_SHIFT = 21;             // cnt[start] = smaller | equal << 21 | larger << 42
+constexpr uint32_t MSD_QK_MASK = (1u << MSD_QK_SHIFT) - 1u;
+constexpr uint32_t MSD_QK_WHOLE = 1u << 31;       // (in a member's class | rank << 2 word)
+static_assert(TILE_E < (1u << MSD_QK_SHIFT) && TILE_E <= 65535, "counts fit their fields, subsegment starts fit 16 bits");
+template <typename idx_t, int BITS, bool RUNS>
+GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) msd_quick_kernel(KCTX const uint32_t* __restrict__ P, uint64_t n, const uint32_t* __restrict__ qlist,
+                                                  const uint64_t* __restrict__ seg_start, const uint64_t* __restrict__ gpos,
+                                                  const uint64_t* __restrict__ gdepth, const idx_t* __restrict__ wsa, idx_t* __restrict__ SA,
+                                                  idx_t* __restrict__ LCP)
+{
+    constexpr uint32_t KCH = TextTraits<BITS>::KCH;
+    SHARED_ARRAY(idx_t, ssa, TILE_E);
+    SHARED_ARRAY(uint64_t, skey, TILE_E);
+    SHARED_ARRAY(uint16_t, sid, TILE_E);          // the start of the member's subsegment
+    SHARED_ARRAY(uint16_t, slen, TILE_E);         // [start] members (1: settled)
+    SHARED_ARRAY(uint32_t, slvl, TILE_E);         // [start] windows behind D0 its members are known to share
+    SHARED_ARRAY(uint32_t, sep, TILE_E);          // [i] the level of the round that separated member i from member i - 1
+    SHARED_ARRAY(uint64_t, cnt, TILE_E);          // [start] the three counts of a round
+    SHARED_ARRAY(uint32_t, open, 1);
+    TL_DECL(idx_t, ra, TILE_EPT);
+    TL_DECL(uint32_t, rs, TILE_EPT);              // the member's subsegment (start), ~0: settled
+    TL_DECL(uint32_t, rc, TILE_EPT);              // class | rank << 2
+    TL_DECL(uint32_t, rl, TILE_EPT);              // the subsegment's level in this round
+    const uint32_t g = qlist[K_BLOCK_IDX];
+    const uint64_t s0 = seg_start[g], D0 = gdepth[g], p0 = gpos[g];
+    const uint32_t N = (uint32_t)(seg_start[g + 1] - s0);
+    PAR(tid) {
+        for (uint32_t e = tid; e < N; e += K_BLOCK_DIM) { ssa[e] = wsa[s0 + e]; sid[e] = 0; sep[e] = 0; }
+        if (tid == 0) { slen[0] = (uint16_t)N; slvl[0] = 0; open[0] = N >= 2 ? 1u : 0u; }
+    }
+    for (;;) {
+        SYNC();
+        if (open[0] == 0) break;                                               // block-uniform
+        PAR(tid) {                                 // A: the window of every member of an open subsegment at the subsegment's depth
+            for (uint32_t e = tid; e < N; e += K_BLOCK_DIM) {
+                const uint32_t s = sid[e];
+                cnt[e] = 0;
+                if (slen[s] >= 2) {
+                    const uint64_t pos = (uint64_t)ssa[e] + D0 + (uint64_t)slvl[s] * KCH;
+                    skey[e] = pos < n ? window64<BITS>(P, pos) : 0;
+                }
+            }
+        }
+        SYNC();
+        PAR(tid) {                                 // B: class and rank inside the class (one LDS atomic per member)
+            if (tid == 0) open[0] = 0;
+            UNROLL
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                const uint32_t e = tid + k * TILE_NT;
+                TL(rs, tid, k) = ~0u;
+                if (e < N) {
+                    const uint32_t s = sid[e];
+                    const idx_t a = ssa[e];
+                    TL(ra, tid, k) = a;
+                    if (slen[s] >= 2) {
+                        const uint32_t lvl = slvl[s];
+                        const uint64_t depth = D0 + (uint64_t)lvl * KCH, kp = skey[s], key = skey[e];
+                        const uint64_t ap = (uint64_t)ssa[s];
+                        uint32_t c = 1;
+                        if (e != s) {
+                            if (key != kp) c = key < kp ? 0u : 2u;
+                            else if (msd_ending<BITS>(n, (uint64_t)a, depth) || msd_ending<BITS>(n, ap, depth)) c = (uint64_t)a > ap ? 0u : 2u;
+                        }
+                        const uint64_t old = FETCH_ADD_U64(&cnt[s], 1ull << (MSD_QK_SHIFT * c));
+                        TL(rs, tid, k) = s;
+                        TL(rl, tid, k) = lvl;
+                        TL(rc, tid, k) = c | ((uint32_t)((old >> (MSD_QK_SHIFT * c)) & MSD_QK_MASK) << 2);
+                    }
+                }
+            }
+        }
+        SYNC();
+        PAR(tid) {                                 // C: the members of a subsegment move to their classes (everything was read in B)
+            UNROLL
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                const uint32_t s = TL(rs, tid, k), e = tid + k * TILE_NT;
+                if (s != ~0u) {
+                    const uint64_t pk = cnt[s];
+                    const uint32_t n0 = (uint32_t)(pk & MSD_QK_MASK), n1 = (uint32_t)((pk >> MSD_QK_SHIFT) & MSD_QK_MASK), n2 = (uint32_t)(pk >> (2 * MSD_QK_SHIFT));
+                    const uint32_t c = TL(rc, tid, k) & 3u, r = (TL(rc, tid, k) >> 2) & MSD_QK_MASK;
+                    const uint32_t base = s + (c == 0 ? 0u : c == 1 ? n0 : n0 + n1);
+                    ssa[base + r] = TL(ra, tid, k);
+                    sid[base + r] = (uint16_t)base;
+                    if (n0 == 0 && n2 == 0 && n1 >= 2) {   // the subsegment comes out whole: it will jump (its key slot collects how far)
+                        TL(rc, tid, k) |= MSD_QK_WHOLE;
+                        if (e == s) skey[s] = 0;
+                    }
+                }
+            }
+        }
+        SYNC();
+        PAR(tid) {                                 // D: the first member of every class opens the class's record; a whole subsegment
+            UNROLL                                 //    measures what its members share with the first one
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                const uint32_t s = TL(rs, tid, k);
+                if (s == ~0u) continue;
+                const uint32_t lvl = TL(rl, tid, k);
+                if (((TL(rc, tid, k) >> 2) & MSD_QK_MASK) == 0) {
+                    const uint64_t pk = cnt[s];
+                    const uint32_t n0 = (uint32_t)(pk & MSD_QK_MASK), n1 = (uint32_t)((pk >> MSD_QK_SHIFT) & MSD_QK_MASK), n2 = (uint32_t)(pk >> (2 * MSD_QK_SHIFT));
+                    const uint32_t c = TL(rc, tid, k) & 3u;
+                    const uint32_t base = s + (c == 0 ? 0u : c == 1 ? n0 : n0 + n1), nc = c == 0 ? n0 : c == 1 ? n1 : n2;
+                    slen[base] = (uint16_t)nc;
+                    slvl[base] = lvl + (c == 1 ? 1u : 0u);
+                    if (base != s) sep[base] = lvl;
+                    if (nc >= 2) open[0] = 1;
+                }
+                if (TL(rc, tid, k) & MSD_QK_WHOLE) {
+                    const uint64_t a = (uint64_t)TL(ra, tid, k), ap = (uint64_t)ssa[s];
+                    if (a != ap) {
+                        const uint64_t l = deep_lcp<BITS, RUNS>(P, n, ap, a, D0 + ((uint64_t)lvl + 1u) * KCH);
+                        ATOMIC_MAX_LDS_U64(&skey[s], ~((l - D0) / KCH));                     // (the minimum, inverted)
+                    }
+                }
+            }
+        }
+        SYNC();
+        PAR(tid) {                                 // E: ... and jumps there
+            UNROLL
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                const uint32_t s = TL(rs, tid, k), e = tid + k * TILE_NT;
+                if (s != ~0u && (TL(rc, tid, k) & MSD_QK_WHOLE) && e == s && skey[s]) {
+                    const uint64_t w = ~skey[s];
+                    if (w > slvl[s]) slvl[s] = (uint32_t)(w < 0xFFFFFFFFull ? w : 0xFFFFFFFFull);
+                }
+            }
+        }
+    }
+    PAR(tid) {                                     // the group in its final order: SA, and the LCPs from the separating rounds
+        for (uint32_t e = tid; e < N; e += K_BLOCK_DIM) {
+            const uint64_t a = (uint64_t)ssa[e];
+            SA[p0 + e] = (idx_t)a;
+            if (e) {
+                const uint64_t b = (uint64_t)ssa[e - 1], depth = D0 + (uint64_t)sep[e] * KCH;
+                const uint64_t wa = a + depth < n ? window64<BITS>(P, a + depth) : 0, wb = b + depth < n ? window64<BITS>(P, b + depth) : 0;
+                const uint64_t l = depth + (wa == wb ? KCH : (uint32_t)caps_clz64(wa ^ wb) / BITS), room = n - (a > b ? a : b);
+                LCP[p0 + e] = (idx_t)(l < room ? l : room);
+            }
+        }
     }
 }
 

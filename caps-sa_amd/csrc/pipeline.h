@@ -987,6 +987,7 @@ bool msd_refine(Backend& be, const uint32_t* P, uint64_t n, const SortResult<idx
     uint8_t* skip_tiles = ar.tail<uint8_t>(m0 / 2 + 2);
     uint32_t* wgid = ar.tail<uint32_t>(m0 + 2);
     uint32_t* flist = ar.tail<uint32_t>(m0 + 2);
+    uint32_t* qlist = ar.tail<uint32_t>(m0 / (MSD_FIN_MAX + 1) + 2);
     uint64_t* edges = ar.tail<uint64_t>(2 * G0 + 4);
     uint64_t* out3 = ar.tail<uint64_t>(8);
     if (ar.failed) return false;
@@ -996,7 +997,7 @@ bool msd_refine(Backend& be, const uint32_t* P, uint64_t n, const SortResult<idx
     uint64_t D = KCH;                                  // (the depth of the groups that never jumped: for the log)
     auto finish = [&](const uint64_t* seg, const uint64_t* gpos, const uint64_t* gdep, const idx_t* wsa, const uint32_t* gid, uint64_t m_bound) {
         const uint32_t ggrid = (uint32_t)std::min<uint64_t>((m_bound / 2 + 255) / 256 + 1, 4ull * be.persistent_blocks());
-        CAPS_LAUNCH(msd_groups_kernel, ggrid, 256, be, seg, skip, skip_tiles, flist, out3);
+        CAPS_LAUNCH(msd_groups_kernel, ggrid, 256, be, seg, skip, skip_tiles, flist, qlist, out3);
         const uint32_t grid = (uint32_t)std::min<uint64_t>((m_bound + MSD_FIN_MEMBERS - 1) / MSD_FIN_MEMBERS, 32ull * be.persistent_blocks());
         if (be.long_runs) CAPS_LAUNCH((msd_finish_kernel<idx_t, BITS, true>), grid ? grid : 1, 256, be, P, n, gdep, seg, gpos, wsa, gid, (const uint32_t*)flist, SA, LCP, (const uint64_t*)out3);
         else CAPS_LAUNCH((msd_finish_kernel<idx_t, BITS, false>), grid ? grid : 1, 256, be, P, n, gdep, seg, gpos, wsa, gid, (const uint32_t*)flist, SA, LCP, (const uint64_t*)out3);
@@ -1004,10 +1005,17 @@ bool msd_refine(Backend& be, const uint32_t* P, uint64_t n, const SortResult<idx
     CAPS_LAUNCH(msd_edges_kernel, (uint32_t)std::min<uint64_t>((G0 + 255) / 256 + 1, 4ull * be.persistent_blocks()), 256, be, (const uint64_t*)segX,
                 (const uint64_t*)gposX, (const uint64_t*)out3, edges);
     finish(segX, gposX, gdepX, wsa0, wgid, m0);
-    uint64_t h3[5] = {0, 0, 0, 0, 0};
+    // (the groups of up to a tile, each finished by one workgroup in LDS; launched once their number is known, reads this generation's tables)
+    auto quick = [&](const uint64_t* seg, const uint64_t* gpos, const uint64_t* gdep, const idx_t* wsa, uint64_t nq) {
+        if (!nq) return;
+        if (be.long_runs) CAPS_LAUNCH((msd_quick_kernel<idx_t, BITS, true>), (uint32_t)nq, TILE_NT, be, P, n, (const uint32_t*)qlist, seg, gpos, gdep, wsa, SA, LCP);
+        else CAPS_LAUNCH((msd_quick_kernel<idx_t, BITS, false>), (uint32_t)nq, TILE_NT, be, P, n, (const uint32_t*)qlist, seg, gpos, gdep, wsa, SA, LCP);
+    };
+    uint64_t h3[7] = {0, 0, 0, 0, 0, 0, 0};
     be.d2h(h3, out3, sizeof h3);
     be.sync();
-    uint64_t G = h3[0], m = h3[1], nopen = h3[2], gmax = h3[3], ntiled = h3[4];
+    uint64_t G = h3[0], m = h3[1], nopen = h3[2], gmax = h3[3];
+    quick(segX, gposX, gdepX, wsa0, h3[6]);
     r.msd_groups = G;
     r.msd_elems = m;
     // (when every group is in its final order: the LCPs at its two ends, see msd_edges_kernel)
@@ -1016,14 +1024,14 @@ bool msd_refine(Backend& be, const uint32_t* P, uint64_t n, const SortResult<idx
         if (n_edges) CAPS_LAUNCH((msd_fix_edges_kernel<idx_t, BITS>), (uint32_t)((n_edges + 255) / 256), 256, be, P, n, (const uint64_t*)edges, n_edges,
                                  r.total, (const idx_t*)SA, LCP);
     };
-    if (dbg) std::fprintf(stderr, "[msd] level 0: %llu flagged tiles, %llu elements in them, %llu groups of %llu members, %llu above %u (%llu above %u, largest %llu)\n",
-                          (unsigned long long)NF, (unsigned long long)M0, (unsigned long long)G, (unsigned long long)m, (unsigned long long)nopen, MSD_FIN_MAX,
-                          (unsigned long long)ntiled, MSD_RANK_MAX, (unsigned long long)gmax);
+    if (dbg) std::fprintf(stderr, "[msd] level 0: %llu flagged tiles, %llu elements in them, %llu groups of %llu members, %llu above %u finished in LDS, %llu above %u (largest %llu)\n",
+                          (unsigned long long)NF, (unsigned long long)M0, (unsigned long long)G, (unsigned long long)m, (unsigned long long)h3[6], MSD_FIN_MAX,
+                          (unsigned long long)nopen, MSD_QK_MAX, (unsigned long long)gmax);
     if (nopen == 0) { fix_edges(); return true; }
     // ---- the levels: work arrays for m members in at most m / 2 groups; level 0's outputs stay where they are (chunk tails)
     ar.lo[0] = reinterpret_cast<char*>(r.buf[0].key);                   // (flags0 / offs0 / stmp are dead)
     ar.lo[1] = reinterpret_cast<char*>(r.buf[1].key);
-    const uint64_t cap2 = m + 2, Gm = m / 2 + 2, tiles_max = m / TILE_E + m / (MSD_RANK_MAX + 1) + 4;
+    const uint64_t cap2 = m + 2, Gm = m / 2 + 2, tiles_max = m / TILE_E + m / (MSD_QK_MAX + 1) + 4;
     ElemBuf<idx_t> E0, E1;
     for (ElemBuf<idx_t>* e : {&E0, &E1}) {
         char* base = reinterpret_cast<char*>(ar.head<uint64_t>(cap2 * per / sizeof(uint64_t) + 1, e == &E0 ? 0 : 1));
@@ -1063,13 +1071,11 @@ bool msd_refine(Backend& be, const uint32_t* P, uint64_t n, const SortResult<idx
             CAPS_LAUNCH(msd_jump_apply_kernel, gg, 256, be, (const uint64_t*)out3, (const uint8_t*)skip, (const uint64_t*)gmin, KCH, gdep);
         }
         CAPS_LAUNCH((msd_rekey_kernel<idx_t, BITS>), mg, 256, be, P, n, (const uint64_t*)gdep, m, (const uint32_t*)gid, (const uint8_t*)skip, in_sa, kin);
-        CAPS_LAUNCH((msd_ranksort_kernel<idx_t>), mg, 256, be, m, (const uint64_t*)seg, (const uint32_t*)gid, (const uint8_t*)skip, (const uint64_t*)kin,
-                    in_sa, E0.key, E0.sa);
-        if (ntiled) {                                   // groups above MSD_RANK_MAX: the segmented sort, tile by tile (+ merge passes above a tile)
+        {                                               // the segmented sort, tile by tile + merge passes
             ls.seg_start = seg;
             ls.G = (uint32_t)G;
             // (no read-back of the tile count: such groups have at most this many tiles, the kernels return on the rest)
-            const uint32_t lt = (uint32_t)std::min<uint64_t>(tiles_max, m / TILE_E + ntiled + 1);
+            const uint32_t lt = (uint32_t)std::min<uint64_t>(tiles_max, m / TILE_E + nopen + 1);
             prepare_segments(be, ls, lt, big_tmp, big_cnt, false, skip_tiles);
             SortOpts o;
             o.keys_only = true;                        // (key, position descending): no comparison reads the text
@@ -1102,10 +1108,10 @@ bool msd_refine(Backend& be, const uint32_t* P, uint64_t n, const SortResult<idx
         m = h3[1];
         nopen = h3[2];
         gmax = h3[3];
-        ntiled = h3[4];
-        if (dbg) std::fprintf(stderr, "[msd] depth %llu: %llu groups of %llu members still open, %llu above %u (%llu above %u, largest %llu)\n", (unsigned long long)D,
-                              (unsigned long long)G, (unsigned long long)m, (unsigned long long)nopen, MSD_FIN_MAX, (unsigned long long)ntiled,
-                              MSD_RANK_MAX, (unsigned long long)gmax);
+        quick(seg, gpos, gdep, in_sa, h3[6]);
+        if (dbg) std::fprintf(stderr, "[msd] depth %llu: %llu groups of %llu members, %llu above %u finished in LDS, %llu above %u (largest %llu)\n", (unsigned long long)D,
+                              (unsigned long long)G, (unsigned long long)m, (unsigned long long)h3[6], MSD_FIN_MAX, (unsigned long long)nopen,
+                              MSD_QK_MAX, (unsigned long long)gmax);
         if (G > Gm - 1 || m > cap2 - 2) return false;                   // (cannot happen: both only shrink)
     }
     fix_edges();

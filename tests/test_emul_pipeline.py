@@ -675,7 +675,6 @@ def test_large_groups_of_equal_keys_are_rekeyed_not_compared(monkeypatch):
     from sa_check import sa_lcp
     E = emul_small()
     rs = np.random.RandomState(47)
-    seen_levels = 0
     for n, alphabet, bits in [(150_000, DNA, 32), (90_000, DNA, 64), (120_000, np.frombuffer(b"acgtn\x80\xfe", dtype=np.uint8), 32)]:
         T = _repeat_rich(rs, n, alphabet)
         SAo, LCPo = sa_lcp(T, idx_bits=bits)
@@ -689,7 +688,6 @@ def test_large_groups_of_equal_keys_are_rekeyed_not_compared(monkeypatch):
             assert np.array_equal(LCP, LCPo), (n, bits, mode)
             if st["path_direct"]:
                 assert st["tie_groups_deferred"] > 0 and st["tie_elems_deferred"] >= 2 * st["tie_groups_deferred"], (n, mode, st)
-                seen_levels = max(seen_levels, st["tie_levels"])
         monkeypatch.setenv("CAPS_SA_NO_DEFER", "1")
         SA, LCP, st = E.build(T, p=0, idx_bits=bits)
         monkeypatch.delenv("CAPS_SA_NO_DEFER")
@@ -707,7 +705,32 @@ def test_large_groups_of_equal_keys_are_rekeyed_not_compared(monkeypatch):
         SA, LCP, st = E.build(T, p=0, idx_bits=bits)
         monkeypatch.delenv("CAPS_SA_HOST_WAVES")
         assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo) and st["tie_groups_deferred"] > 0 and st["result_waves"] >= 2
-    assert seen_levels >= 2, seen_levels
+
+
+def _tandem(rs, T, at, unit_len, copies, rate, alphabet=DNA):
+    unit = rs.choice(alphabet, size=unit_len)
+    seg = np.tile(unit, copies)
+    m = rs.rand(seg.size) < rate
+    seg[m] = rs.choice(alphabet, size=int(m.sum()))
+    T[at:at + seg.size] = seg
+
+
+def test_groups_larger_than_a_tile_take_the_level_loop(monkeypatch):
+    """A group of equal keys of at most a tile of members is finished by one workgroup in LDS (msd_quick_kernel: multikey quicksort,
+    no level of msd_refine's loop); a larger one is re-keyed and sorted level by level until its parts fit.  A tandem array of a
+    23-char unit with 700 copies at the 256-element tiles (groups of ~700 > 256), 6000 copies at the 4096-element tiles; texts
+    that end inside the array; both index widths.  tie_levels counts the levels of the loop."""
+    from emul_util import emul_small
+    from sa_check import sa_lcp
+    rs = np.random.RandomState(71)
+    for E, n, copies, bits in [(emul_small(), 120_000, 700, 32), (emul_small(), 150_001, 900, 64), (emul(), 1_000_000, 6000, 32)]:
+        T = rs.choice(DNA, size=n)
+        _tandem(rs, T, n // 3, 23, copies, 0.003)
+        _tandem(rs, T, n - 23 * 40, 23, 40, 0.0)                  # (another unit: the text ends inside a short exact array)
+        SAo, LCPo = sa_lcp(T, idx_bits=bits)
+        SA, LCP, st = E.build(T, p=0, idx_bits=bits)
+        assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), (n, bits)
+        assert st["path_direct"] == 1 and st["tie_groups_deferred"] > 0 and st["tie_levels"] >= 2, (n, st["tie_groups_deferred"], st["tie_levels"])
 
 
 def test_deferred_groups_that_agree_for_thousands_of_chars_jump(monkeypatch):

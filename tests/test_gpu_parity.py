@@ -282,7 +282,7 @@ def test_genome_like_256mi_with_grch38_shaped_repeats_device(L, sa_path):
     assert st["path_direct"] == (0 if sa_path == "classic" else 1), st
     assert int(LCP.max().item()) >= 49_999
     if sa_path != "classic":                         # the cluster tiles' ties were deferred and re-keyed, many levels deep
-        assert st["tie_groups_deferred"] > 1000 and st["tie_levels"] >= 8, (st["tie_groups_deferred"], st["tie_levels"])
+        assert st["tie_groups_deferred"] > 1000, (st["tie_groups_deferred"], st["tie_levels"])
 
 
 def test_sharded_driver_single_rank_rccl(L, sa_path):
@@ -865,9 +865,30 @@ def test_large_groups_of_equal_keys_are_rekeyed_not_compared_device(L, oracle, m
             assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), (n, bits, mode)
             assert st["path_direct"] == 1
             if alphabet is DNA:     # (8-char keys of a byte alphabet tie all the time: most tiles would be deferred, so none is -- segmented_sort defer_check)
-                assert st["tie_groups_deferred"] > 0 and st["tie_levels"] >= 2, (n, mode, st["tie_groups_deferred"], st["tie_levels"])
+                assert st["tie_groups_deferred"] > 0, (n, mode, st["tie_groups_deferred"], st["tie_levels"])
         monkeypatch.delenv("CAPS_SA_DIRECT_MODE", raising=False)
         monkeypatch.setenv("CAPS_SA_NO_DEFER", "1")
         SA, LCP, st = L.build(T, p=800, idx_bits=bits)
         monkeypatch.delenv("CAPS_SA_NO_DEFER")
         assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo) and st["tie_groups_deferred"] == 0
+
+
+def test_groups_larger_than_a_tile_take_the_level_loop_device(L):
+    """A group of equal keys of at most a tile of members is finished by one workgroup in LDS (msd_quick_kernel); a larger one goes
+    through msd_refine's level loop until its parts fit.  A tandem array of a 23-char unit with 9000 copies (groups of ~9000
+    members > 4096), a text that ends inside an exact array; both index widths; against tests/sa_check.py (the oracle is
+    quadratic on such texts)."""
+    from sa_check import sa_lcp
+    rs = np.random.RandomState(71)
+    for n, copies, bits in [(1_500_000, 9000, 32), (1_000_001, 7000, 64)]:
+        T = rs.choice(DNA, size=n)
+        for at, k, rate in [(n // 3, copies, 0.002), (n - 23 * 300, 300, 0.0)]:
+            unit = rs.choice(DNA, size=23)
+            seg = np.tile(unit, k)
+            m = rs.rand(seg.size) < rate
+            seg[m] = rs.choice(DNA, size=int(m.sum()))
+            T[at:at + seg.size] = seg
+        SAo, LCPo = sa_lcp(T, idx_bits=bits)
+        SA, LCP, st = L.build(T, p=0, idx_bits=bits)
+        assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), (n, bits)
+        assert st["path_direct"] == 1 and st["tie_groups_deferred"] > 0 and st["tie_levels"] >= 2, (n, st["tie_groups_deferred"], st["tie_levels"])
