@@ -3938,7 +3938,7 @@ GLOBAL_FN LAUNCH_BOUNDS(64) msd_close_kernel(KCTX const uint64_t* __restrict__ t
             out3[3] = 0;                               //   the largest of them,
             out3[4] = 0;                               //   (the same count: they are sorted tile by tile),
             out3[5] = 0;                               //   members listed for msd_finish_kernel,
-            out3[6] = 0;                               //   groups listed for msd_quick_kernel
+            out3[6] = out3[7] = out3[8] = 0;           //   groups listed for msd_quick_kernel, by capacity class
         }
     }
 }
@@ -3946,6 +3946,9 @@ GLOBAL_FN LAUNCH_BOUNDS(64) msd_close_kernel(KCTX const uint64_t* __restrict__ t
 // ---- one level.  Everything below is one THREAD per member of the work array (wgid: its group; skip[g] != 0: the group is
 // finished -- its members are dead weight until the next compaction drops them).
 constexpr uint32_t MSD_QK_MAX = TILE_E;       // groups up to this size are finished in LDS (msd_quick_kernel); only larger ones see another level
+// (three capacities, so that small groups do not occupy a compute unit each: 8 / 32 / 128 KB of LDS per workgroup)
+constexpr uint32_t MSD_QK_CAP[3] = {TILE_E / 16, TILE_E / 4, TILE_E};
+constexpr uint32_t MSD_QK_NT[3] = {TILE_NT / 4, TILE_NT / 4, TILE_NT};
 
 // key = the KCH chars behind the D known-equal ones
 template <typename idx_t, int BITS>
@@ -4088,20 +4091,22 @@ GLOBAL_FN LAUNCH_BOUNDS(256) msd_fix_edges_kernel(KCTX const uint32_t* __restric
 }
 
 // The groups of a level, one thread each.  At most MSD_FIN_MAX members: listed for msd_finish_kernel (flist: the indices of its
-// members, out3[5] of them in all).  At most MSD_QK_MAX: listed for msd_quick_kernel (qlist: the group, out3[6] of them).  Both are
+// members, out3[5] of them in all).  At most MSD_QK_MAX: listed for msd_quick_kernel by capacity class (qlist[c]: the group,
+// out3[6 + c] of them).  Both are
 // taken out (skip[g] = skip_tiles[g] = 1).  Larger ones go through another level: out3[2] = out3[4] counts them, out3[3] = the largest.
 GLOBAL_FN LAUNCH_BOUNDS(256) msd_groups_kernel(KCTX const uint64_t* __restrict__ seg_start, uint8_t* __restrict__ skip, uint8_t* __restrict__ skip_tiles,
-                                               uint32_t* __restrict__ flist, uint32_t* __restrict__ qlist, uint64_t* __restrict__ out3)
+                                               uint32_t* __restrict__ flist, uint32_t* __restrict__ qlist0, uint32_t* __restrict__ qlist1,
+                                               uint32_t* __restrict__ qlist2, uint64_t* __restrict__ out3)
 {
     // (a workgroup reserves its share of the lists and adds its counts with ONE global atomic each: a million groups bumping the
     // counters one by one took longer than finishing them)
-    SHARED_ARRAY(uint32_t, acc, 4);            // [0] members listed by this workgroup, [1] groups for the quick kernel, [2] larger ones, [3] largest
-    SHARED_ARRAY(uint64_t, at0, 2);
+    SHARED_ARRAY(uint32_t, acc, 6);            // [0] members listed by this workgroup, [1] larger groups, [2] the largest, [3..5] groups per quick class
+    SHARED_ARRAY(uint64_t, at0, 4);
     const uint64_t G = out3[0];
     for (uint64_t gb = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM; gb < G; gb += (uint64_t)K_GRID_DIM * K_BLOCK_DIM) {
         TL_DECL(uint32_t, mine, 1);
         TL_DECL(uint32_t, mineq, 1);
-        PAR(tid) { if (tid < 4) acc[tid] = 0; }
+        PAR(tid) { if (tid < 6) acc[tid] = 0; }
         SYNC();
         PAR(tid) {
             const uint64_t g = gb + tid;
@@ -4111,14 +4116,17 @@ GLOBAL_FN LAUNCH_BOUNDS(256) msd_groups_kernel(KCTX const uint64_t* __restrict__
                 const uint64_t len = seg_start[g + 1] - seg_start[g];
                 if (len <= MSD_QK_MAX) {
                     if (len <= MSD_FIN_MAX) TL(mine, tid, 0) = FETCH_ADD_U32(&acc[0], (uint32_t)len);
-                    else TL(mineq, tid, 0) = FETCH_ADD_U32(&acc[1], 1u);
+                    else {
+                        const uint32_t c = len <= MSD_QK_CAP[0] ? 0u : len <= MSD_QK_CAP[1] ? 1u : 2u;
+                        TL(mineq, tid, 0) = FETCH_ADD_U32(&acc[3 + c], 1u) | (c << 30);
+                    }
                     skip[g] = 1;
                     skip_tiles[g] = 1;
                 } else {
                     skip[g] = 0;
                     skip_tiles[g] = 0;
-                    FETCH_ADD_U32(&acc[2], 1u);
-                    ATOMIC_MAX_U32(&acc[3], (uint32_t)(len < 0xFFFFFFFFull ? len : 0xFFFFFFFFull));
+                    FETCH_ADD_U32(&acc[1], 1u);
+                    ATOMIC_MAX_U32(&acc[2], (uint32_t)(len < 0xFFFFFFFFull ? len : 0xFFFFFFFFull));
                 }
             }
         }
@@ -4126,9 +4134,9 @@ GLOBAL_FN LAUNCH_BOUNDS(256) msd_groups_kernel(KCTX const uint64_t* __restrict__
         PAR(tid) {
             if (tid == 0) {
                 at0[0] = acc[0] ? FETCH_ADD_U64(&out3[5], (uint64_t)acc[0]) : 0;
-                at0[1] = acc[1] ? FETCH_ADD_U64(&out3[6], (uint64_t)acc[1]) : 0;
-                if (acc[2]) { ATOMIC_ADD_U64(&out3[2], (uint64_t)acc[2]); ATOMIC_ADD_U64(&out3[4], (uint64_t)acc[2]); }
-                if (acc[3]) ATOMIC_MAX_U64(&out3[3], (uint64_t)acc[3]);
+                for (uint32_t c = 0; c < 3; ++c) at0[1 + c] = acc[3 + c] ? FETCH_ADD_U64(&out3[6 + c], (uint64_t)acc[3 + c]) : 0;
+                if (acc[1]) { ATOMIC_ADD_U64(&out3[2], (uint64_t)acc[1]); ATOMIC_ADD_U64(&out3[4], (uint64_t)acc[1]); }
+                if (acc[2]) ATOMIC_MAX_U64(&out3[3], (uint64_t)acc[2]);
             }
         }
         SYNC();
@@ -4138,7 +4146,10 @@ GLOBAL_FN LAUNCH_BOUNDS(256) msd_groups_kernel(KCTX const uint64_t* __restrict__
                 const uint64_t s0 = seg_start[g], len = seg_start[g + 1] - s0, at = at0[0] + TL(mine, tid, 0);
                 for (uint64_t k = 0; k < len; ++k) flist[at + k] = (uint32_t)(s0 + k);
             }
-            if (g < G && TL(mineq, tid, 0) != ~0u) qlist[at0[1] + TL(mineq, tid, 0)] = (uint32_t)g;
+            if (g < G && TL(mineq, tid, 0) != ~0u) {
+                const uint32_t c = TL(mineq, tid, 0) >> 30, at = TL(mineq, tid, 0) & 0x3FFFFFFFu;
+                (c == 0 ? qlist0 : c == 1 ? qlist1 : qlist2)[at0[1 + c] + at] = (uint32_t)g;
+            }
         }
         SYNC();
     }
@@ -4206,42 +4217,44 @@ GLOBAL_FN LAUNCH_BOUNDS(MSD_FIN_NT) msd_finish_kernel(KCTX const uint32_t* __res
 // to what all its members share (deep_lcp: a periodic stretch is one step).  The LCP of a member with its predecessor follows
 // from the round that separated the two: the depth of that round + what their windows there share (sep[i]: its level).
 // Replaces ~45 launches-and-syncs deep level loops over the thousands of groups of a tandem array (25 of 119 ms on the
-// GRCh38-shaped workload) by one kernel.  LDS: 128 KB (32-bit indices), one workgroup per CU.
+// GRCh38-shaped workload) by one kernel.  Every round waits for the text once (one workgroup: ~2 us), so the compute unit
+// must hold several groups: capacities of 256 / 1024 / 4096 members (MSD_QK_CAP: 8 / 32 / 128 KB of LDS).
 constexpr uint32_t MSD_QK_SHIFT = 21;             // cnt[start] = smaller | equal << 21 | larger << 42
 constexpr uint32_t MSD_QK_MASK = (1u << MSD_QK_SHIFT) - 1u;
 constexpr uint32_t MSD_QK_WHOLE = 1u << 31;       // (in a member's class | rank << 2 word)
 static_assert(TILE_E < (1u << MSD_QK_SHIFT) && TILE_E <= 65535, "counts fit their fields, subsegment starts fit 16 bits");
-template <typename idx_t, int BITS, bool RUNS>
-GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) msd_quick_kernel(KCTX const uint32_t* __restrict__ P, uint64_t n, const uint32_t* __restrict__ qlist,
+template <typename idx_t, int BITS, bool RUNS, uint32_t CAP, uint32_t NT>
+GLOBAL_FN LAUNCH_BOUNDS(NT) msd_quick_kernel(KCTX const uint32_t* __restrict__ P, uint64_t n, const uint32_t* __restrict__ qlist,
                                                   const uint64_t* __restrict__ seg_start, const uint64_t* __restrict__ gpos,
                                                   const uint64_t* __restrict__ gdepth, const idx_t* __restrict__ wsa, idx_t* __restrict__ SA,
                                                   idx_t* __restrict__ LCP)
 {
-    constexpr uint32_t KCH = TextTraits<BITS>::KCH;
-    SHARED_ARRAY(idx_t, ssa, TILE_E);
-    SHARED_ARRAY(uint64_t, skey, TILE_E);
-    SHARED_ARRAY(uint16_t, sid, TILE_E);          // the start of the member's subsegment
-    SHARED_ARRAY(uint16_t, slen, TILE_E);         // [start] members (1: settled)
-    SHARED_ARRAY(uint32_t, slvl, TILE_E);         // [start] windows behind D0 its members are known to share
-    SHARED_ARRAY(uint32_t, sep, TILE_E);          // [i] the level of the round that separated member i from member i - 1
-    SHARED_ARRAY(uint64_t, cnt, TILE_E);          // [start] the three counts of a round
+    constexpr uint32_t KCH = TextTraits<BITS>::KCH, EPT = CAP / NT;
+    static_assert(CAP % NT == 0 && CAP <= MSD_QK_MAX, "capacity classes");
+    SHARED_ARRAY(idx_t, ssa, CAP);
+    SHARED_ARRAY(uint64_t, skey, CAP);
+    SHARED_ARRAY(uint16_t, sid, CAP);          // the start of the member's subsegment
+    SHARED_ARRAY(uint16_t, slen, CAP);         // [start] members (1: settled)
+    SHARED_ARRAY(uint32_t, slvl, CAP);         // [start] windows behind D0 its members are known to share
+    SHARED_ARRAY(uint32_t, sep, CAP);          // [i] the level of the round that separated member i from member i - 1
+    SHARED_ARRAY(uint64_t, cnt, CAP);          // [start] the three counts of a round
     SHARED_ARRAY(uint32_t, open, 1);
-    TL_DECL(idx_t, ra, TILE_EPT);
-    TL_DECL(uint32_t, rs, TILE_EPT);              // the member's subsegment (start), ~0: settled
-    TL_DECL(uint32_t, rc, TILE_EPT);              // class | rank << 2
-    TL_DECL(uint32_t, rl, TILE_EPT);              // the subsegment's level in this round
+    TL_DECL(idx_t, ra, EPT);
+    TL_DECL(uint32_t, rs, EPT);              // the member's subsegment (start), ~0: settled
+    TL_DECL(uint32_t, rc, EPT);              // class | rank << 2
+    TL_DECL(uint32_t, rl, EPT);              // the subsegment's level in this round
     const uint32_t g = qlist[K_BLOCK_IDX];
     const uint64_t s0 = seg_start[g], D0 = gdepth[g], p0 = gpos[g];
     const uint32_t N = (uint32_t)(seg_start[g + 1] - s0);
     PAR(tid) {
-        for (uint32_t e = tid; e < N; e += K_BLOCK_DIM) { ssa[e] = wsa[s0 + e]; sid[e] = 0; sep[e] = 0; }
+        for (uint32_t e = tid; e < N; e += NT) { ssa[e] = wsa[s0 + e]; sid[e] = 0; sep[e] = 0; }
         if (tid == 0) { slen[0] = (uint16_t)N; slvl[0] = 0; open[0] = N >= 2 ? 1u : 0u; }
     }
     for (;;) {
         SYNC();
         if (open[0] == 0) break;                                               // block-uniform
         PAR(tid) {                                 // A: the window of every member of an open subsegment at the subsegment's depth
-            for (uint32_t e = tid; e < N; e += K_BLOCK_DIM) {
+            for (uint32_t e = tid; e < N; e += NT) {
                 const uint32_t s = sid[e];
                 cnt[e] = 0;
                 if (slen[s] >= 2) {
@@ -4254,8 +4267,8 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) msd_quick_kernel(KCTX const uint32_t* __restric
         PAR(tid) {                                 // B: class and rank inside the class (one LDS atomic per member)
             if (tid == 0) open[0] = 0;
             UNROLL
-            for (uint32_t k = 0; k < TILE_EPT; ++k) {
-                const uint32_t e = tid + k * TILE_NT;
+            for (uint32_t k = 0; k < EPT; ++k) {
+                const uint32_t e = tid + k * NT;
                 TL(rs, tid, k) = ~0u;
                 if (e < N) {
                     const uint32_t s = sid[e];
@@ -4281,8 +4294,8 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) msd_quick_kernel(KCTX const uint32_t* __restric
         SYNC();
         PAR(tid) {                                 // C: the members of a subsegment move to their classes (everything was read in B)
             UNROLL
-            for (uint32_t k = 0; k < TILE_EPT; ++k) {
-                const uint32_t s = TL(rs, tid, k), e = tid + k * TILE_NT;
+            for (uint32_t k = 0; k < EPT; ++k) {
+                const uint32_t s = TL(rs, tid, k), e = tid + k * NT;
                 if (s != ~0u) {
                     const uint64_t pk = cnt[s];
                     const uint32_t n0 = (uint32_t)(pk & MSD_QK_MASK), n1 = (uint32_t)((pk >> MSD_QK_SHIFT) & MSD_QK_MASK), n2 = (uint32_t)(pk >> (2 * MSD_QK_SHIFT));
@@ -4300,8 +4313,8 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) msd_quick_kernel(KCTX const uint32_t* __restric
         SYNC();
         PAR(tid) {                                 // D: the first member of every class opens the class's record; a whole subsegment
             UNROLL                                 //    measures what its members share with the first one
-            for (uint32_t k = 0; k < TILE_EPT; ++k) {
-                const uint32_t s = TL(rs, tid, k);
+            for (uint32_t k = 0; k < EPT; ++k) {
+                const uint32_t s = TL(rs, tid + 0u, k);
                 if (s == ~0u) continue;
                 const uint32_t lvl = TL(rl, tid, k);
                 if (((TL(rc, tid, k) >> 2) & MSD_QK_MASK) == 0) {
@@ -4326,8 +4339,8 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) msd_quick_kernel(KCTX const uint32_t* __restric
         SYNC();
         PAR(tid) {                                 // E: ... and jumps there
             UNROLL
-            for (uint32_t k = 0; k < TILE_EPT; ++k) {
-                const uint32_t s = TL(rs, tid, k), e = tid + k * TILE_NT;
+            for (uint32_t k = 0; k < EPT; ++k) {
+                const uint32_t s = TL(rs, tid, k), e = tid + k * NT;
                 if (s != ~0u && (TL(rc, tid, k) & MSD_QK_WHOLE) && e == s && skey[s]) {
                     const uint64_t w = ~skey[s];
                     if (w > slvl[s]) slvl[s] = (uint32_t)(w < 0xFFFFFFFFull ? w : 0xFFFFFFFFull);
@@ -4336,7 +4349,7 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) msd_quick_kernel(KCTX const uint32_t* __restric
         }
     }
     PAR(tid) {                                     // the group in its final order: SA, and the LCPs from the separating rounds
-        for (uint32_t e = tid; e < N; e += K_BLOCK_DIM) {
+        for (uint32_t e = tid; e < N; e += NT) {
             const uint64_t a = (uint64_t)ssa[e];
             SA[p0 + e] = (idx_t)a;
             if (e) {

@@ -987,9 +987,10 @@ bool msd_refine(Backend& be, const uint32_t* P, uint64_t n, const SortResult<idx
     uint8_t* skip_tiles = ar.tail<uint8_t>(m0 / 2 + 2);
     uint32_t* wgid = ar.tail<uint32_t>(m0 + 2);
     uint32_t* flist = ar.tail<uint32_t>(m0 + 2);
-    uint32_t* qlist = ar.tail<uint32_t>(m0 / (MSD_FIN_MAX + 1) + 2);
+    uint32_t* qlist[3] = {ar.tail<uint32_t>(m0 / (MSD_FIN_MAX + 1) + 2), ar.tail<uint32_t>(m0 / (MSD_QK_CAP[0] + 1) + 2),
+                          ar.tail<uint32_t>(m0 / (MSD_QK_CAP[1] + 1) + 2)};
     uint64_t* edges = ar.tail<uint64_t>(2 * G0 + 4);
-    uint64_t* out3 = ar.tail<uint64_t>(8);
+    uint64_t* out3 = ar.tail<uint64_t>(12);
     if (ar.failed) return false;
     CAPS_LAUNCH((msd_compact0_kernel<idx_t>), (uint32_t)NF, 256, be, sd, (const uint32_t*)ftile, (const uint64_t*)toff, (const idx_t*)SA,
                 (const uint64_t*)flags0, (const uint64_t*)offs0, wsa0, segX, gposX, wgid, gdepX, (uint64_t)KCH, gplX);
@@ -997,7 +998,7 @@ bool msd_refine(Backend& be, const uint32_t* P, uint64_t n, const SortResult<idx
     uint64_t D = KCH;                                  // (the depth of the groups that never jumped: for the log)
     auto finish = [&](const uint64_t* seg, const uint64_t* gpos, const uint64_t* gdep, const idx_t* wsa, const uint32_t* gid, uint64_t m_bound) {
         const uint32_t ggrid = (uint32_t)std::min<uint64_t>((m_bound / 2 + 255) / 256 + 1, 4ull * be.persistent_blocks());
-        CAPS_LAUNCH(msd_groups_kernel, ggrid, 256, be, seg, skip, skip_tiles, flist, qlist, out3);
+        CAPS_LAUNCH(msd_groups_kernel, ggrid, 256, be, seg, skip, skip_tiles, flist, qlist[0], qlist[1], qlist[2], out3);
         const uint32_t grid = (uint32_t)std::min<uint64_t>((m_bound + MSD_FIN_MEMBERS - 1) / MSD_FIN_MEMBERS, 32ull * be.persistent_blocks());
         if (be.long_runs) CAPS_LAUNCH((msd_finish_kernel<idx_t, BITS, true>), grid ? grid : 1, 256, be, P, n, gdep, seg, gpos, wsa, gid, (const uint32_t*)flist, SA, LCP, (const uint64_t*)out3);
         else CAPS_LAUNCH((msd_finish_kernel<idx_t, BITS, false>), grid ? grid : 1, 256, be, P, n, gdep, seg, gpos, wsa, gid, (const uint32_t*)flist, SA, LCP, (const uint64_t*)out3);
@@ -1006,16 +1007,22 @@ bool msd_refine(Backend& be, const uint32_t* P, uint64_t n, const SortResult<idx
                 (const uint64_t*)gposX, (const uint64_t*)out3, edges);
     finish(segX, gposX, gdepX, wsa0, wgid, m0);
     // (the groups of up to a tile, each finished by one workgroup in LDS; launched once their number is known, reads this generation's tables)
-    auto quick = [&](const uint64_t* seg, const uint64_t* gpos, const uint64_t* gdep, const idx_t* wsa, uint64_t nq) {
-        if (!nq) return;
-        if (be.long_runs) CAPS_LAUNCH((msd_quick_kernel<idx_t, BITS, true>), (uint32_t)nq, TILE_NT, be, P, n, (const uint32_t*)qlist, seg, gpos, gdep, wsa, SA, LCP);
-        else CAPS_LAUNCH((msd_quick_kernel<idx_t, BITS, false>), (uint32_t)nq, TILE_NT, be, P, n, (const uint32_t*)qlist, seg, gpos, gdep, wsa, SA, LCP);
+    auto quick = [&](const uint64_t* seg, const uint64_t* gpos, const uint64_t* gdep, const idx_t* wsa, const uint64_t* nq) {
+        auto go = [&](auto cls) {
+            constexpr uint32_t C = decltype(cls)::value;
+            if (!nq[C]) return;
+            if (be.long_runs) CAPS_LAUNCH((msd_quick_kernel<idx_t, BITS, true, MSD_QK_CAP[C], MSD_QK_NT[C]>), (uint32_t)nq[C], MSD_QK_NT[C], be, P, n, (const uint32_t*)qlist[C], seg, gpos, gdep, wsa, SA, LCP);
+            else CAPS_LAUNCH((msd_quick_kernel<idx_t, BITS, false, MSD_QK_CAP[C], MSD_QK_NT[C]>), (uint32_t)nq[C], MSD_QK_NT[C], be, P, n, (const uint32_t*)qlist[C], seg, gpos, gdep, wsa, SA, LCP);
+        };
+        go(std::integral_constant<uint32_t, 2>());      // (the long ones first)
+        go(std::integral_constant<uint32_t, 1>());
+        go(std::integral_constant<uint32_t, 0>());
     };
-    uint64_t h3[7] = {0, 0, 0, 0, 0, 0, 0};
+    uint64_t h3[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     be.d2h(h3, out3, sizeof h3);
     be.sync();
     uint64_t G = h3[0], m = h3[1], nopen = h3[2], gmax = h3[3];
-    quick(segX, gposX, gdepX, wsa0, h3[6]);
+    quick(segX, gposX, gdepX, wsa0, h3 + 6);
     r.msd_groups = G;
     r.msd_elems = m;
     // (when every group is in its final order: the LCPs at its two ends, see msd_edges_kernel)
@@ -1025,7 +1032,7 @@ bool msd_refine(Backend& be, const uint32_t* P, uint64_t n, const SortResult<idx
                                  r.total, (const idx_t*)SA, LCP);
     };
     if (dbg) std::fprintf(stderr, "[msd] level 0: %llu flagged tiles, %llu elements in them, %llu groups of %llu members, %llu above %u finished in LDS, %llu above %u (largest %llu)\n",
-                          (unsigned long long)NF, (unsigned long long)M0, (unsigned long long)G, (unsigned long long)m, (unsigned long long)h3[6], MSD_FIN_MAX,
+                          (unsigned long long)NF, (unsigned long long)M0, (unsigned long long)G, (unsigned long long)m, (unsigned long long)(h3[6] + h3[7] + h3[8]), MSD_FIN_MAX,
                           (unsigned long long)nopen, MSD_QK_MAX, (unsigned long long)gmax);
     if (nopen == 0) { fix_edges(); return true; }
     // ---- the levels: work arrays for m members in at most m / 2 groups; level 0's outputs stay where they are (chunk tails)
@@ -1108,9 +1115,9 @@ bool msd_refine(Backend& be, const uint32_t* P, uint64_t n, const SortResult<idx
         m = h3[1];
         nopen = h3[2];
         gmax = h3[3];
-        quick(seg, gpos, gdep, in_sa, h3[6]);
+        quick(seg, gpos, gdep, in_sa, h3 + 6);
         if (dbg) std::fprintf(stderr, "[msd] depth %llu: %llu groups of %llu members, %llu above %u finished in LDS, %llu above %u (largest %llu)\n", (unsigned long long)D,
-                              (unsigned long long)G, (unsigned long long)m, (unsigned long long)h3[6], MSD_FIN_MAX, (unsigned long long)nopen,
+                              (unsigned long long)G, (unsigned long long)m, (unsigned long long)(h3[6] + h3[7] + h3[8]), MSD_FIN_MAX, (unsigned long long)nopen,
                               MSD_QK_MAX, (unsigned long long)gmax);
         if (G > Gm - 1 || m > cap2 - 2) return false;                   // (cannot happen: both only shrink)
     }
