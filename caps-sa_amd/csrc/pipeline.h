@@ -905,6 +905,7 @@ void sort_run_buckets(Backend& be, const uint32_t* P, uint64_t n, const SortResu
 
 // ---- deferred ties, resolved (kernels.h "Deferred ties, resolved") --------------------------------------------------
 // Work memory: the two element buffers of the sort, idle once its result is in SA / LCP -- two chunks of 16 (24) bytes per element.
+constexpr uint32_t MSD_MAX_LEVELS = 128;          // (GRCh38-shaped repeats: 7; a million-member group at 2 % divergence: ~15)
 struct MsdArena {
     char* lo[2] = {nullptr, nullptr};
     char* hi[2] = {nullptr, nullptr};
@@ -1068,7 +1069,14 @@ bool msd_refine(Backend& be, const uint32_t* P, uint64_t n, const SortResult<idx
     uint64_t* kin = E1.key;                                             // the level's keys before the sort; the flags after it
     uint64_t* flags = E1.key;
     uint64_t* offs = reinterpret_cast<uint64_t*>(E1.sa);
+    // A level takes 32 chars off a group.  Groups whose members agree for tens of thousands of chars WITHOUT ever coming out of a
+    // level unchanged (an exact tandem array of thousands of copies, a single-letter block outside quantile mode: every level
+    // peels the members that leave the array inside the window) would take a level per window: past MSD_MAX_LEVELS the groups
+    // are the comparators' business after all (the caller builds again without deferring; they know the run table).
+    uint32_t max_levels = MSD_MAX_LEVELS;
+    if (const char* ml = std::getenv("CAPS_SA_TEST_MSD_MAX_LEVELS")) max_levels = (uint32_t)std::atoi(ml);
     while (nopen > 0) {
+        if (r.msd_levels >= max_levels) return false;
         const uint32_t mg = (uint32_t)((m + 255) / 256);
         if (r.msd_levels) {                             // a group the last level left as it was jumps to what all its members share
             const uint32_t gg = (uint32_t)std::min<uint64_t>((G + 255) / 256 + 1, 4ull * be.persistent_blocks());

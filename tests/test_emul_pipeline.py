@@ -731,6 +731,19 @@ def test_groups_larger_than_a_tile_take_the_level_loop(monkeypatch):
         SA, LCP, st = E.build(T, p=0, idx_bits=bits)
         assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), (n, bits)
         assert st["path_direct"] == 1 and st["tie_groups_deferred"] > 0 and st["tie_levels"] >= 2, (n, st["tie_groups_deferred"], st["tie_levels"])
+    # an EXACT array of 900 copies: every level only peels the copies that leave the array inside its 32 chars -- ~650 levels; past
+    # MSD_MAX_LEVELS (pipeline.h) the groups go to the comparators after all: the build is done again without deferring
+    E = emul_small()
+    T = rs.choice(DNA, size=150_000)
+    _tandem(rs, T, 50_000, 23, 900, 0.0)
+    SAo, LCPo = sa_lcp(T)
+    SA, LCP, st = E.build(T, p=0)
+    assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo)
+    assert st["path_direct"] == 1 and st["tie_groups_deferred"] == 0, (st["tie_groups_deferred"], st["tie_levels"])
+    monkeypatch.setenv("CAPS_SA_TEST_MSD_MAX_LEVELS", "100000")     # ... and level by level to the end, with the cap lifted
+    SA, LCP, st = E.build(T, p=0)
+    assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo)
+    assert st["tie_groups_deferred"] > 0 and st["tie_levels"] > 128, (st["tie_groups_deferred"], st["tie_levels"])
 
 
 def test_deferred_groups_that_agree_for_thousands_of_chars_jump(monkeypatch):

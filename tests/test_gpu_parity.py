@@ -892,3 +892,11 @@ def test_groups_larger_than_a_tile_take_the_level_loop_device(L):
         SA, LCP, st = L.build(T, p=0, idx_bits=bits)
         assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), (n, bits)
         assert st["path_direct"] == 1 and st["tie_groups_deferred"] > 0 and st["tie_levels"] >= 2, (n, st["tie_groups_deferred"], st["tie_levels"])
+    # an EXACT array of 9000 copies would take a level per 32 chars of the array (~6,500): past MSD_MAX_LEVELS the build is done
+    # again without deferring (the comparators finish such groups)
+    T = rs.choice(DNA, size=1_200_000)
+    T[400_000:400_000 + 23 * 9000] = np.tile(rs.choice(DNA, size=23), 9000)
+    SAo, LCPo = sa_lcp(T)
+    SA, LCP, st = L.build(T, p=0)
+    assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo)
+    assert st["path_direct"] == 1 and st["tie_groups_deferred"] == 0, (st["tie_groups_deferred"], st["tie_levels"])
