@@ -103,6 +103,7 @@ class ShardInfo(ctypes.Structure):
         ("slot_splits", ctypes.c_uint32), ("slot_splits_redone", ctypes.c_uint32),
         ("key_bytes", ctypes.c_uint32), ("exchange", ctypes.c_uint32),
         ("direct_quantile", ctypes.c_uint32), ("run_buckets", ctypes.c_uint32),
+        ("tie_groups_deferred", ctypes.c_uint64), ("tie_levels", ctypes.c_uint32), ("reserved_", ctypes.c_uint32),
     ]
 
     def as_dict(self) -> dict:

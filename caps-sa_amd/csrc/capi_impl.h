@@ -516,6 +516,10 @@ int build_multi(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context,
             stats->ms_d2h = ms(t3, t4);
             stats->ms_total = ms(t1, t3);
             for (auto& q : ranks) { stats->slot_splits += q->info.slot_splits; stats->slot_splits_redone += q->info.slot_splits_redone; }
+            for (auto& q : ranks) {
+                stats->tie_groups_deferred += q->info.tie_groups_deferred;
+                stats->tie_levels = std::max(stats->tie_levels, q->info.tie_levels);
+            }
             stats->n_devices = (uint32_t)world;
             stats->result_waves = 1;
             stats->ms_upload_min = stats->ms_device_build_min = stats->ms_download_min = 1e300;

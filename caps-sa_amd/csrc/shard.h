@@ -180,6 +180,9 @@ public:
         o->exchange = direct_fb_ == CAPS_SA_FB_NONE && local_ ? 0u : 1u;
         o->direct_quantile = quantile_ ? 1u : 0u;
         o->run_buckets = run_buckets_;
+        o->tie_groups_deferred = tie_groups_;
+        o->tie_levels = tie_levels_;
+        o->reserved_ = 0;
         o->ms_scatter = ms_scatter_; o->ms_sort = ms_sort_;
         o->key_bytes = key_bits_ / 8;
         o->ms_level_a = ms_level_a_; o->ms_level_b = ms_level_b_ + ms_count_; o->ms_tile_sort = ms_tile_sort_; o->ms_merge_passes = ms_merge_;
@@ -486,8 +489,22 @@ public:
         int code = CAPS_SA_FB_NONE;
         if (recv_total_) {
             ::caps::prepare_segments(be_, seg2_, n_tiles2_ + 1, nullptr, nullptr, true);
-            const bool ok = bits_ == 2 ? sort_owned_bits<2>(d_recv_keys, d_recv_sa, dSA, dLCP)
-                                       : sort_owned_bits<8>(d_recv_keys, d_recv_sa, dSA, dLCP);
+            // large groups of equal keys are re-keyed, not compared (kernels.h "Deferred ties"): when every rank sorts the streams it
+            // scattered itself (no exchange) under 64-bit keys.  Groups that do not fit the work memory, or need more levels than
+            // msd_refine allows: level A again -- the sort has used its buffers -- and the sort with every tie compared
+            bool retry = false;
+            const bool defer = local_ && key_bits_ == 64 && !std::getenv("CAPS_SA_NO_DEFER");
+            bool ok = bits_ == 2 ? sort_owned_bits<2>(d_recv_keys, d_recv_sa, dSA, dLCP, defer, &retry)
+                                 : sort_owned_bits<8>(d_recv_keys, d_recv_sa, dSA, dLCP, defer, &retry);
+            if (ok && retry) {
+                uint32_t* dflag = reinterpret_cast<uint32_t*>(dstat_ + 2);
+                be_.memset(dstat_, 0, 4 * sizeof(uint64_t));
+                if (bits_ == 2) scatter_bits<2>(const_cast<void*>(d_recv_keys), const_cast<void*>(d_recv_sa), dflag);
+                else scatter_bits<8>(const_cast<void*>(d_recv_keys), const_cast<void*>(d_recv_sa), dflag);
+                ::caps::prepare_segments(be_, seg2_, n_tiles2_ + 1, nullptr, nullptr, true);
+                ok = bits_ == 2 ? sort_owned_bits<2>(d_recv_keys, d_recv_sa, dSA, dLCP, false, &retry)
+                                : sort_owned_bits<8>(d_recv_keys, d_recv_sa, dSA, dLCP, false, &retry);
+            }
             if (!ok) code = CAPS_SA_FB_KEY32;
             dSA_ = static_cast<idx_t*>(dSA);
         }
@@ -538,6 +555,8 @@ private:
     int bits_ = 0;
     uint32_t slot_stats_[2] = {0, 0};    // bucket splits of the current build: kept with slots / redone
     uint32_t run_buckets_ = 0;           // letter-run buckets of the last sort_owned (text.h "letter runs")
+    uint64_t tie_groups_ = 0;            // groups of equal keys the last sort_owned deferred (kernels.h "Deferred ties")
+    uint32_t tie_levels_ = 0;
     uint32_t h_flag_ = 0;                // scatter_bits: the fallback word on its way to the device
     uint32_t* P_ = nullptr;
     uint32_t* present_ = nullptr;
@@ -656,8 +675,11 @@ private:
         level_a_ran_ = true;
     }
 
-    template <int BITS> bool sort_owned_bits(const void* d_recv_keys, const void* d_recv_sa, void* dSA, void* dLCP)
+    template <int BITS> bool sort_owned_bits(const void* d_recv_keys, const void* d_recv_sa, void* dSA, void* dLCP, bool defer, bool* retry)
     {
+        *retry = false;
+        tie_groups_ = 0;
+        tie_levels_ = 0;
         SortOpts o;
         o.need_lcp = true;
         o.skip_finished = true;
@@ -679,6 +701,10 @@ private:
         o.slot_stats = slot_stats_;
         o.speculate = std::getenv("CAPS_SA_NO_SLOTS") == nullptr;
         if (key_bits_ == 32) { o.k32 = true; o.range_mode = 2; o.gshift = gshift_; o.speculate = true; }
+        if (defer && bk_.fcount) {
+            o.defer_flags = bk_.fcount;           // (the fine-count table: idle outside the equalised split)
+            o.run_tables = &seg1_;                // (idle since level A; the bucket tables stay intact for msd_refine)
+        }
         if (quantile_) {                          // the owned groups' buckets are (knots[k - 1], knots[k]], KPG per group
             o.knots = knots_ + (size_t)jlo_ * KPG_;
             o.knots_per_parent = KPG_;
@@ -696,6 +722,9 @@ private:
         run_buckets_ = (uint32_t)r.run_buckets.size();
         if (r.failed) return false;
         finalize<idx_t, BITS>(be_, P_, n_, r, static_cast<idx_t*>(dSA), static_cast<idx_t*>(dLCP));
+        if (r.msd_failed) { *retry = true; return true; }
+        tie_groups_ = r.msd_groups;
+        tie_levels_ = r.msd_levels;
         return true;
     }
 

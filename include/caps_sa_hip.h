@@ -287,6 +287,9 @@ typedef struct caps_sa_shard_info {
     uint32_t direct_quantile;      /* 1: the last shard_scatter chose quantile buckets for level B (skewed keys, frequent keys, long
                                       runs; csrc/pipeline.h Builder::run_direct) -- no-exchange mode only */
     uint32_t run_buckets;          /* letter-run buckets of the last shard_sort (see caps_sa_stats.run_buckets) */
+    uint64_t tie_groups_deferred;  /* groups of equal keys the last shard_sort re-keyed instead of comparing (see caps_sa_stats; no-exchange
+                                      mode, 64-bit keys) */
+    uint32_t tie_levels, reserved_;
 } caps_sa_shard_info;
 
 int caps_sa_hip_shard_create(const void* dT, uint64_t n, uint64_t subproblem_count, int idx_bytes, int rank, int world,

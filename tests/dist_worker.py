@@ -45,6 +45,20 @@ def main():
     runs = rs.choice(dna, size=180_000)
     runs[20_000:26_000] = ord("G")                                           # an N-block: long run -> every rank falls back together
     cases.append((runs, 0, 32))
+    # tandem arrays: thousands of suffixes with one key -- deferred and re-keyed on the rank that owns them (kernels.h "Deferred ties";
+    # every rank sorts what it scattered itself: not in exchange mode), checked against the independent construction
+    rep = rs.choice(dna, size=160_000)
+    for at, unit, copies, rate in [(30_000, 23, 700, 0.003), (90_000, 57, 150, 0.02), (160_000 - 31 * 40, 31, 40, 0.0)]:
+        seg = np.tile(rs.choice(dna, size=unit), copies)
+        mut = rs.rand(seg.size) < rate
+        seg[mut] = rs.choice(dna, size=int(mut.sum()))
+        rep[at:at + seg.size] = seg
+    cases.append((rep, 0, 32))
+    if os.environ.get("CAPS_DIST_CASE") == "repeats":
+        cases = [(rep, 0, 32), (rep[:120_001].copy(), 0, 64)]
+        rep2 = cases[1][0]
+    else:
+        rep2 = None
     if world >= 8:          # a node's worth of ranks: every case with a few partitions per rank (fewer is refused, see "imbalance")
         cases = [(rs.choice(dna, size=150_001), 24, 32), (rs.choice(np.frombuffer(b"abcdefgh", dtype=np.uint8), size=60_000), 32, 64),
                  (rs.choice(dna, size=200_000, p=[0.6, 0.2, 0.1, 0.1]), 40, 64), (runs, 0, 32)]
@@ -62,8 +76,17 @@ def main():
         SA_all = caps_sa_dist._all_gather_var(SA, counts).numpy()
         LCP_all = caps_sa_dist._all_gather_var(LCP, counts).numpy()
         dt = np.uint32 if bits == 32 else np.uint64
-        SAo, LCPo = (O.naive_sa_lcp(T_np, idx_bits=bits) if T_np.size <= 200_000 else O.build_sa_lcp(T_np, p=p, idx_bits=bits)[:2])
+        if T_np is rep or T_np is rep2:
+            from sa_check import sa_lcp
+            SAo, LCPo = sa_lcp(T_np, idx_bits=bits)
+        else:
+            SAo, LCPo = (O.naive_sa_lcp(T_np, idx_bits=bits) if T_np.size <= 200_000 else O.build_sa_lcp(T_np, p=p, idx_bits=bits)[:2])
         good = np.array_equal(SA_all.view(dt), SAo) and np.array_equal(LCP_all.view(dt), LCPo)
+        ties = torch.tensor([int(info.get("tie_groups_deferred", 0))], dtype=torch.int64)
+        dist.all_reduce(ties)
+        if T_np is rep and info["path"] == "direct" and not info.get("exchange", 1):
+            # (CAPS_SA_TEST_MSD_FAIL: the refinement "does not fit" -- the rank scatters again and compares every tie)
+            good = good and (int(ties) == 0 if os.environ.get("CAPS_SA_TEST_MSD_FAIL") else int(ties) > 0)
         # the slice-wise verifier bench.py uses at N > 1 (nothing gathered): clean on the result, loud on a corrupted one
         good = good and caps_sa_dist.verify_sharded(E, T, SA, LCP, off, bits) == 0
         if T_np.size >= 40_000:
@@ -75,7 +98,7 @@ def main():
             good = good and caps_sa_dist.verify_sharded(E, T, bad_sa, bad_lcp, off, bits) >= 2
         if rank == 0:
             print(f"case n={T_np.size} p={p} bits={bits} path={info['path']} fb={info.get('direct_fallback')} keys={info.get('key_bytes')} "
-                  f"retry={info.get('key_retry')} exch={info.get('exchange')} quant={info.get('direct_quantile')} counts={counts} "
+                  f"retry={info.get('key_retry')} exch={info.get('exchange')} quant={info.get('direct_quantile')} ties={int(ties)} counts={counts} "
                   f"{'OK' if good else 'MISMATCH'}", flush=True)
         ok = ok and good
     dist.destroy_process_group()

@@ -119,4 +119,5 @@ def _stitch(shards, bufs, n, sync, path):
     SA = torch.cat([B.SA[:c] for B, c in zip(bufs, lens)])
     LCP = torch.cat([B.LCP[:c] for B, c in zip(bufs, lens)])
     build_world.last_path = path
+    build_world.last_tie_groups = sum(int(i.get("tie_groups_deferred", 0)) for i in infos)
     return SA, LCP

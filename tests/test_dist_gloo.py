@@ -36,7 +36,7 @@ def test_sharded_build_matches_oracle(world, port, a2a_limit, small, path, excha
     if world >= 8:                                     # (its own, shorter case list: dist_worker.py)
         assert r.stdout.count(" OK") == 4 and "path=direct" in r.stdout, r.stdout
         return
-    assert r.stdout.count(" OK") == 8, r.stdout
+    assert r.stdout.count(" OK") == 9, r.stdout
     if path == "classic":
         assert "path=direct" not in r.stdout
     else:
@@ -64,3 +64,23 @@ def test_imbalanced_ownership_fails_on_every_rank_together():
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count("refused") == 2, r.stdout
+
+
+@pytest.mark.parametrize("small", [0, 1])
+def test_sharded_deferral_and_its_retry_over_gloo(small):
+    """Deferred ties in the sharded build (shard.h sort_owned): tandem arrays on two ranks, u32 and u64 -- re-keyed on the rank that
+    owns them; and with CAPS_SA_TEST_MSD_FAIL=1 (the refinement's work memory "does not fit"): every rank runs its level A again
+    and sorts with every tie compared.  Both against tests/sa_check.py."""
+    for fail in (False, True):
+        env = dict(os.environ, CAPS_DIST_CASE="repeats", CAPS_EMUL_SMALL=str(small), PYTHONPATH=ROOT)
+        env.pop("CAPS_SA_SHARD_EXCHANGE", None)
+        if fail:
+            env["CAPS_SA_TEST_MSD_FAIL"] = "1"
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+               "--master-port", "29547", os.path.join(ROOT, "tests", "dist_worker.py")]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        assert r.stdout.count(" OK") == 2, r.stdout
+        first = [ln for ln in r.stdout.splitlines() if ln.startswith("case n=160000 ")]
+        assert len(first) == 1 and "path=direct" in first[0] and "exch=0" in first[0], r.stdout
+        assert ("ties=0 " in first[0]) == fail, first[0]

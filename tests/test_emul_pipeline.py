@@ -350,6 +350,18 @@ def test_one_process_several_devices(oracle, monkeypatch):
     SA, LCP, st = E.build_multi(T, [0, 0, 0], p=0)
     SAo, LCPo = oracle.build_sa_lcp(T, p=64)
     assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo) and st["path_fallback"] != 0
+    # tandem arrays: the groups of equal keys are deferred and re-keyed on the device that owns them (shard.h sort_owned)
+    from sa_check import sa_lcp
+    T = rs.choice(DNA, size=160_000)
+    for at, unit, copies, rate in [(30_000, 23, 700, 0.003), (90_000, 57, 150, 0.02)]:
+        seg = np.tile(rs.choice(DNA, size=unit), copies)
+        mut = rs.rand(seg.size) < rate
+        seg[mut] = rs.choice(DNA, size=int(mut.sum()))
+        T[at:at + seg.size] = seg
+    SAo, LCPo = sa_lcp(T)
+    SA, LCP, st = E.build_multi(T, [0, 0], p=0)
+    assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo)
+    assert st["path_direct"] == 1 and st["n_devices"] == 2 and st["tie_groups_deferred"] > 0, st["tie_groups_deferred"]
 
 
 def test_cli_validates_before_it_writes(tmp_path):

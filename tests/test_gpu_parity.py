@@ -615,7 +615,7 @@ def test_shard_kernels_at_world_sizes_above_one_loopback(L, sa_path, world, n, p
         assert (build_world.last_exchange, build_world.last_key_bytes, build_world.last_key_retry) == ((1, 4, 0) if exchange else (0, 8, 0))
 
 
-@pytest.mark.parametrize("world,kind", [(4, "genome"), (2, "genome+n"), (8, "genome+n")])
+@pytest.mark.parametrize("world,kind", [(4, "genome"), (2, "genome+n"), (8, "genome+n"), (2, "genome+r"), (4, "genome+r")])
 def test_shard_quantile_mode_on_genome_like_text_loopback(L, world, kind, monkeypatch):
     """The sharded direct path on skewed keys and N-block stand-ins (tools/genome_like.py, 96 Mi bases): every rank takes the
     quantile buckets of Builder::run_direct for the groups it owns (no exchange) -- same arrays as the single-GPU build."""
@@ -637,6 +637,8 @@ def test_shard_quantile_mode_on_genome_like_text_loopback(L, world, kind, monkey
     SA, LCP = build_world(L, T, 8000, world, 32)
     assert torch.equal(SA, SA1) and torch.equal(LCP, LCP1)
     assert build_world.last_path == "direct" and build_world.last_quantile == 1 and build_world.last_exchange == 0
+    if kind == "genome+r":          # the satellite arrays' groups of equal keys are re-keyed on the ranks that own them, not compared
+        assert build_world.last_tie_groups > 100, build_world.last_tie_groups
 
 
 def test_shard_key_width_retry_on_skewed_keys_loopback(L, monkeypatch):
