@@ -3,7 +3,8 @@ arrays of random unit length / copy number / divergence, higher-order arrays, re
 blocks, texts that end inside a repeat -- against tests/sa_check.py (prefix doubling + Kasai: independent of the oracle, and not
 quadratic on such texts).  Every build bit for bit; the last line counts builds, builds that deferred, and the largest tie_levels.
 
-    python3 tools/stress_repeats.py <builds> <seed> [gpu | emul | emul_small]     (STRESS_MAX_N: largest text, default 2,500,000)
+    python3 tools/stress_repeats.py <builds> <seed> [gpu | emul | emul_small]     (STRESS_MAX_N: largest text, default 2,500,000;
+                                                                                   STRESS_MULTI=1: 2 - 8 ranks of the sharded build)
 
 gpu: libcaps_sa_hip.so on cuda:0 (run on the GPU box); emul / emul_small: the host emulation (4096- / 256-element tiles)."""
 import json
@@ -96,7 +97,9 @@ def main():
         else:
             os.environ.pop("CAPS_SA_DIRECT_MODE", None)
         SAo, LCPo = sa_lcp(T, idx_bits=bits)
-        SA, LCP, st = L.build(T, p=p, idx_bits=bits)
+        world = int(rs.choice([2, 3, 4, 8])) if os.environ.get("STRESS_MULTI") == "1" else 1
+        # STRESS_MULTI=1: the sharded build (caps_sa_hip_build_multi_*), all ranks on device 0 -- the ranks defer and retry on their own
+        SA, LCP, st = L.build_multi(T, [0] * world, p=p, idx_bits=bits) if world > 1 else L.build(T, p=p, idx_bits=bits)
         ok = bool(np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo))
         tot["builds"] += 1
         tot["direct"] += int(st["path_direct"])
