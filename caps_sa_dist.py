@@ -273,9 +273,17 @@ def bench_main(args, rank: int, local_rank: int, world: int):
     """bench.py's N > 1 leg: same text on every GPU, strong scaling."""
     import caps_sa_amd
     from bench import WORKLOADS, make_text, roofline, cpu_baseline
+    # CAPS_SA_DIST_REHEARSAL=1 (a one-GPU box): every rank on device 0, collectives over gloo -- RCCL refuses two ranks on one
+    # device.  Exercises this function's N > 1 logic (mode calibration, max over ranks, slice sums, the rank-0 line); its timings
+    # mean nothing (the ranks share the GPU).
+    rehearsal = os.environ.get("CAPS_SA_DIST_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world == 1 and "RANK" not in os.environ:          # forced single-rank run without torchrun
+    if rehearsal:
+        dist.init_process_group("gloo")
+    elif world == 1 and "RANK" not in os.environ:        # forced single-rank run without torchrun
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
