@@ -315,23 +315,40 @@ def bench_main(args, rank: int, local_rank: int, world: int):
         mode = "exchange"
     calib = None
     if mode == "auto" and world > 1:
-        calib = {}
+        calib, calib_errors = {}, {}
         for m in ("local", "exchange"):
-            s_, b_ = make_shard(m)
-            build_sharded(L, T, args.p, idx_bits, stream, shard=s_, bufs=b_)            # first build: allocations, RCCL connections
-            dist.barrier()
-            torch.cuda.synchronize()
-            t_ = time.perf_counter()
-            build_sharded(L, T, args.p, idx_bits, stream, shard=s_, bufs=b_)
-            dist.barrier()
-            torch.cuda.synchronize()
-            el_ = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device=dev)
+            # a trial that fails (the exchange variant has never run over RCCL: its buffers, its all-to-all) must not cost the run:
+            # the ranks agree on the failure (errors of this kind -- out of memory, a refused message size -- hit every rank alike)
+            # and the mode is left out.  The default mode failing is an error as before.
+            s_ = b_ = None
+            err = None
+            try:
+                s_, b_ = make_shard(m)
+                build_sharded(L, T, args.p, idx_bits, stream, shard=s_, bufs=b_)        # first build: allocations, RCCL connections
+                dist.barrier()
+                torch.cuda.synchronize()
+                t_ = time.perf_counter()
+                build_sharded(L, T, args.p, idx_bits, stream, shard=s_, bufs=b_)
+                dist.barrier()
+                torch.cuda.synchronize()
+                took = time.perf_counter() - t_
+            except Exception as e:          # noqa: BLE001
+                if m == "local":
+                    raise
+                err, took = e, 0.0
+            el_ = torch.tensor([took, 1.0 if err is not None else 0.0], dtype=torch.float64, device=dev)
             dist.all_reduce(el_, op=dist.ReduceOp.MAX)
-            calib[m] = 1e3 * float(el_.item())
-            s_.close()
+            if float(el_[1].item()) != 0.0:
+                calib_errors[m] = repr(err) if err is not None else "failed on another rank"
+            else:
+                calib[m] = 1e3 * float(el_[0].item())
+            if s_ is not None:
+                s_.close()
             del s_, b_
             torch.cuda.empty_cache()
         mode = min(calib, key=calib.get)
+        if calib_errors:
+            calib = dict(calib, errors=calib_errors)
     elif mode == "auto":
         mode = "local"
     sh, bufs = make_shard(mode)
