@@ -4232,58 +4232,54 @@ GLOBAL_FN LAUNCH_BOUNDS(NT) msd_quick_kernel(KCTX const uint32_t* __restrict__ P
     constexpr uint32_t KCH = TextTraits<BITS>::KCH, EPT = CAP / NT;
     static_assert(CAP % NT == 0 && CAP <= MSD_QK_MAX, "capacity classes");
     SHARED_ARRAY(idx_t, ssa, CAP);
-    SHARED_ARRAY(uint64_t, skey, CAP);
     SHARED_ARRAY(uint16_t, sid, CAP);          // the start of the member's subsegment
     SHARED_ARRAY(uint16_t, slen, CAP);         // [start] members (1: settled)
     SHARED_ARRAY(uint32_t, slvl, CAP);         // [start] windows behind D0 its members are known to share
     SHARED_ARRAY(uint32_t, sep, CAP);          // [i] the level of the round that separated member i from member i - 1
-    SHARED_ARRAY(uint64_t, cnt, CAP);          // [start] the three counts of a round
-    SHARED_ARRAY(uint32_t, open, 1);
+    SHARED_ARRAY(uint64_t, cnt, CAP);          // [start] the three counts of a round (zero between rounds)
+    SHARED_ARRAY(uint64_t, jacc, CAP / 2);     // [start / 2] what a subsegment that came out whole shares, inverted minimum (zero between rounds;
+                                               //   an open subsegment has two members at least: start / 2 is its own)
+    SHARED_ARRAY(uint32_t, open, 2);           // [round & 1] a subsegment of two or more members is left
     TL_DECL(idx_t, ra, EPT);
+    TL_DECL(idx_t, rp, EPT);                 // the first member of the subsegment this round (the one the others are compared with)
     TL_DECL(uint32_t, rs, EPT);              // the member's subsegment (start), ~0: settled
-    TL_DECL(uint32_t, rc, EPT);              // class | rank << 2
+    TL_DECL(uint32_t, rc, EPT);              // class | rank << 2 | MSD_QK_WHOLE
     TL_DECL(uint32_t, rl, EPT);              // the subsegment's level in this round
     const uint32_t g = qlist[K_BLOCK_IDX];
     const uint64_t s0 = seg_start[g], D0 = gdepth[g], p0 = gpos[g];
     const uint32_t N = (uint32_t)(seg_start[g + 1] - s0);
     PAR(tid) {
-        for (uint32_t e = tid; e < N; e += NT) { ssa[e] = wsa[s0 + e]; sid[e] = 0; sep[e] = 0; }
-        if (tid == 0) { slen[0] = (uint16_t)N; slvl[0] = 0; open[0] = N >= 2 ? 1u : 0u; }
+        for (uint32_t e = tid; e < N; e += NT) { ssa[e] = wsa[s0 + e]; sid[e] = 0; sep[e] = 0; cnt[e] = 0; jacc[e >> 1] = 0; }
+        if (tid == 0) { slen[0] = (uint16_t)N; slvl[0] = 0; open[0] = 0; open[1] = N >= 2 ? 1u : 0u; }
     }
-    for (;;) {
+    // Three barriers per round (a round is as long as its trip to the text and its barriers: the launch lasts as long as its deepest
+    // group, hundreds of rounds): every member fetches its own window AND the first member's (no hand-over through LDS), classes,
+    // moves and records share a phase (everything they read was read before the barrier in front of them).
+    for (uint32_t round = 0;; ++round) {
         SYNC();
-        if (open[0] == 0) break;                                               // block-uniform
-        PAR(tid) {                                 // A: the window of every member of an open subsegment at the subsegment's depth
-            for (uint32_t e = tid; e < N; e += NT) {
-                const uint32_t s = sid[e];
-                cnt[e] = 0;
-                if (slen[s] >= 2) {
-                    const uint64_t pos = (uint64_t)ssa[e] + D0 + (uint64_t)slvl[s] * KCH;
-                    skey[e] = pos < n ? window64<BITS>(P, pos) : 0;
-                }
-            }
-        }
-        SYNC();
-        PAR(tid) {                                 // B: class and rank inside the class (one LDS atomic per member)
-            if (tid == 0) open[0] = 0;
+        if (open[(round + 1u) & 1u] == 0) break;                               // block-uniform; set in the round before (or at the start)
+        PAR(tid) {                                 // 1: windows, class, rank inside the class (one LDS atomic per member)
+            if (tid == 0) open[round & 1u] = 0;                                //    (this round's flag: last read two barriers ago)
             UNROLL
             for (uint32_t k = 0; k < EPT; ++k) {
                 const uint32_t e = tid + k * NT;
                 TL(rs, tid, k) = ~0u;
                 if (e < N) {
                     const uint32_t s = sid[e];
-                    const idx_t a = ssa[e];
-                    TL(ra, tid, k) = a;
                     if (slen[s] >= 2) {
                         const uint32_t lvl = slvl[s];
-                        const uint64_t depth = D0 + (uint64_t)lvl * KCH, kp = skey[s], key = skey[e];
-                        const uint64_t ap = (uint64_t)ssa[s];
+                        const idx_t a = ssa[e], apx = ssa[s];
+                        const uint64_t depth = D0 + (uint64_t)lvl * KCH, ap = (uint64_t)apx;
+                        const uint64_t pa = (uint64_t)a + depth, pp = ap + depth;
+                        const uint64_t key = pa < n ? window64<BITS>(P, pa) : 0, kp = pp < n ? window64<BITS>(P, pp) : 0;
                         uint32_t c = 1;
                         if (e != s) {
                             if (key != kp) c = key < kp ? 0u : 2u;
                             else if (msd_ending<BITS>(n, (uint64_t)a, depth) || msd_ending<BITS>(n, ap, depth)) c = (uint64_t)a > ap ? 0u : 2u;
                         }
                         const uint64_t old = FETCH_ADD_U64(&cnt[s], 1ull << (MSD_QK_SHIFT * c));
+                        TL(ra, tid, k) = a;
+                        TL(rp, tid, k) = apx;
                         TL(rs, tid, k) = s;
                         TL(rl, tid, k) = lvl;
                         TL(rc, tid, k) = c | ((uint32_t)((old >> (MSD_QK_SHIFT * c)) & MSD_QK_MASK) << 2);
@@ -4292,58 +4288,46 @@ GLOBAL_FN LAUNCH_BOUNDS(NT) msd_quick_kernel(KCTX const uint32_t* __restrict__ P
             }
         }
         SYNC();
-        PAR(tid) {                                 // C: the members of a subsegment move to their classes (everything was read in B)
-            UNROLL
-            for (uint32_t k = 0; k < EPT; ++k) {
-                const uint32_t s = TL(rs, tid, k), e = tid + k * NT;
-                if (s != ~0u) {
-                    const uint64_t pk = cnt[s];
-                    const uint32_t n0 = (uint32_t)(pk & MSD_QK_MASK), n1 = (uint32_t)((pk >> MSD_QK_SHIFT) & MSD_QK_MASK), n2 = (uint32_t)(pk >> (2 * MSD_QK_SHIFT));
-                    const uint32_t c = TL(rc, tid, k) & 3u, r = (TL(rc, tid, k) >> 2) & MSD_QK_MASK;
-                    const uint32_t base = s + (c == 0 ? 0u : c == 1 ? n0 : n0 + n1);
-                    ssa[base + r] = TL(ra, tid, k);
-                    sid[base + r] = (uint16_t)base;
-                    if (n0 == 0 && n2 == 0 && n1 >= 2) {   // the subsegment comes out whole: it will jump (its key slot collects how far)
-                        TL(rc, tid, k) |= MSD_QK_WHOLE;
-                        if (e == s) skey[s] = 0;
-                    }
-                }
-            }
-        }
-        SYNC();
-        PAR(tid) {                                 // D: the first member of every class opens the class's record; a whole subsegment
-            UNROLL                                 //    measures what its members share with the first one
+        PAR(tid) {                                 // 2: the members move to their classes; the first of every class opens the class's record; a
+            UNROLL                                 //    subsegment that came out whole measures what its members share with its first one
             for (uint32_t k = 0; k < EPT; ++k) {
                 const uint32_t s = TL(rs, tid + 0u, k);
                 if (s == ~0u) continue;
-                const uint32_t lvl = TL(rl, tid, k);
-                if (((TL(rc, tid, k) >> 2) & MSD_QK_MASK) == 0) {
-                    const uint64_t pk = cnt[s];
-                    const uint32_t n0 = (uint32_t)(pk & MSD_QK_MASK), n1 = (uint32_t)((pk >> MSD_QK_SHIFT) & MSD_QK_MASK), n2 = (uint32_t)(pk >> (2 * MSD_QK_SHIFT));
-                    const uint32_t c = TL(rc, tid, k) & 3u;
-                    const uint32_t base = s + (c == 0 ? 0u : c == 1 ? n0 : n0 + n1), nc = c == 0 ? n0 : c == 1 ? n1 : n2;
+                const uint64_t pk = cnt[s];
+                const uint32_t n0 = (uint32_t)(pk & MSD_QK_MASK), n1 = (uint32_t)((pk >> MSD_QK_SHIFT) & MSD_QK_MASK), n2 = (uint32_t)(pk >> (2 * MSD_QK_SHIFT));
+                const uint32_t c = TL(rc, tid, k) & 3u, r = (TL(rc, tid, k) >> 2) & MSD_QK_MASK, lvl = TL(rl, tid, k);
+                const uint32_t base = s + (c == 0 ? 0u : c == 1 ? n0 : n0 + n1);
+                ssa[base + r] = TL(ra, tid, k);
+                sid[base + r] = (uint16_t)base;
+                if (r == 0) {
+                    const uint32_t nc = c == 0 ? n0 : c == 1 ? n1 : n2;
                     slen[base] = (uint16_t)nc;
                     slvl[base] = lvl + (c == 1 ? 1u : 0u);
                     if (base != s) sep[base] = lvl;
-                    if (nc >= 2) open[0] = 1;
+                    if (nc >= 2) open[round & 1u] = 1;
                 }
-                if (TL(rc, tid, k) & MSD_QK_WHOLE) {
-                    const uint64_t a = (uint64_t)TL(ra, tid, k), ap = (uint64_t)ssa[s];
+                if (n0 == 0 && n2 == 0 && n1 >= 2) {
+                    TL(rc, tid, k) |= MSD_QK_WHOLE;
+                    const uint64_t a = (uint64_t)TL(ra, tid, k), ap = (uint64_t)TL(rp, tid, k);
                     if (a != ap) {
                         const uint64_t l = deep_lcp<BITS, RUNS>(P, n, ap, a, D0 + ((uint64_t)lvl + 1u) * KCH);
-                        ATOMIC_MAX_LDS_U64(&skey[s], ~((l - D0) / KCH));                     // (the minimum, inverted)
+                        ATOMIC_MAX_LDS_U64(&jacc[s >> 1], ~((l - D0) / KCH));                    // (the minimum, inverted)
                     }
                 }
             }
         }
         SYNC();
-        PAR(tid) {                                 // E: ... and jumps there
+        PAR(tid) {                                 // 3: ... and jumps there; the counters are zero again
             UNROLL
             for (uint32_t k = 0; k < EPT; ++k) {
                 const uint32_t s = TL(rs, tid, k), e = tid + k * NT;
-                if (s != ~0u && (TL(rc, tid, k) & MSD_QK_WHOLE) && e == s && skey[s]) {
-                    const uint64_t w = ~skey[s];
-                    if (w > slvl[s]) slvl[s] = (uint32_t)(w < 0xFFFFFFFFull ? w : 0xFFFFFFFFull);
+                if (s != ~0u && e == s) {
+                    cnt[s] = 0;
+                    if ((TL(rc, tid, k) & MSD_QK_WHOLE) && jacc[s >> 1]) {
+                        const uint64_t w = ~jacc[s >> 1];
+                        jacc[s >> 1] = 0;
+                        if (w > slvl[s]) slvl[s] = (uint32_t)(w < 0xFFFFFFFFull ? w : 0xFFFFFFFFull);
+                    }
                 }
             }
         }
