@@ -184,17 +184,22 @@ def kernel_sources_sha256():
     return h.hexdigest()
 
 
-def roofline(kernels, w, traffic_key):
-    """kernels: {family: (ms summed over its launches, launches, elements summed)} over the timed steps.
-    Every family is one streaming pass over the suffixes; algorithmic bytes = 4w per suffix (read + write of an SA- and
-    an LCP-sized payload: SURVEY 8d's per-pass figure).  The dominant (largest summed time) family is the headline;
-    all of them are listed."""
-    moved = {                               # what a pass really moves per suffix (64-bit keys travel with the indices)
+def roofline(kernels, w, traffic_key, build_ms_total):
+    """kernels: {family: (ms summed over its launches, launches, elements summed, algorithmic bytes per element or None)} over the
+    timed steps.  The streaming passes over the suffixes (level A, level B count and scatter, tile sort, merge passes) are priced
+    at the algorithmic 4w bytes per suffix (read + write of an SA- and an LCP-sized payload: SURVEY 8d's per-pass figure); the
+    small families at what they must move (pack: text in, packed text + run table out; deferred ties: key + index in and out per
+    level).  The dominant (largest summed time) family is the headline; all of them are listed, and `coverage_of_build` says what
+    share of the builds' device time they explain."""
+    moved = {                               # what a pass really moves per element (64-bit keys travel with the indices)
+        "pack": 1.0 + 0.25 + 0.25,                               # text in, 2-bit text + run table out
         "level_a_scatter": 0.25 + (8 + w),                       # packed text in, (key, sa) out
+        "level_b_count": 8 + 2,                                  # keys in, 16-bit bucket ids out
         "level_b_scatter": 2 * (8 + w),                          # (key, sa) in and out
         "bucket_scatter_kernel": 2 * (8 + w),
         "tile_sort_kernel": (8 + w) + 2 * w,                     # (key, sa) in, SA + LCP out
         "merge_pass_kernel": 2 * (8 + w),
+        "deferred_ties": 2 * (8 + w),
     }
     traffic, traffic_note = {}, "no profiles/traffic.json"
     try:
@@ -209,11 +214,11 @@ def roofline(kernels, w, traffic_key):
     except OSError:
         pass
     rows = {}
-    for name, (ms, launches, elems) in kernels.items():
+    for name, (ms, launches, elems, alg_per_elem) in kernels.items():
         if not launches or ms <= 0:
             continue
         avg_ms = ms / launches
-        alg = 4 * w * (elems / launches)
+        alg = (alg_per_elem if alg_per_elem is not None else 4 * w) * (elems / launches)
         ach = alg / (avg_ms * 1e-3) / 1e9
         rows[name] = {"avg_launch_ms": avg_ms, "launches": launches, "achieved": ach, "frac": ach / HBM_PEAK_GBS,
                       "algorithmic_bytes_per_launch": alg,
@@ -223,11 +228,14 @@ def roofline(kernels, w, traffic_key):
         return None
     dom = max(rows, key=lambda k: rows[k]["avg_launch_ms"] * rows[k]["launches"])
     d = rows[dom]
+    explained = sum(r["avg_launch_ms"] * r["launches"] for r in rows.values())
     return {"bound": "hbm", "kernel": dom, "achieved": d["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac"],
             "traffic": d["traffic"], "avg_launch_ms": d["avg_launch_ms"],
             "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"],
             "moved_bytes_per_launch_incl_keys": d["moved_bytes_per_launch_incl_keys"],
             "traffic_source": traffic_note,
+            "coverage_of_build": explained / build_ms_total if build_ms_total > 0 else None,
+            "coverage_note": "sum of the families' device times (HIP events on the build's stream) / sum of the builds' device times (ms_total)",
             "kernels": rows}
 
 
@@ -331,19 +339,34 @@ def main():
     w = idx_bits // 8
     direct = all(s["path_direct"] for s in stats)
     fams = {}
+    S = len(stats)
+    tot = lambda k: sum(s[k] for s in stats)                                               # noqa: E731
+    bits = stats[-1]["bits_per_char"]
+    fams["pack"] = (tot("ms_pack"), S, n * S, 1.0 + bits / 8.0 + bits / 8.0)             # text in; packed text + run table out
+    # samples -> sorted -> pivots / knots / group keys: its elements are the samples, a few per mille of the suffixes
+    m_samples = stats[-1]["p_eff"] * stats[-1]["ppp"]
+    fams["sample_pivots"] = (tot("ms_select_pivots"), S, m_samples * S, 2.0 * (8 + w))
     if direct:      # the first scatter launch of a direct build is level A (text -> groups), the second level B
-        la = sum(s["level_a_ms"] for s in stats)
-        fams["level_a_scatter"] = (la, len(stats), n * len(stats))
+        fams["level_a_scatter"] = (tot("level_a_ms"), S, n * S, None)
         lb = sum(s["bucket_scatter_ms"] - s["level_a_ms"] for s in stats)
-        fams["level_b_scatter"] = (lb, sum(s["bucket_scatter_launches"] - 1 for s in stats), n * len(stats))
+        fams["level_b_scatter"] = (lb, sum(s["bucket_scatter_launches"] - 1 for s in stats), n * S, None)
     else:
-        fams["bucket_scatter_kernel"] = (sum(s["bucket_scatter_ms"] for s in stats), sum(s["bucket_scatter_launches"] for s in stats),
-                                         sum(s["bucket_scatter_elems"] for s in stats))
-    fams["tile_sort_kernel"] = (sum(s["tile_sort_ms"] for s in stats), sum(s["tile_sort_launches"] for s in stats),
-                                sum(s["tile_sort_elems"] for s in stats))
-    fams["merge_pass_kernel"] = (sum(s["merge_pass_ms"] for s in stats), sum(s["merge_pass_launches"] for s in stats),
-                                 sum(s["merge_pass_elems"] for s in stats))
-    roof = roofline(fams, w, args.workload if not args.bases else "")
+        fams["bucket_scatter_kernel"] = (tot("bucket_scatter_ms"), tot("bucket_scatter_launches"), tot("bucket_scatter_elems"), None)
+    if tot("bucket_count_ms") > 0:
+        fams["level_b_count"] = (tot("bucket_count_ms"), S, n * S, None)
+    fams["tile_sort_kernel"] = (tot("tile_sort_ms"), tot("tile_sort_launches"), tot("tile_sort_elems"), None)
+    fams["merge_pass_kernel"] = (tot("merge_pass_ms"), tot("merge_pass_launches"), tot("merge_pass_elems"), None)
+    if tot("collate_ms") > 0:
+        fams["collate"] = (tot("collate_ms"), S, n * S, None)
+    if tot("ms_sort_subarrays") > 0 or tot("ms_locate_pivots") > 0:                        # samplesort path: the located pivots (a8)
+        fams["locate_pivots"] = (tot("ms_locate_pivots"), S, n * S, None)
+    fams["finish_gather_head_lcps"] = (tot("finish_ms"), S, n * S, 2.0 * w)
+    if tot("run_bucket_ms") > 0:
+        fams["run_buckets"] = (tot("run_bucket_ms"), S, max(1, n * S), None)
+    if tot("msd_ms") > 0:
+        te = max(1, tot("tie_elems_deferred"))
+        fams["deferred_ties"] = (tot("msd_ms"), S, te, 2.0 * (8 + w) * max(1, stats[-1]["tie_levels"]))
+    roof = roofline(fams, w, args.workload if not args.bases else "", tot("ms_total"))
     last = stats[-1]
     phases = {k: last[k] for k in ("ms_total", "ms_pack", "ms_sort_subarrays", "ms_select_pivots", "ms_locate_pivots",
                                    "ms_partition", "ms_merge_partitions", "ms_boundary_lcp", "ms_output",

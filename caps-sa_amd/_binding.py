@@ -72,6 +72,9 @@ class Stats(ctypes.Structure):
         ("tie_elems_deferred", ctypes.c_uint64),
         ("tie_levels", ctypes.c_uint32),
         ("reserved_", ctypes.c_uint32),
+        ("finish_ms", ctypes.c_double),
+        ("run_bucket_ms", ctypes.c_double),
+        ("msd_ms", ctypes.c_double),
     ]
 
     def as_dict(self) -> dict:
@@ -114,7 +117,7 @@ SHARD_EXPORTS = ["shard_create", "shard_destroy", "shard_info", "shard_phase1", 
                  "shard_phase2", "shard_last_sa", "shard_fix_first_lcp", "shard_scatter", "shard_plan", "shard_sort",
                  "shard_phase1_arrays", "shard_set_key_bits"]
 
-EXPORTS = ["device_count", "last_error", "version", "workspace_bytes", "workspace_bytes_ex", "release_cache", "host_alloc", "host_free", "gen_rand_seq"] + SHARD_EXPORTS + [
+EXPORTS = ["device_count", "last_error", "version", "stats_bytes", "shard_info_bytes", "workspace_bytes", "workspace_bytes_ex", "release_cache", "host_alloc", "host_free", "gen_rand_seq"] + SHARD_EXPORTS + [
     f"{name}_{sfx}"
     for sfx in ("u32", "u64")
     for name in ("build", "build_multi", "build_device", "verify_device", "verify_slice_device", "sort_suffixes", "sort_segments", "merge",
@@ -142,6 +145,14 @@ class CapsLib:
         f("device_count").argtypes = []
         f("last_error").restype = ctypes.c_char_p
         f("version").restype = ctypes.c_char_p
+        # the structs grow at their end from release to release and the library writes all of them: a mirror of another size
+        # would be overrun (or read short) -- refuse to work with it
+        for name, mirror in (("stats_bytes", Stats), ("shard_info_bytes", ShardInfo)):
+            f(name).restype = ctypes.c_uint32
+            f(name).argtypes = []
+            if f(name)() != ctypes.sizeof(mirror):
+                raise CapsSaError(-1, f"{path}: its {name} = {f(name)()}, this binding's mirror has {ctypes.sizeof(mirror)} "
+                                      "(library and _binding.py are of different versions)")
         f("workspace_bytes").restype = _ci
         f("workspace_bytes").argtypes = [_u64, _u64, _ci, ctypes.POINTER(_u64)]
         f("workspace_bytes_ex").restype = _ci

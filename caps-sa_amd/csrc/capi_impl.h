@@ -843,7 +843,9 @@ int lcp_pairs(const char* T, uint64_t n, const idx_t* a, const idx_t* b, uint64_
 extern "C" {
 
 const char* CAPS_API(last_error)(void) { return caps::last_error_ref().c_str(); }
-const char* CAPS_API(version)(void) { return "caps-sa_amd 0.1 (gfx950)"; }
+const char* CAPS_API(version)(void) { return "caps-sa_amd 0.2 (gfx950)"; }
+uint32_t CAPS_API(stats_bytes)(void) { return (uint32_t)sizeof(caps_sa_stats); }
+uint32_t CAPS_API(shard_info_bytes)(void) { return (uint32_t)sizeof(caps_sa_shard_info); }
 
 void CAPS_API(release_cache)(void)
 {

@@ -37,45 +37,82 @@ namespace caps { struct EmulCtx { uint32_t block_idx, grid_dim, block_dim; }; }
 #define K_BLOCK_IDX (kctx_.block_idx)
 #define K_GRID_DIM (kctx_.grid_dim)
 #define K_BLOCK_DIM (kctx_.block_dim)
+// CAPS_EMUL_RACE (tests/emul/race_rt.h): the barrier-race detector -- every PAR iteration announces its thread, every barrier
+// starts a new epoch, LDS arrays register their storage, atomics mark themselves.  Without the switch all of it expands to nothing.
+#ifdef CAPS_EMUL_RACE
+#include "race_rt.h"
+#define CAPS_RACE_IN(t) caps_race::enter_thread((t), __LINE__)
+#define CAPS_RACE_OUT() caps_race::leave_region()
+#define CAPS_RACE_ARRAY(name, bytes) ; caps_race::ArrayGuard name##_rg_(name, (bytes), #name)
+#define CAPS_RACE_ATOMIC caps_race::AtomicScope caps_as_
+#define CAPS_RACE_BARRIER() caps_race::barrier()
+#else
+#define CAPS_RACE_IN(t) true
+#define CAPS_RACE_OUT() false
+#define CAPS_RACE_ARRAY(name, bytes)
+#define CAPS_RACE_ATOMIC ((void)0)
+#define CAPS_RACE_BARRIER() ((void)0)
+#endif
+#define CAPS_PAR_COND(tid, more) ((more) ? CAPS_RACE_IN(tid) : CAPS_RACE_OUT())
 #if defined(CAPS_EMUL_SCATTER)   /* ... or in a scattered order: start anywhere, step by an odd stride (block sizes are powers of two) */
 static inline uint32_t caps_emul_phase_start() { static uint32_t c = 12345u; c = c * 1664525u + 1013904223u; return c >> 8; }
-#define PAR(tid) for (uint32_t tid##_i_ = 0, tid##_s_ = (kctx_.block_dim / 2u + 1u) | 1u, tid = caps_emul_phase_start() % kctx_.block_dim;                       tid##_i_ < kctx_.block_dim; ++tid##_i_, tid = (tid + tid##_s_) % kctx_.block_dim)
+#define PAR(tid) for (uint32_t tid##_i_ = 0, tid##_s_ = (kctx_.block_dim / 2u + 1u) | 1u, tid = caps_emul_phase_start() % kctx_.block_dim;                       CAPS_PAR_COND(tid, tid##_i_ < kctx_.block_dim); ++tid##_i_, tid = (tid + tid##_s_) % kctx_.block_dim)
 #elif defined(CAPS_EMUL_REVERSE)   /* the threads of every phase in descending order: a phase that depends on the order of its threads
                               (a missing barrier between a write and a read of two threads) gives a different result than with
                               the ascending build, or a wrong one (tests/test_emul_pipeline.py, reversed-order cases) */
-#define PAR(tid) for (uint32_t tid##_i_ = 0, tid = kctx_.block_dim - 1; tid##_i_ < kctx_.block_dim; ++tid##_i_, --tid)
+#define PAR(tid) for (uint32_t tid##_i_ = 0, tid = kctx_.block_dim - 1; CAPS_PAR_COND(tid, tid##_i_ < kctx_.block_dim); ++tid##_i_, --tid)
 #else
-#define PAR(tid) for (uint32_t tid = 0; tid < kctx_.block_dim; ++tid)
+#define PAR(tid) for (uint32_t tid = 0; CAPS_PAR_COND(tid, tid < kctx_.block_dim); ++tid)
 #endif
 // PAR_FRESH_SET / PAR_SAME (see the product side below): a region that shares the thread index of a group must come behind the
-// region that took it -- here a flag per kernel invocation says so, and a PAR_SAME that runs before any PAR_FRESH_SET aborts
-// (on the GPU it would run all threads as thread 0).
+// region that took it -- here a flag says so, and a PAR_SAME that runs before any PAR_FRESH_SET aborts (on the GPU it would run all
+// threads as thread 0).  PAR_TID_RESET: at the head of every tile of a kernel that loops over tiles (the flag is per tile).
 static inline bool caps_par_same_ok_(bool set, const char* file, int line)
 {
     if (!set) { std::fprintf(stderr, "%s:%d: PAR_SAME before its PAR_FRESH_SET\n", file, line); std::abort(); }
     return true;
 }
 #define PAR_TID_DECL bool caps_par_set_ = false
-#define PAR_FRESH_SET(tid) if ((caps_par_set_ = true)) PAR(tid)
-#define PAR_SAME_G(g, tid) if (caps_par_same_ok_(caps_par_set_, __FILE__, __LINE__)) PAR(tid)
-#define SYNC() ((void)0)
-#define SYNC_LDS() ((void)0)
-#define SHARED_ARRAY(type, name, count) std::vector<type> name##_vec_(count); type* name = name##_vec_.data()
-#define TL_DECL(type, name, cnt) std::vector<type> name##_tl_((size_t)kctx_.block_dim * (cnt)); \
+#define PAR_TID_RESET (caps_par_set_ = false)
+// (if (!cond) {} else for (...): an `else` behind the use site cannot pair with this `if`)
+#define PAR_FRESH_SET(tid) if (!(caps_par_set_ = true)) {} else PAR(tid)
+#define PAR_SAME_G(g, tid) if (!caps_par_same_ok_(caps_par_set_, __FILE__, __LINE__)) {} else PAR(tid)
+#define SYNC() CAPS_RACE_BARRIER()
+#define SYNC_LDS() CAPS_RACE_BARRIER()
+// CAPS_EMUL_POISON: LDS arrays and per-thread registers start as 0xA5 bytes instead of zeros (on the GPU they start as whatever
+// the last workgroup left: a kernel that reads what it has not written must not pass because the emulation hands it zeros)
+#ifdef CAPS_EMUL_POISON
+#define CAPS_EMUL_FILL(vec) std::memset((void*)(vec).data(), 0xA5, (vec).size() * sizeof((vec)[0]))
+#else
+#define CAPS_EMUL_FILL(vec) ((void)0)
+#endif
+#define SHARED_ARRAY(type, name, count) std::vector<type> name##_vec_(count); CAPS_EMUL_FILL(name##_vec_); type* name = name##_vec_.data() CAPS_RACE_ARRAY(name, (size_t)(count) * sizeof(type))
+#define TL_DECL(type, name, cnt) std::vector<type> name##_tl_((size_t)kctx_.block_dim * (cnt)); CAPS_EMUL_FILL(name##_tl_); \
     type* const name##_tlp_ = name##_tl_.data(); const uint32_t name##_tlc_ = (cnt)
 #define TL(name, tid, k) name##_tlp_[(size_t)(tid) * name##_tlc_ + (k)]
 #define UNROLL
-#define ATOMIC_OR_U32(ptr, v) (*(ptr) |= (v))
-#define ATOMIC_MIN_U32(ptr, v) (*(ptr) = std::min<uint32_t>(*(ptr), (v)))
-#define ATOMIC_MAX_U32(ptr, v) (*(ptr) = std::max<uint32_t>(*(ptr), (v)))
-#define ATOMIC_ADD_U64(ptr, v) (*(ptr) += (v))
-#define ATOMIC_ADD_LDS_U64(ptr, v) (*(ptr) += (v))
-#define ATOMIC_MAX_U64(ptr, v) (*(ptr) = std::max<uint64_t>(*(ptr), (v)))
-#define ATOMIC_MAX_LDS_U64(ptr, v) (*(ptr) = std::max<uint64_t>(*(ptr), (v)))
-static inline uint32_t caps_fetch_add_u32(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
-static inline uint64_t caps_fetch_add_u64(uint64_t* p, uint64_t v) { const uint64_t o = *p; *p = o + v; return o; }
+template <typename T> static inline void caps_emul_or(T* p, T v) { CAPS_RACE_ATOMIC; *p |= v; }
+template <typename T> static inline void caps_emul_min(T* p, T v) { CAPS_RACE_ATOMIC; if (v < *p) *p = v; }
+template <typename T> static inline void caps_emul_max(T* p, T v) { CAPS_RACE_ATOMIC; if (v > *p) *p = v; }
+template <typename T> static inline void caps_emul_add(T* p, T v) { CAPS_RACE_ATOMIC; *p += v; }
+// a load / store of a word that other threads update atomically in the same phase, BY DESIGN (any interleaving gives a valid
+// state: the use sites say why): plain accesses on the GPU, marked for the race detector here
+template <typename T> static inline T caps_emul_load(const T* p) { CAPS_RACE_ATOMIC; return *p; }
+template <typename T> static inline void caps_emul_store(T* p, T v) { CAPS_RACE_ATOMIC; *p = v; }
+#define RACY_LOAD_U32(ptr) caps_emul_load<uint32_t>((ptr))
+#define RACY_STORE_U32(ptr, v) caps_emul_store<uint32_t>((ptr), (v))
+#define ATOMIC_OR_U32(ptr, v) caps_emul_or<uint32_t>((ptr), (v))
+#define ATOMIC_MIN_U32(ptr, v) caps_emul_min<uint32_t>((ptr), (v))
+#define ATOMIC_MAX_U32(ptr, v) caps_emul_max<uint32_t>((ptr), (v))
+#define ATOMIC_ADD_U64(ptr, v) caps_emul_add<uint64_t>((ptr), (v))
+#define ATOMIC_ADD_LDS_U64(ptr, v) caps_emul_add<uint64_t>((ptr), (v))
+#define ATOMIC_MAX_U64(ptr, v) caps_emul_max<uint64_t>((ptr), (v))
+#define ATOMIC_MAX_LDS_U64(ptr, v) caps_emul_max<uint64_t>((ptr), (v))
+static inline uint32_t caps_fetch_add_u32(uint32_t* p, uint32_t v) { CAPS_RACE_ATOMIC; const uint32_t o = *p; *p = o + v; return o; }
+static inline uint64_t caps_fetch_add_u64(uint64_t* p, uint64_t v) { CAPS_RACE_ATOMIC; const uint64_t o = *p; *p = o + v; return o; }
 #define FETCH_ADD_U32(ptr, v) caps_fetch_add_u32((ptr), (v))      /* returns the old value */
-#define BLOCK_MINMAX_U64(pmin, pmax, mn, mx) do { if ((mn) < *(pmin)) *(pmin) = (mn); if ((mx) > *(pmax)) *(pmax) = (mx); } while (0)
+static inline void caps_emul_minmax(uint64_t* pmin, uint64_t* pmax, uint64_t mn, uint64_t mx) { caps_emul_min<uint64_t>(pmin, mn); caps_emul_max<uint64_t>(pmax, mx); }
+#define BLOCK_MINMAX_U64(pmin, pmax, mn, mx) caps_emul_minmax((pmin), (pmax), (mn), (mx))
 #define FETCH_ADD_U64(ptr, v) caps_fetch_add_u64((ptr), (v))
 static inline uint32_t caps_fetch_add(uint32_t* p, uint32_t v) { return caps_fetch_add_u32(p, v); }
 static inline uint64_t caps_fetch_add(uint64_t* p, uint64_t v) { return caps_fetch_add_u64(p, v); }
@@ -112,6 +149,7 @@ static __device__ __forceinline__ uint32_t caps_tid_fresh() { uint32_t t = threa
 // CAPS_PAR_GROUPS is a mask of the groups that share (1: equalisation, 2: tie rounds, 4: pick-up + placement); PAR_SAME_G(g, tid).
 #ifdef CAPS_PAR_GROUPS
 #define PAR_TID_DECL uint32_t caps_par_tid_ = 0
+#define PAR_TID_RESET ((void)0)
 #define PAR_FRESH_SET(tid) for (uint32_t tid = (caps_par_tid_ = caps_tid_fresh()), par_once_ = 1; par_once_; par_once_ = 0)
 #define PAR_SAME_ON_(tid) for (uint32_t tid = caps_par_tid_, par_once_ = 1; par_once_; par_once_ = 0)
 #if (CAPS_PAR_GROUPS) & 1
@@ -161,6 +199,7 @@ static __device__ __forceinline__ uint32_t caps_tid_fresh() { uint32_t t = threa
 #endif
 #else
 #define PAR_TID_DECL ((void)0)
+#define PAR_TID_RESET ((void)0)
 #define PAR_FRESH_SET(tid) PAR(tid)
 #define PAR_SAME_1(tid) PAR(tid)
 #define PAR_SAME_1a(tid) PAR(tid)
@@ -190,6 +229,8 @@ static __device__ __forceinline__ void caps_lds_barrier()
 #define TL_DECL(type, name, cnt) type name##_reg_[cnt]
 #define TL(name, tid, k) name##_reg_[k]
 #define UNROLL _Pragma("unroll")
+#define RACY_LOAD_U32(ptr) (*(ptr))                 /* see the emulation side: racing with atomics by design */
+#define RACY_STORE_U32(ptr, v) (*(ptr) = (v))
 #define ATOMIC_OR_U32(ptr, v) atomicOr((ptr), (v))
 #define ATOMIC_MIN_U32(ptr, v) atomicMin((ptr), (v))
 #define ATOMIC_MAX_U32(ptr, v) atomicMax((ptr), (v))

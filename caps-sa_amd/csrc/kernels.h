@@ -255,11 +255,7 @@ GLOBAL_FN LAUNCH_BOUNDS(256) run_chunk_heads_kernel(KCTX const uint64_t* __restr
         for (uint32_t k = 0; k < RUN_PER; ++k) {
             const uint64_t b = base + (uint64_t)tid * RUN_PER + k;
             if (b < entries && R[b] != RUN_LINKED) {
-#ifdef CAPS_EMUL
-                if (tid * RUN_PER + k < first[0]) first[0] = tid * RUN_PER + k;
-#else
-                atomicMin(&first[0], tid * RUN_PER + k);
-#endif
+                ATOMIC_MIN_U32(&first[0], tid * RUN_PER + k);
                 break;
             }
         }
@@ -688,9 +684,15 @@ DEV_INLINE void block_exclusive_scan(KCTX uint32_t* h)
 {
 #ifdef CAPS_EMUL
     (void)kctx_;
+    // the same barrier structure as the product code below (the race detector of tests/emul counts on it): every counter is read,
+    // barrier, every sum is written, barrier
+    std::vector<uint32_t> c(NBINS);
+    for (uint32_t i = 0; i < NBINS; ++i) c[i] = h[i];
+    SYNC_LDS();
     uint32_t run = 0;
-    for (uint32_t i = 0; i < NBINS; ++i) { const uint32_t c = h[i]; h[i] = run; run += c; }
+    for (uint32_t i = 0; i < NBINS; ++i) { h[i] = run; run += c[i]; }
     h[NBINS] = run;
+    SYNC_LDS();
 #else
     constexpr uint32_t BPT = NBINS / TILE_NT;
     static_assert(BPT >= 1 && BPT * TILE_NT == NBINS, "counters per thread");
@@ -1261,6 +1263,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
     uint32_t qi = K_BLOCK_IDX;
     if (qi >= n_redo) return;
     do {
+    PAR_TID_RESET;
     const uint32_t b = redo ? redo[1 + qi] : qi;
     if (!EQ_OK(b < sd.tile_off[sd.G], 0)) return;
     const TileInfo t = tile_info(sd, b);
@@ -1413,13 +1416,15 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                     uint32_t own = 0;                                      // my first entry, counted from the top of the list
                     if (ties == 1u && slot > tj) {
                         const uint32_t pi = FETCH_ADD_U32(&pcnt[0], 1u);
-                        if (pi < TIE_LIST_CAP) plist[pi] = 0xFF000000u | (slot << 12) | tj;
+                        // (RACY_STORE: pairs from the bottom and own entries from the top run into each other only when np + nm >
+                        // TIE_LIST_CAP, and then the tile fails below before anything reads the list)
+                        if (pi < TIE_LIST_CAP) RACY_STORE_U32(&plist[pi], 0xFF000000u | (slot << 12) | tj);
                     } else if (ties >= 2u && ties <= TIE_LIST_MAX) {
                         own = FETCH_ADD_U32(&pcnt[1], ties);
                         if (own + ties <= TIE_LIST_CAP) {
                             uint32_t q = own;
                             for (uint32_t j = bs; j < be; ++j)
-                                if (skey[j] == key && j != slot) plist[TIE_LIST_CAP - 1u - q++] = 0xFF000000u | (slot << 12) | j;
+                                if (skey[j] == key && j != slot) RACY_STORE_U32(&plist[TIE_LIST_CAP - 1u - q++], 0xFF000000u | (slot << 12) | j);
                         } else {
                             own = 0;                                       // (the tile fails below: the list is full)
                         }
@@ -1488,7 +1493,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                             if (vi < n_ent) {
                                 const uint32_t vj = round ? deep[vi] : vi;
                                 const uint32_t pi = vj < np ? vj : TIE_LIST_CAP - 1u - (vj - np);
-                                const uint32_t ent = plist[pi];
+                                const uint32_t ent = RACY_LOAD_U32(&plist[pi]);     // (the lanes of this entry may have touched it: below)
                                 TL(tpi, tid, 0) = pi | (vj < np ? 0u : 0x80000000u) | (vj << 16);
                                 // open: untouched (0xFF) or touched by another lane of THIS round (its window number) -- not
                                 // "untouched" alone: the lanes of an entry would then depend on each other's timing (they do run
@@ -1517,7 +1522,9 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                             const uint32_t W = W0 + tid % G, tp = TL(tpi, tid, 0);
                             if (tp != ~0u) {
                                 const uint32_t pi = tp & 0xFFFFu, vj = (tp >> 16) & 0x7FFFu;
-                                const uint32_t ent = plist[pi], lo = ent & 0xFFFu, hi = (ent >> 12) & 0xFFFu;
+                                // (racing with the winner's store below by design: a settled own entry reads 0x80 / 0x81 in its top byte,
+                                // which is neither a window number nor 0xFF, and the lane that reads it does nothing)
+                                const uint32_t ent = RACY_LOAD_U32(&plist[pi]), lo = ent & 0xFFFu, hi = (ent >> 12) & 0xFFFu;
                                 if ((ent >> 24) == W) {                   // mine is the first window that differs (or ends)
                                     const uint64_t a = (uint64_t)ssa[lo], b2 = (uint64_t)ssa[hi];
                                     const uint64_t maxlen = a < n && b2 < n ? n - (a > b2 ? a : b2) : 0;
@@ -1531,7 +1538,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                                         lo_first = wa < wb;
                                     }
                                     if (tp & 0x80000000u) {               // an element's own entry: "the other sorts before you" + lcp
-                                        plist[pi] = (lo_first ? 0x81000000u : 0x80000000u) | (uint32_t)d;
+                                        RACY_STORE_U32(&plist[pi], (lo_first ? 0x81000000u : 0x80000000u) | (uint32_t)d);
                                     } else {                              // a pair: the same for both members
                                         tinfo[hi] = (uint16_t)(lo_first ? 0x8000u | (uint32_t)d : 0u);
                                         tinfo[lo] = (uint16_t)(lo_first ? 0u : 0x8000u | (uint32_t)d);

@@ -423,6 +423,10 @@ template <typename idx_t> struct SortResult {
     TileDesc* defer_desc = nullptr;
     uint64_t cap = 0;                                                 // elements buf[0] / buf[1] hold
     mutable bool msd_failed = false;
+    // clocks of finalize()'s three parts (null: untimed): gather + head LCPs, letter-run buckets, deferred ties
+    KernelClock* finish_clock = nullptr;
+    KernelClock* runb_clock = nullptr;
+    KernelClock* msd_clock = nullptr;
     mutable uint64_t msd_groups = 0, msd_elems = 0;
     mutable uint32_t msd_levels = 0;
     uint32_t n_tiles = 0;
@@ -1140,16 +1144,26 @@ template <typename idx_t, int BITS>
 void finalize(Backend& be, const uint32_t* P, uint64_t n, const SortResult<idx_t>& r, idx_t* dSA, idx_t* dLCP)
 {
     if (r.n_tiles == 0) return;
-    if (r.fin.sa == nullptr || r.passes > 0)
-        CAPS_LAUNCH((finalize_kernel<idx_t, BITS>), r.n_tiles, 256, be, r.segs.desc(), P, n, r.pingpong(), r.skip_finished ? 1u : 0u,
-                    r.passes & 1u, dSA, dLCP, r.fin);
-    if (r.fin.sa != nullptr)
-        CAPS_LAUNCH((head_lcp_kernel<idx_t, BITS>), (r.segs.G + 255) / 256, 256, be, P, n, (const uint64_t*)r.segs.seg_start, r.segs.G,
-                    r.fin, r.k32 ? 1u : 0u);
-    if (!r.run_buckets.empty()) sort_run_buckets<idx_t, BITS>(be, P, n, r, dSA, dLCP);
+    auto timed = [&](KernelClock* c, uint64_t elems, auto&& body) {
+        if (!c) { body(); return; }
+        const BackendEvent a = be.record();
+        body();
+        c->spans.push_back({a, be.record()});
+        c->elems.push_back(elems);
+    };
+    timed(r.finish_clock, r.total, [&] {
+        if (r.fin.sa == nullptr || r.passes > 0)
+            CAPS_LAUNCH((finalize_kernel<idx_t, BITS>), r.n_tiles, 256, be, r.segs.desc(), P, n, r.pingpong(), r.skip_finished ? 1u : 0u,
+                        r.passes & 1u, dSA, dLCP, r.fin);
+        if (r.fin.sa != nullptr)
+            CAPS_LAUNCH((head_lcp_kernel<idx_t, BITS>), (r.segs.G + 255) / 256, 256, be, P, n, (const uint64_t*)r.segs.seg_start, r.segs.G,
+                        r.fin, r.k32 ? 1u : 0u);
+    });
+    if (!r.run_buckets.empty()) timed(r.runb_clock, 0, [&] { sort_run_buckets<idx_t, BITS>(be, P, n, r, dSA, dLCP); });
     // deferred ties last: the neighbours of a group never change their LCP with it (all members share the key, and a member
     // whose suffix ends inside the key is placed -- first -- by the sort itself), so the head LCPs above stand
-    if (r.defer_flags && !std::getenv("CAPS_SA_DEBUG_NO_MSD") && !msd_refine<idx_t, BITS>(be, P, n, r, dSA, dLCP)) r.msd_failed = true;
+    if (r.defer_flags && !std::getenv("CAPS_SA_DEBUG_NO_MSD"))
+        timed(r.msd_clock, 0, [&] { if (!msd_refine<idx_t, BITS>(be, P, n, r, dSA, dLCP)) r.msd_failed = true; });
 }
 
 // Shape of the direct path's two-level distribution: PG consecutive partitions per group, K1 groups.  Level A
@@ -1267,6 +1281,7 @@ private:
     KernelClock scatter_clock_;
     KernelClock count_clock_;
     KernelClock collate_clock_;
+    KernelClock finish_clock_, runb_clock_, msd_clock_;      // finalize(): gather + head LCPs, letter-run buckets, deferred ties
     uint32_t pass_base_ = 0;
     uint32_t slot_stats_[2] = {0, 0};
     // per-build results of the phase sequences below
@@ -1296,7 +1311,12 @@ private:
             o.speculate = std::getenv("CAPS_SA_NO_SLOTS") == nullptr && slot_stats_[1] == 0;
         }
         SortResult<idx_t> r = segmented_sort<idx_t, BITS>(be_, pl_.P, pl_.n, pl_.desc, s, n_tiles, max_len, cur, oth, n_elems, o);
-        if (timed) pass_base_ += r.passes;
+        if (timed) {
+            pass_base_ += r.passes;
+            r.finish_clock = &finish_clock_;
+            r.runb_clock = &runb_clock_;
+            r.msd_clock = &msd_clock_;
+        }
         return r;
     }
     void prepare_segments(const SegBufs& s, uint64_t tile_bound) { ::caps::prepare_segments(be_, s, tile_bound); }
@@ -1843,6 +1863,9 @@ private:
             sum(scatter_clock_, &st->bucket_scatter_ms, &st->bucket_scatter_launches, &st->bucket_scatter_elems);
             sum(count_clock_, &st->bucket_count_ms, &dummy_l, &dummy_e);
             sum(collate_clock_, &st->collate_ms, &dummy_l, &dummy_e);
+            sum(finish_clock_, &st->finish_ms, &dummy_l, &dummy_e);
+            sum(runb_clock_, &st->run_bucket_ms, &dummy_l, &dummy_e);
+            sum(msd_clock_, &st->msd_ms, &dummy_l, &dummy_e);
             st->path_direct = path_direct_;
             st->path_fallback = path_fallback_;
             st->direct_groups = direct_groups_;

@@ -91,7 +91,16 @@ typedef struct caps_sa_stats {
      * members, and the deepest level (each 64 / bits_per_char chars). */
     uint64_t tie_groups_deferred, tie_elems_deferred;
     uint32_t tie_levels, reserved_;
+    /* the three parts of the last stage, summed over their launches (device time, as the kernel clocks above): gathering SA / LCP
+     * with the segment-head LCPs (a11), the letter-run buckets (run_buckets), the deferred ties (tie_groups_deferred) */
+    double finish_ms, run_bucket_ms, msd_ms;
 } caps_sa_stats;
+
+/* sizeof(caps_sa_stats) / sizeof(caps_sa_shard_info) of THIS library.  Both structs grow at their end from release to release and
+ * the entry points write all of them: a caller compiled against an older header must check these against its own sizeof before
+ * passing a buffer (caps-sa_amd/_binding.py does at load time). */
+uint32_t caps_sa_hip_stats_bytes(void);
+uint32_t caps_sa_hip_shard_info_bytes(void);
 
 #define CAPS_SA_FB_NONE 0
 #define CAPS_SA_FB_FORCED 1        /* CAPS_SA_PATH=classic */

@@ -73,6 +73,9 @@ template <typename F> inline void emul_launch(uint32_t grid, uint32_t block, F&&
 {
     for (uint32_t b = 0; b < grid; ++b) {
         EmulCtx c{b, grid, block};
+#ifdef CAPS_EMUL_RACE
+        caps_race::barrier();                     // every workgroup starts its own epochs, outside any PAR region
+#endif
         body(c);
     }
 }

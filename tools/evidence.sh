@@ -9,7 +9,7 @@
 #   pmc <wl> [groups]   PMC passes (tools/pmc.sh) + traffic figures into profiles/traffic.json
 #   phase <wl ...>      phase clock of the tile sorts (variant `phase`)
 #   gputest [-k expr]   the -m gpu suite in one process
-#   variants <wl> v ... bench one workload under each tuning variant caps-sa_amd/variants/libcaps_sa_hip_<v>.so
+#   variants <wl> v ... bench one workload under each tuning variant variants/libcaps_sa_hip_<v>.so
 #   fault               tools/fault_probe.sh
 set -o pipefail
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.." || exit 1
@@ -63,7 +63,7 @@ PY
     rm -rf $O/pmc_${wl}_lds $O/pmc_${wl}_wait $O/pmc_${wl}_fetch $O/pmc_${wl}_write $O/pmc_${wl}_tcc $O/pmc_${wl}_tcp $O/pmc_${wl}_grbm
     cp profiles/traffic.json $O/${T}_traffic.json; head -40 $O/${T}_${wl}_rocprofv3_pmc_summary.txt ;;
   phase)
-    CAPS_SA_LIB=$PWD/caps-sa_amd/variants/libcaps_sa_hip_${VAR:-phase}.so timeout -k 10 ${TMO:-500} python3 tools/phase_clock.py "$@" > $O/${T}_phase_clock.log 2>&1; rc=$?
+    CAPS_SA_LIB=$PWD/variants/libcaps_sa_hip_${VAR:-phase}.so timeout -k 10 ${TMO:-500} python3 tools/phase_clock.py "$@" > $O/${T}_phase_clock.log 2>&1; rc=$?
     echo "phase rc=$rc"; grep '^{' $O/${T}_phase_clock.log; [ $rc -eq 124 ] || [ $rc -eq 137 ] && exit 1 ;;
   gputest)
     timeout -k 10 ${TMO:-1150} python3 -m pytest tests -q -m gpu -x --durations=15 "$@" > $O/${T}_gputest.log 2>&1; rc=$?
@@ -71,7 +71,7 @@ PY
   variants)
     wl=$1; shift
     for v in "$@"; do
-      lib=$PWD/caps-sa_amd/variants/libcaps_sa_hip_$v.so; [ "$v" = base ] && lib=$PWD/caps-sa_amd/libcaps_sa_hip.so
+      lib=$PWD/variants/libcaps_sa_hip_$v.so; [ "$v" = base ] && lib=$PWD/caps-sa_amd/libcaps_sa_hip.so
       CAPS_SA_LIB=$lib timeout -k 10 ${TMO:-420} python3 bench.py --workload $wl --steps ${STEPS:-3} --warmup 1 --no-cpu-baseline --no-host-path > $O/${T}_var_${v}_${wl}.json.log 2> $O/${T}_var_${v}_${wl}.err
       rc=$?; echo "variant $v $wl rc=$rc"; summ $O/${T}_var_${v}_${wl}.json.log
       [ $rc -eq 124 ] || [ $rc -eq 137 ] && exit 1

@@ -1,5 +1,5 @@
 """Phase clock of the tile sort kernels (measurement variant: make -C caps-sa_amd variant TAG=phase VARIANT_DEFS=-DCAPS_PHASE_CLOCK,
-run with CAPS_SA_LIB=caps-sa_amd/variants/libcaps_sa_hip_phase.so).  Prints, per workload, the share of thread-0 cycles that
+run with CAPS_SA_LIB=variants/libcaps_sa_hip_phase.so).  Prints, per workload, the share of thread-0 cycles that
 each barrier-separated phase of tile_sort_kernel / tile_sort_eq_kernel took (summed over all workgroups of one build)."""
 import ctypes
 import json
