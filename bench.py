@@ -92,6 +92,36 @@ def make_text(torch, n_bases, seed, device, kind="uniform"):
     return T
 
 
+def cpu_quota_cores():
+    """CPU cores this process may use: the cgroup's quota when there is one (the GPU box shows all 256 hardware threads of its node but
+    runs the command under cpu.max = 16 cores' worth), else the affinity mask."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            q, per = open(path).read().split()
+            if q != "max":
+                return max(1.0, min(float(aff), int(q) / int(per)))
+        except (OSError, ValueError):
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return max(1.0, min(float(aff), q / per))
+    except (OSError, ValueError):
+        pass
+    return float(aff)
+
+
+def cpu_threads():
+    """Threads for the oracle: two per core of the quota (measured on the GPU box, 64 Mi text, quota 16: 16 / 24 / 32 / 64 / 128 /
+    256 threads -> 28.8 / 29.9 / 31.3 / 27.5 / 23.1 / 16.5 M suffixes/s; tools/cpu_threads_probe.py)."""
+    env = os.environ.get("CAPS_BENCH_CPU_THREADS")
+    if env:
+        return max(1, int(env))
+    return max(1, int(round(2 * cpu_quota_cores())))
+
+
 def cpu_baseline(T_dev, n_sample, p, n_full):
     """The oracle (C restatement of the reference algorithm: kind 'port') timed on this host's
     cores on a bounded sample of the same text."""
@@ -99,18 +129,21 @@ def cpu_baseline(T_dev, n_sample, p, n_full):
     T = T_dev[:n_sample].cpu().numpy()
     tm = {}
     t0 = time.time()
-    O.build_sa_lcp(T, p=p, timings=tm)
+    O.build_sa_lcp(T, p=p, threads=cpu_threads(), timings=tm)
     wall = time.time() - t0
     rate = n_sample / tm["total"]
+    cores = cpu_quota_cores()
     return {
         "value": rate,
         "unit": "suffixes/s",
-        "cores": int(tm["threads"]),
+        "cores": int(round(cores)),
+        "threads": int(tm["threads"]),
         "kind": "port",
         "seconds": tm["total"],
         "sample": f"first {n_sample} chars of the same text, p={p}: oracle construct() interval {tm['total']:.2f} s "
-                  f"(wall {wall:.2f} s) on {int(tm['threads'])} threads of this host (cpus={os.cpu_count()}); at that rate "
-                  f"the full {n_full}-char text would take {n_full / rate:.0f} s (an underestimate: merge depth grows with n)",
+                  f"(wall {wall:.2f} s) on {int(tm['threads'])} threads over the {cores:g} cores this process may use (cgroup quota; the "
+                  f"node shows {os.cpu_count()} hardware threads); at that rate the full {n_full}-char text would take "
+                  f"{n_full / rate:.0f} s (an underestimate: merge depth grows with n)",
     }
 
 
@@ -150,8 +183,9 @@ def cpu_baseline_full(torch, T_dev, n, p, idx_bits, SA_dev, LCP_dev):
     T = T_dev.cpu().numpy()
     tm = {}
     t0 = time.time()
-    SAo, LCPo = O.build_sa_lcp(T, p=p, idx_bits=idx_bits, timings=tm)
+    SAo, LCPo = O.build_sa_lcp(T, p=p, idx_bits=idx_bits, threads=cpu_threads(), timings=tm)
     wall = time.time() - t0
+    cores = cpu_quota_cores()
     dt = torch.int32 if idx_bits == 32 else torch.int64
     sa_diff = lcp_diff = 0
     step = 1 << 28
@@ -164,9 +198,11 @@ def cpu_baseline_full(torch, T_dev, n, p, idx_bits, SA_dev, LCP_dev):
         del a
     del SAo, LCPo
     return {
-        "value": n / tm["total"], "unit": "suffixes/s", "cores": int(tm["threads"]), "kind": "port", "seconds": tm["total"],
+        "value": n / tm["total"], "unit": "suffixes/s", "cores": int(round(cores)), "threads": int(tm["threads"]), "kind": "port",
+        "seconds": tm["total"],
         "sample": f"full text ({n} chars), p={p}: oracle construct() interval {tm['total']:.1f} s (wall {wall:.1f} s) on "
-                  f"{int(tm['threads'])} threads of this host (cpus={os.cpu_count()})",
+                  f"{int(tm['threads'])} threads over the {cores:g} cores this process may use (cgroup quota; the node shows "
+                  f"{os.cpu_count()} hardware threads); its SA and LCP compared entry by entry with the GPU build's",
         "phases_s": {k: v for k, v in tm.items() if k != "threads"},
         "sa_mismatches_vs_gpu": sa_diff, "lcp_mismatches_vs_gpu": lcp_diff,
     }
@@ -255,8 +291,12 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample", type=int, default=256 * 1024 * 1024 + 1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-full", action="store_true",
-                    help="time the oracle on the WHOLE text (all host threads, minutes, ~(1 + 4w) n bytes of host memory) instead of on "
-                         "the --cpu-sample prefix, and compare its SA / LCP with the GPU's entry by entry")
+                    help="time the oracle on the WHOLE text (minutes, ~(1 + 4w) n bytes of host memory) and compare its SA / LCP with the "
+                         "GPU's entry by entry, whatever the projection says (the default does this when host memory and time allow)")
+    ap.add_argument("--cpu-sample-only", action="store_true",
+                    help="CPU baseline on the --cpu-sample prefix only (also: CAPS_BENCH_CPU_FULL=0)")
+    ap.add_argument("--cpu-full-budget-s", type=float, default=float(os.environ.get("CAPS_BENCH_CPU_FULL_BUDGET_S", "330")),
+                    help="the default run times the oracle on the whole text only when the sample's rate projects it under this many seconds")
     ap.add_argument("--no-verify", action="store_true", help="skip the device verifier after the timed steps")
     ap.add_argument("--verify", action="store_true", help="(default; kept for old command lines)")
     ap.add_argument("--no-host-path", action="store_true", help="skip timing the host-buffer entry point (PCIe inclusive)")
@@ -370,7 +410,8 @@ def main():
     last = stats[-1]
     phases = {k: last[k] for k in ("ms_total", "ms_pack", "ms_sort_subarrays", "ms_select_pivots", "ms_locate_pivots",
                                    "ms_partition", "ms_merge_partitions", "ms_boundary_lcp", "ms_output",
-                                   "merge_pass_ms", "tile_sort_ms", "bucket_scatter_ms", "bucket_count_ms", "collate_ms")}
+                                   "merge_pass_ms", "tile_sort_ms", "bucket_scatter_ms", "bucket_count_ms", "collate_ms",
+                                   "level_a_ms", "finish_ms", "run_bucket_ms", "msd_ms")}
     out = {
         "metric": "suffixes/sec (SA+LCP build)", "value": value, "unit": "suffixes/s", "n_gpus": 1,
         "steps": args.steps, "warmup": args.warmup, "prewarm_steps": prewarm_steps, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -392,21 +433,34 @@ def main():
         "verify_errors": verify_errors,
     }
     parity_errors = 0
-    if args.cpu_full and not args.no_cpu_baseline:
-        del ws
-        torch.cuda.empty_cache()
-        out["cpu_baseline"] = cpu_baseline_full(torch, T, n, args.p, idx_bits, SA, LCP)
-        parity_errors = out["cpu_baseline"].get("sa_mismatches_vs_gpu", 0) + out["cpu_baseline"].get("lcp_mismatches_vs_gpu", 0)
-        if "skipped" in out["cpu_baseline"]:
-            out["cpu_baseline_full_skipped"] = out["cpu_baseline"].pop("skipped")
-            out["cpu_baseline"] = cpu_baseline(T, min(args.cpu_sample, n), args.p, n)
-        ws = None
+    if not args.no_cpu_baseline:
+        # The CPU path on the WHOLE text, its arrays compared with the GPU's entry by entry (north_star: "bit-exact ... with that CPU
+        # path timed on the GPU box's own host cores in the same run") -- by default, when the host can hold it and the sample's rate
+        # projects it inside the budget; the sample alone otherwise (and with --cpu-sample-only / CAPS_BENCH_CPU_FULL=0).
+        sample = cpu_baseline(T, min(args.cpu_sample, n), args.p, n)
+        want_full = args.cpu_full or not (args.cpu_sample_only or os.environ.get("CAPS_BENCH_CPU_FULL") == "0")
+        projected = 1.3 * n / sample["value"]              # merge depth grows with n: C3 measured 1.25 x the sample's projection
+        if want_full and n > args.cpu_sample and (args.cpu_full or projected <= args.cpu_full_budget_s):
+            del ws
+            torch.cuda.empty_cache()
+            full = cpu_baseline_full(torch, T, n, args.p, idx_bits, SA, LCP)
+            ws = None
+            if "skipped" in full:
+                out["cpu_baseline_full_skipped"] = full["skipped"]
+                out["cpu_baseline"] = sample
+            else:
+                parity_errors = full.get("sa_mismatches_vs_gpu", 0) + full.get("lcp_mismatches_vs_gpu", 0)
+                out["cpu_baseline"] = full
+                out["cpu_baseline_sample"] = {k: sample[k] for k in ("value", "seconds", "sample")}
+        else:
+            if want_full and n > args.cpu_sample:
+                out["cpu_baseline_full_skipped"] = (f"projected {projected:.0f} s for the whole text exceeds the budget of "
+                                                    f"{args.cpu_full_budget_s:.0f} s (--cpu-full forces it)")
+            out["cpu_baseline"] = sample
     if not args.no_host_path:
         del ws, SA, LCP
         torch.cuda.empty_cache()
         out["pcie_inclusive"] = host_path(L, torch, T, n, args.p, idx_bits)
-    if not args.no_cpu_baseline and "cpu_baseline" not in out:
-        out["cpu_baseline"] = cpu_baseline(T, min(args.cpu_sample, n), args.p, n)
     print(json.dumps(out))
     host_errors = (out.get("pcie_inclusive") or {}).get("verify_errors") or 0
     if verify_errors or parity_errors or host_errors:           # a wrong result is not a benchmark result

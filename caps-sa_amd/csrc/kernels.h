@@ -1164,14 +1164,20 @@ DEV_INLINE uint32_t eq_big_lcp(const uint16_t* vslot, const uint32_t* vlcp, uint
 // every pair of equal keys has its lcp from the tie phases, and those are never 0 -- so the keys tell; the comparator through
 // the text, unrolled four times in the emit phase, cost that phase registers (scratch) for a path no tile takes.
 template <int BITS, bool TEXT, typename idx_t>
-DEV_INLINE uint64_t eq_emit_lcp(const uint32_t* __restrict__ P, uint64_t n, uint64_t ka, idx_t a, uint64_t kb, idx_t b)
+DEV_INLINE uint64_t eq_emit_lcp(const uint32_t* __restrict__ P, uint64_t n, uint64_t ka, idx_t a, uint64_t kb, idx_t b, uint32_t* lost, bool test_drop)
 {
     if (TEXT) return pair_lcp<BITS, false>(P, n, ka, (uint64_t)a, kb, (uint64_t)b);
     const uint64_t x = ka ^ kb;
+    if (x == 0) {
+        // The invariant the plain build rests on: equal keys always come with their lcp from the tie phases.  Should a note ever be
+        // lost, the capped key length would be a WRONG lcp: the tile is handed to the comparison sort instead (*lost, read by the
+        // kernel behind its last barrier), which sorts it again from its input.  The emulation aborts (unless the test switch that
+        // drops notes on purpose is on): there the invariant is a test.
 #ifdef CAPS_EMUL
-    // the invariant the plain build rests on: a lost note would make this return the capped KCH silently
-    if (x == 0) { std::fprintf(stderr, "eq_emit_lcp: neighbours %llu, %llu with equal keys and no lcp from the tie phases\n", (unsigned long long)a, (unsigned long long)b); std::abort(); }
+        if (!test_drop) { std::fprintf(stderr, "eq_emit_lcp: neighbours %llu, %llu with equal keys and no lcp from the tie phases\n", (unsigned long long)a, (unsigned long long)b); std::abort(); }
 #endif
+        *lost = 1;                                                   // (benign race: every writer stores 1)
+    }
     return lcp_capped<idx_t>(x ? (uint32_t)caps_clz64(x) / BITS : TextTraits<BITS>::KCH, n, a, b);
 }
 
@@ -1179,7 +1185,7 @@ DEV_INLINE uint64_t eq_emit_lcp(const uint32_t* __restrict__ P, uint64_t n, uint
 #define CAPS_EQ_WAVES TILE_WAVES_PER_SIMD
 #endif
 #undef TILE_EMIT_LCP_
-#define TILE_EMIT_LCP_(ka, a, kb, b) eq_emit_lcp<BITS, VDEEP>(P, n, ka, a, kb, b)
+#define TILE_EMIT_LCP_(ka, a, kb, b) eq_emit_lcp<BITS, VDEEP>(P, n, ka, a, kb, b, &flag[1], TEST_DROP)
 #ifndef CAPS_EQ_FULL_SYNC          /* measurement: -DCAPS_EQ_FULL_SYNC keeps __syncthreads() in this kernel */
 #undef TILE_SYNC
 #define TILE_SYNC() SYNC_LDS()
@@ -1212,7 +1218,10 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
     // keys_from_text != 0: the slots hold 32-bit keys (tile_sort_kernel<..., uint32_t> ran first); this kernel works on the
     // 64-bit keys, cut from the text at the elements' positions (seg_map is then null: the tile's own key range)
     constexpr bool TILE_RUNS = false;
-    const bool TILE_KEYS_FROM_TEXT = keys_from_text != 0;
+    const bool TILE_KEYS_FROM_TEXT = (keys_from_text & 1u) != 0;
+    // bit 1 of keys_from_text (tests only, CAPS_SA_TEST_DROP_NOTE): the lcp notes of tied pairs are dropped on purpose -- the emit
+    // phase must then notice equal keys without a note and hand the tile to the comparison sort (eq_emit_lcp)
+    const bool TEST_DROP = (keys_from_text & 2u) != 0;
     const uint32_t TILE_KEY_SHIFT = 0;
     (void)TILE_RUNS;
     (void)TILE_KEY_SHIFT;
@@ -1223,8 +1232,14 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
     constexpr bool SLOT_ORDER = sizeof(idx_t) == 4;
     constexpr uint32_t BIG_CAP = sizeof(idx_t) == 4 ? TIE_BIG_CAP : TIE_BIG_CAP / 4;
     SHARED_ARRAY(uint16_t, sbin, SLOT_ORDER ? TILE_E : 1);   // the bin of the element in slot e (after the placement by bin)
+    // PERM (where sbin exists): no second placement.  Once an element knows its final position d it only notes perm[d] = its slot (in
+    // sbin's memory, dead by then) and leaves its lcp note in tinfo[slot]; the emit phase reads keys and indices THROUGH perm.  The
+    // pick-up of (key, index) into registers, the barrier, their second trip through LDS and the registers they held are gone.
+    constexpr bool PERM = SLOT_ORDER;
+    uint16_t* perm = sbin;
     SHARED_ARRAY(uint64_t, kmm, 2);
-    SHARED_ARRAY(uint32_t, flag, 2);         // [0] the tile is the comparison sort's; [1] it only needs the third tie stage
+    SHARED_ARRAY(uint32_t, flag, 2);         // [0] the tile is the comparison sort's; [1] it only needs the third tie stage; during the
+                                             //   emit phase [1]: neighbours with equal keys and no lcp note (eq_emit_lcp)
     TL_DECL(uint64_t, rk, TILE_EPT);
     TL_DECL(idx_t, rs, TILE_EPT);
     TL_DECL(uint32_t, rd, TILE_EPT);
@@ -1246,6 +1261,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
     SHARED_ARRAY(uint32_t, vlcp, TIE_VDEEP_CAP);      // third stage: the lcp of pair q (too large for the 15 bits of its members' notes);
                                                       //   after the final placement: the lcps >= 0x7FFF, with ...
     SHARED_ARRAY(uint16_t, vslot, TIE_VDEEP_CAP);     //   ... the slots they belong to
+    SHARED_ARRAY(uint32_t, vlcp2, PERM ? TIE_VDEEP_CAP : 1);   // PERM: the lcps >= 0x7FFF live here (vlcp is still being read when they are noted)
     static_assert((TILE_BINS + 1) * sizeof(uint32_t) >= TILE_E * sizeof(uint16_t) && TILE_E <= (1u << 12) && EQ_BIN_LIMIT <= 128 &&
                   TILE_NT % TIE_G1 == 0 && TILE_NT % TIE_G2 == 0 && TIE_G1 + TIE_G2 < 0x80u && TIE_LIST_CAP <= (1u << 12) &&
                   TIE_BIG_CAP <= (1u << 12) && (TILE_NT & (TILE_NT - 1u)) == 0 &&
@@ -1622,11 +1638,13 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
         }
         TILE_SYNC();
         PHASE_MARK(17);                                        // T: the listed ties
+        fast = flag[0] == 0 && flag[1] == 0;                   // (the tie phases were the last to raise them)
+        if (fast) {
         PAR_FRESH_SET(tid) {
             UNROLL
             for (uint32_t k = 0; k < TILE_EPT; ++k) {
                 const uint32_t e = tid + k * TILE_NT;
-                TL(rl, tid, k) = 0;
+                if (!PERM) TL(rl, tid, k) = 0;
                 if (e < cnt) {
                     const uint32_t info = TL(rt, tid, k);
                     const uint32_t ties = info >> 28, slot = TL(rd, tid, k), own = (info >> 8) & 0xFFFu;
@@ -1644,28 +1662,41 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                                     if (vj < pcnt[0]) { const uint32_t en = plist[vj]; if ((en & 0xFFFu) == slot || ((en >> 12) & 0xFFFu) == slot) best = vlcp[q]; }
                                 }
                             }
+                            if (TEST_DROP) best = 0;                       // (tests: the note is lost)
                         }
                     } else if (ties >= 2u && ties <= TIE_LIST_MAX) {
                         for (uint32_t q = 0; q < ties; ++q) {
-                            const uint32_t r = plist[TIE_LIST_CAP - 1u - (own + q)];       // (anything when the tile has failed)
+                            const uint32_t r = plist[TIE_LIST_CAP - 1u - (own + q)];
                             if (r & 0x01000000u) { ++more; best = (r & 0xFFFFFFu) > best ? (r & 0xFFFFFFu) : best; }
                         }
                     } else if (ties > TIE_LIST_MAX) {
-                        more = bmore[own];                                 // (phase B; anything when the tile has failed)
+                        more = bmore[own];                                 // (phase B)
                         best = bbest[own];
                     }
-                    TL(rl, tid, k) = best;
-                    TL(rk, tid, k) = skey[slot];                           // picked up for the final placement (behind the barrier)
-                    TL(rs, tid, k) = ssa[slot];
-                    TL(rd, tid, k) = bs + (((info & 0xFFu) + more) & 0xFFu);
-                    EQ_CHK(slot < cnt, 12);
+                    const uint32_t d = bs + (((info & 0xFFu) + more) & 0xFFu);
+                    EQ_CHK(slot < cnt && d < cnt, 12);
+                    if (PERM) {
+                        // the lcp with the predecessor, where a tie settled it, stays with the SLOT (the few beyond 15 bits: vslot / vlcp2)
+                        uint32_t lc = best;
+                        if (VDEEP && lc >= 0x7FFFu) {
+                            const uint32_t q = FETCH_ADD_U32(&pcnt[5], 1u);
+                            if (q < TIE_VDEEP_CAP) { vslot[q] = (uint16_t)slot; vlcp2[q] = lc; }
+                            lc = q < TIE_VDEEP_CAP ? 0x7FFFu : 0u;         // (no room: the emit phase derives it from the text)
+                        }
+                        tinfo[slot] = (uint16_t)lc;
+                        if (d < TILE_E) perm[d] = (uint16_t)slot;          // (always, in a tile that has not failed: d < cnt)
+                    } else {
+                        TL(rl, tid, k) = best;
+                        TL(rk, tid, k) = skey[slot];                       // picked up for the final placement (behind the barrier)
+                        TL(rs, tid, k) = ssa[slot];
+                        TL(rd, tid, k) = d;
+                    }
                 }
             }
         }
         TILE_SYNC();
-        fast = flag[0] == 0 && flag[1] == 0;
         PHASE_MARK(13);                                        // rank inside the bin
-        if (fast) {
+        if (!PERM) {
             PAR_SAME_G(4, tid) {
                 UNROLL
                 for (uint32_t k = 0; k < TILE_EPT; ++k) {
@@ -1689,6 +1720,7 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
             TILE_SYNC();
             PHASE_MARK(14);                                    // place final
         }
+        }
     }
 #ifdef CAPS_EMUL
     caps_emul_count_tile3(fast);
@@ -1696,10 +1728,43 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
     if (!fast) {
         uint32_t* q_ = !VDEEP && redo_deep && flag[0] == 0 ? redo_deep : redo2;        // block-uniform
         PAR(tid) { if (tid == 0) q_[1 + FETCH_ADD_U32(&q_[0], 1u)] = b; }
+    } else if (PERM) {
+        // sorted order -> HBM through perm (+ LCPs: the tie phases' notes, else from the neighbours' keys, + boundary records)
+        PAR(tid) {
+            UNROLL
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                const uint32_t e = tid + k * TILE_NT;
+                if (e < cnt) {
+                    const uint32_t sl = perm[e];
+                    const uint64_t key = skey[sl];
+                    const idx_t sa = ssa[sl];
+                    uint64_t l = 0;
+                    if (with_lcp && e) {
+                        uint32_t ov = tinfo[sl];
+                        if (VDEEP && ov == 0x7FFFu) ov = eq_big_lcp(vslot, vlcp2, pcnt[5], sl);
+                        if (ov) l = ov;
+                        else { const uint32_t sp = perm[e - 1]; l = TILE_EMIT_LCP_(skey[sp], ssa[sp], key, sa); }
+                    }
+                    if (direct) {
+                        fin.sa[start + e] = sa;
+                        fin.lcp[start + e] = (idx_t)l;
+                        if (e == 0) { fin.first_key[g] = key; fin.first_sa[g] = sa; }
+                        if (e == cnt - 1) { fin.last_key[g] = key; fin.last_sa[g] = sa; }
+                    } else {
+                        out_key[start + e] = key;
+                        out_sa[start + e] = sa;
+                        if (with_lcp) out_lcp[start + e] = (idx_t)l;
+                    }
+                }
+            }
+        }
     } else {
         TILE_SORT_EMIT_((!VDEEP || tinfo[e] != 0x7FFFu ? (uint32_t)tinfo[e] : eq_big_lcp(vslot, vlcp, pcnt[5], e)))
     }
     TILE_SYNC();                                                    // the staging arrays are free for the next tile
+    if (!VDEEP && fast && flag[1]) {                                // block-uniform: eq_emit_lcp met equal keys without a note
+        PAR(tid) { if (tid == 0) redo2[1 + FETCH_ADD_U32(&redo2[0], 1u)] = b; }
+    }
     PHASE_MARK(15);                                            // emit (+ LCPs) and the barrier behind it
     qi += K_GRID_DIM;
     } while (PERSIST && qi < n_redo);

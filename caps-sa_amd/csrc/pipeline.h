@@ -748,6 +748,8 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
     be.memset(redo3, 0, sizeof(uint32_t));
     const uint32_t ggrid = n_tiles < 4 * be.persistent_blocks() ? n_tiles : 4 * be.persistent_blocks();
     const bool eq_tiles = !std::getenv("CAPS_SA_NO_EQ_TILES");        // measurement: skip tile_sort_eq_kernel
+    // tests: tile_sort_eq_kernel loses the lcp notes of its tied pairs on purpose -- its emit phase must notice and pass the tile on
+    const uint32_t drop = std::getenv("CAPS_SA_TEST_DROP_NOTE") ? 2u : 0u;
     if (!eq_tiles) redo3 = redo2 = redo;
     // deferred ties: only where the sort writes THE arrays (sentinels must not reach a consumer that reads LCPs as numbers)
     uint64_t* bflag = o.defer_flags && o.need_lcp && o.final_sa && !o.keys_only && !(o.k32 && slot_cap) ? o.defer_flags : nullptr;
@@ -775,7 +777,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, true>), n_tiles, TILE_NT, be, sd, P, n, o.text_base, lcp_mode, 0u,
                     (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, seg_map, redo, no_shift);
         if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, true>), ggrid, TILE_NT, be, sd, P, n, o.text_base, lcp_mode, 0u,
-                    (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo, redo3, 0u, redo2);
+                    (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo, redo3, 0u | drop, redo2);
         if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, true, true>), ggrid, TILE_NT, be, sd, P, n, o.text_base, lcp_mode, 0u,
                     (const uint64_t*)nullptr, (const idx_t*)nullptr, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo2, redo3, 0u, (uint32_t*)nullptr);
         CAPS_LAUNCH_RUNS(tile_sort_general_kernel, (idx_t, BITS, true), ggrid, TILE_NT, be, sd, P, n, o.text_base, lcp_mode, 0u,
@@ -785,7 +787,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, false, uint32_t>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
                     reinterpret_cast<const uint32_t*>(in_key), in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, redo, (const uint8_t*)o.bk->kshift);
         if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false>), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
-                    (const uint64_t*)nullptr, in_sa, cur.key, cur.sa, cur.lcp, fin, (const BucketParams*)nullptr, (const uint32_t*)redo, redo3, 1u, redo2);
+                    (const uint64_t*)nullptr, in_sa, cur.key, cur.sa, cur.lcp, fin, (const BucketParams*)nullptr, (const uint32_t*)redo, redo3, 1u | drop, redo2);
         if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false, true>), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
                     (const uint64_t*)nullptr, in_sa, cur.key, cur.sa, cur.lcp, fin, (const BucketParams*)nullptr, (const uint32_t*)redo2, redo3, 1u, (uint32_t*)nullptr);
         CAPS_LAUNCH_RUNS(tile_sort_general_kernel, (idx_t, BITS, false), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
@@ -806,7 +808,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         if (per_tile) {
             // (no queue: workgroup b takes tile b)
             CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false, false, false>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
-                        in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)nullptr, redo3, 0u, redo2);
+                        in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)nullptr, redo3, 0u | drop, redo2);
             // what is left goes on with exact grids, one workgroup per entry: the lengths of the two queues come back to the
             // host (a round trip of ~20 us; a grid over all tiles for a queue that is mostly empty costs 0.8 ms at 3e9, and the
             // builds that walk a queue with a fixed grid hold 6 - 20 x more registers in scratch)
@@ -831,7 +833,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
                             in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo3, 0u, bflag);
         } else {
             if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false>), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
-                        in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo, redo3, 0u, redo2);
+                        in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo, redo3, 0u | drop, redo2);
             if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false, true>), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
                         in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo2, redo3, 0u, (uint32_t*)nullptr);
             if (bflag) {                                  // (one round trip, only where ties may be deferred)

@@ -407,18 +407,20 @@ def bench_main(args, rank: int, local_rank: int, world: int):
             roof = None
             if not direct:    # samplesort sequence: each phase is two streaming passes (bucket scatter + tile sort) over the rank's share
                 k = len(infos)
-                roof = roofline({"phase1_sort_subarrays": (sum(i["ms_phase1"] for i in infos) / 2, k, sum(i["local_elems"] for i in infos)),
-                                 "phase2_sort_partitions": (sum(i["ms_phase2"] for i in infos) / 2, k, sum(i["recv_total"] for i in infos))}, w, "")
+                roof = roofline({"phase1_sort_subarrays": (sum(i["ms_phase1"] for i in infos) / 2, k, sum(i["local_elems"] for i in infos), None),
+                                 "phase2_sort_partitions": (sum(i["ms_phase2"] for i in infos) / 2, k, sum(i["recv_total"] for i in infos), None)}, w, "",
+                                sum(i["ms_phase1"] + i["ms_pivots"] + i["ms_collate"] + i["ms_exchange"] + i["ms_phase2"] for i in infos))
                 if roof:
                     roof["scope"] = (f"rank 0 of {world}, samplesort sequence: a phase is two streaming passes (bucket scatter + tile sort) over the "
                                      "rank's share; avg_launch_ms = half the phase")
             if direct:        # rank 0's kernels over ITS share of the suffixes, same convention as at N = 1
                 k = len(infos)
-                roof = roofline({"level_a_scatter": (sum(i["ms_level_a"] for i in infos), k, sum(i["level_a_elems"] for i in infos)),
-                                 "level_b_scatter": (sum(i["ms_level_b"] for i in infos), k, sum(i["recv_total"] for i in infos)),
-                                 "tile_sort_kernel": (sum(i["ms_tile_sort"] for i in infos), k, sum(i["recv_total"] for i in infos)),
+                roof = roofline({"level_a_scatter": (sum(i["ms_level_a"] for i in infos), k, sum(i["level_a_elems"] for i in infos), None),
+                                 "level_b_scatter": (sum(i["ms_level_b"] for i in infos), k, sum(i["recv_total"] for i in infos), None),
+                                 "tile_sort_kernel": (sum(i["ms_tile_sort"] for i in infos), k, sum(i["recv_total"] for i in infos), None),
                                  "merge_pass_kernel": (sum(i["ms_merge_passes"] for i in infos), k if info["ms_merge_passes"] > 0 else 0,
-                                                       sum(i["recv_total"] for i in infos))}, w, "")
+                                                       sum(i["recv_total"] for i in infos), None)}, w, "",
+                                sum(i["ms_scatter"] + i["ms_exchange"] + i["ms_sort"] for i in infos))
                 if roof:
                     roof["scope"] = f"rank 0 of {world}: its kernels over its {mine} suffixes"
             ms_x = sum(i["ms_exchange"] for i in infos) / len(infos)
@@ -446,6 +448,9 @@ def bench_main(args, rank: int, local_rank: int, world: int):
                 "ranks_ms": ranks_ms,
                 "suffixes_per_rank": {"max": int(share.max().item()), "min": int(share.min().item())},
                 "shard_mode": "exchange" if info.get("exchange") else "local",
+                "shard_mode_requested": args.shard_mode,
+                "process_group": {"backend": dist.get_backend(), "ranks_seen": dist.get_world_size(),
+                                  "devices_visible_to_rank0": torch.cuda.device_count() if torch.cuda.is_available() else 0},
                 "exchange": {"ms": ms_x, "bytes_sent_per_rank": sent, "GBps_per_rank": (sent / 1e9) / (ms_x * 1e-3) if ms_x > 0 and sent else None,
                              "key_bytes": info.get("key_bytes", 8) if direct else 8, "key_retries": sum(i.get("key_retry", 0) for i in infos),
                              "note": ("no data-path collective: every rank scatters the whole (replicated) text and keeps the groups it owns"

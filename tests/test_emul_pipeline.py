@@ -522,6 +522,35 @@ def test_equalised_tile_sort_settles_ties_once(oracle):
         assert int((LCP >= 40).sum()) > n // 100 and int(LCP.max()) >= 2999
 
 
+def test_a_lost_tie_note_sends_the_tile_to_the_comparison_sort(oracle, monkeypatch):
+    """a tie note that gets lost must not become a wrong LCP.  CAPS_SA_TEST_DROP_NOTE makes tile_sort_eq_kernel lose
+    the notes of its tied pairs; its emit phase then meets equal keys without a note and hands the tile to the comparison sort (the
+    counters: tiles there that were not before), and the arrays are still THE arrays."""
+    import ctypes
+    E = emul()
+    f = E.dll.caps_sa_emul_tile_stats8
+    f.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    a = (ctypes.c_uint64 * 8)()
+    rs = np.random.RandomState(77)
+    n = 300_000
+    T = rs.choice(DNA, size=n, p=[0.4, 0.1, 0.15, 0.35])
+    for _ in range(n // 1500):                               # pairs of equal 32-mers: a copy with one mutation
+        s, d = rs.randint(0, n - 90, size=2)
+        T[d:d + 90] = T[s:s + 90]
+        T[d + rs.randint(40, 90)] = DNA[rs.randint(0, 4)]
+    SAo, LCPo = oracle.build_sa_lcp(T, p=24)
+    seen = []
+    for drop in (False, True):
+        if drop:
+            monkeypatch.setenv("CAPS_SA_TEST_DROP_NOTE", "1")
+        f(a, 1)
+        SA, LCP, st = E.build(T, p=24)
+        f(a, 1)
+        assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), drop
+        seen.append((int(a[4] + a[5]), int(a[7])))           # tiles of the comparison sort, tiles the equalised kernel finished
+    assert seen[0][1] > 0 and seen[1][0] > seen[0][0] + 10, seen
+
+
 def test_phases_do_not_depend_on_the_order_of_their_threads(oracle, monkeypatch):
     """the emulation runs the threads of a phase one after the other, so it cannot see a missing barrier -- unless
     the order changes the outcome.  The same sources compiled with the threads of every phase in DESCENDING order

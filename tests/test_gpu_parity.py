@@ -825,6 +825,32 @@ def test_results_leave_in_waves_host_path(L, oracle, monkeypatch):
     L.release_cache()
 
 
+@pytest.mark.gpu
+def test_a_lost_tie_note_sends_the_tile_to_the_comparison_sort_device(oracle, monkeypatch):
+    """tile_sort_eq_kernel's plain build reads the lcp of two neighbours with EQUAL keys from the note the tie
+    phases left; if a note were ever lost it would emit the capped key length -- a wrong LCP nothing but the verifier would see.
+    CAPS_SA_TEST_DROP_NOTE makes it lose the notes of all tied pairs: the emit phase must notice (equal keys, no note), queue the
+    tile for the comparison sort, and the arrays must still be THE arrays."""
+    L = _gpu_lib()
+    rs = np.random.RandomState(77)
+    n = 1_500_000
+    T = rs.choice(DNA, size=n, p=[0.4, 0.1, 0.15, 0.35])
+    for _ in range(n // 1500):                               # pairs of equal 32-mers: a copy with one mutation
+        s, d = rs.randint(0, n - 90, size=2)
+        T[d:d + 90] = T[s:s + 90]
+        T[d + rs.randint(40, 90)] = DNA[rs.randint(0, 4)]
+    SAo, LCPo = oracle.build_sa_lcp(T, p=200)
+    for mode in ("quantile", "linear"):
+        monkeypatch.setenv("CAPS_SA_DIRECT_MODE", mode)
+        monkeypatch.setenv("CAPS_SA_TEST_DROP_NOTE", "1")
+        SA, LCP, st = L.build(T, p=200)
+        assert st["path_direct"] == 1
+        assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), mode
+        monkeypatch.delenv("CAPS_SA_TEST_DROP_NOTE")
+        SA, LCP, st = L.build(T, p=200)
+        assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), mode
+
+
 def _repeat_rich(rs, n, alphabet=DNA):
     """GRCh38-shaped repeat content at oracle-checkable size (tools/genome_like.py plant_genome_repeats in small): a tandem array of
     a 171-char monomer at 2 %, a higher-order array (12 monomers 20 % apart, units 0.7 % apart), 3000 copies of a 300-char family

@@ -14,8 +14,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import kernel_sources_sha256  # noqa: E402
 
-FAMILY = [("group_scatter_kernel", "level_a_scatter"), ("bucket_scatter_kernel", "level_b_scatter"), ("tile_sort_eq_kernel", "tile_sort_kernel"),
-          ("tile_sort_kernel", "tile_sort_kernel"), ("tile_sort_general_kernel", "tile_sort_kernel"), ("merge_pass_kernel", "merge_pass_kernel")]
+# kernel name prefix -> family of bench.py's roofline (first match wins)
+FAMILY = [("group_scatter_kernel", "level_a_scatter"), ("bucket_scatter_kernel", "level_b_scatter"), ("bucket_count_kernel", "level_b_count"),
+          ("tile_sort_eq_kernel", "tile_sort_kernel"), ("tile_sort_kernel", "tile_sort_kernel"), ("tile_sort_general_kernel", "tile_sort_kernel"),
+          ("merge_pass_kernel", "merge_pass_kernel"), ("merge_partition_kernel", "merge_pass_kernel"),
+          ("pack_kernel", "pack"), ("alphabet_kernel", "pack"), ("run_blocks_kernel", "pack"), ("run_chunk_heads_kernel", "pack"),
+          ("run_carry_kernel", "pack"), ("run_resolve_kernel", "pack"),
+          ("msd_", "deferred_ties"), ("finalize_kernel", "finish_gather_head_lcps"), ("head_lcp_kernel", "finish_gather_head_lcps"),
+          ("sample_", "sample_pivots"), ("pick_pivots_kernel", "sample_pivots"), ("knot", "sample_pivots"), ("group_keys_kernel", "sample_pivots"),
+          ("group_caps_kernel", "sample_pivots"), ("skew_probe_kernel", "sample_pivots"), ("make_keys_kernel", "sample_pivots"),
+          ("locate_kernel", "locate_pivots"), ("collate_kernel", "collate"), ("run_", "run_buckets")]
 
 
 def sums(d, counter):
@@ -26,7 +34,7 @@ def sums(d, counter):
             continue
         name = re.sub(r"^void caps::", "", row["Kernel_Name"])
         for pat, fam in FAMILY:
-            if name.startswith(pat + "<") or name.startswith(pat + "("):
+            if name.startswith(pat + "<") or name.startswith(pat + "(") or (pat.endswith("_") and name.startswith(pat)) or (pat == "knot" and name.startswith(pat)):
                 out[fam] += float(row["Counter_Value"]) * 1024.0          # both counters are reported in KB
                 break
     return out
