@@ -71,7 +71,7 @@ class Stats(ctypes.Structure):
         ("tie_groups_deferred", ctypes.c_uint64),
         ("tie_elems_deferred", ctypes.c_uint64),
         ("tie_levels", ctypes.c_uint32),
-        ("reserved_", ctypes.c_uint32),
+        ("lcp_bytes_on_link", ctypes.c_uint32),
         ("finish_ms", ctypes.c_double),
         ("run_bucket_ms", ctypes.c_double),
         ("msd_ms", ctypes.c_double),

@@ -9,6 +9,8 @@
 #include <exception>
 #include <limits>
 #include <memory>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -143,17 +145,195 @@ int build_device(const void* dT, uint64_t n, uint64_t p_arg, uint64_t max_contex
 // SA / LCP is final), a second stream waits for that point of the build's stream and copies the slice to the caller's arrays
 // while the next wave is sorted -- the D2H of 2 n indices (24 GB at C3: 420 ms at the link rate) then hides the rest of the
 // build instead of following it.  (The upload of T cannot hide anything: sampling and level A need the whole text.)
+//
+// LCP as bytes (32-bit indices; lcp_narrow_kernel): on the link the LCP array is a quarter of its size -- 15 GB instead of 24 at C3.
+// Per slice, on the copy stream: narrow on the device, copy the bytes into a page-locked staging array, copy the SA slice; a host
+// thread waits for the bytes and widens them into the caller's array (a few worker threads, streaming stores) while the SA slice
+// and the next slices are on the link.  Values of 255 and more travel as (position, value) pairs at the end; when there are more of
+// them than the list holds (a^n: every value), the whole array is copied at full width as before.
+inline uint32_t host_worker_threads()
+{
+    if (const char* e = std::getenv("CAPS_SA_HOST_THREADS")) return (uint32_t)std::max(1, std::atoi(e));
+    uint32_t hw = std::thread::hardware_concurrency();
+    // (a container's CPU quota is usually far below the node's thread count: the GPU boxes show 256 and grant 16)
+    FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r");
+    if (f) {
+        long long q = 0, per = 0;
+        char qs[32] = {0};
+        if (std::fscanf(f, "%31s %lld", qs, &per) == 2 && std::strcmp(qs, "max") != 0 && per > 0) {
+            q = std::atoll(qs);
+            if (q > 0) hw = std::min<uint32_t>(hw ? hw : 1u, (uint32_t)std::max<long long>(1, (q + per - 1) / per));
+        }
+        std::fclose(f);
+    }
+    return std::max(1u, std::min(hw ? hw : 1u, 32u));
+}
+
+// out[i] = in[i] for i in [0, cnt): bytes to 32-bit values, with streaming stores where the compiler has them (the 12 GB written at
+// C3 would otherwise be read first, line by line)
+inline void widen_bytes(const uint8_t* in, uint32_t* out, uint64_t cnt)
+{
+    uint64_t i = 0;
+#if defined(__clang__) && defined(__SSE2__)
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    for (; i < cnt && (reinterpret_cast<uintptr_t>(out + i) & 15u); ++i) out[i] = in[i];
+    for (; i + 4 <= cnt; i += 4) {
+        const v4u v = {in[i], in[i + 1], in[i + 2], in[i + 3]};
+        __builtin_nontemporal_store(v, reinterpret_cast<v4u*>(out + i));
+    }
+#endif
+    for (; i < cnt; ++i) out[i] = in[i];
+}
+
 template <typename idx_t> struct HostCopySink : WaveSink {
     decltype(Backend::stream) copy_stream;
     idx_t *SA, *LCP;
     const idx_t *dSA, *dLCP;
     uint64_t copied = 0;
+    // LCP as bytes (null: plain copies)
+    uint8_t* d8 = nullptr;             // device: the bytes
+    uint64_t* dexc = nullptr;          // device: exceptions, (position << 32 | value)
+    uint64_t* dexc_count = nullptr;
+    uint64_t exc_cap = 0;
+    uint8_t* h8 = nullptr;             // host, page-locked: the bytes
+    uint64_t* hexc = nullptr;          // host, page-locked: the exceptions (hexc[exc_cap] receives the count)
+    uint32_t workers = 1;
+    struct Task { BackendEvent ev; uint64_t base, cnt; };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Task> tasks;
+    bool closing = false, busy = false;
+    std::thread dispatcher;
+    std::exception_ptr failure;
+
+    bool narrow() const { return d8 != nullptr; }
+    void widen_slice(uint64_t base, uint64_t cnt)
+    {
+        if (sizeof(idx_t) != 4) return;
+        uint32_t* out = reinterpret_cast<uint32_t*>(LCP) + base;
+        const uint8_t* in = h8 + base;
+#ifdef CAPS_EMUL
+        widen_bytes(in, out, cnt);
+#else
+        const uint32_t K = (uint32_t)std::min<uint64_t>(workers, std::max<uint64_t>(1, cnt >> 20));
+        if (K <= 1) { widen_bytes(in, out, cnt); return; }
+        std::vector<std::thread> th;
+        const uint64_t per = ((cnt + K - 1) / K + 63) & ~uint64_t(63);
+        for (uint32_t k = 0; k < K; ++k) {
+            const uint64_t a = std::min<uint64_t>(cnt, (uint64_t)k * per), b = std::min<uint64_t>(cnt, a + per);
+            if (a < b) th.emplace_back([=] { widen_bytes(in + a, out + a, b - a); });
+        }
+        for (auto& t : th) t.join();
+#endif
+    }
+    void start()
+    {
+#ifndef CAPS_EMUL
+        if (!narrow()) return;
+        dispatcher = std::thread([this] {
+            for (;;) {
+                Task t;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [this] { return closing || !tasks.empty(); });
+                    if (tasks.empty()) return;
+                    t = tasks.front();
+                    tasks.pop_front();
+                    busy = true;
+                }
+                try {
+                    Backend::wait_event(t.ev);
+                    Backend::destroy_event(t.ev);
+                    widen_slice(t.base, t.cnt);
+                } catch (...) { std::lock_guard<std::mutex> lk(mu); failure = std::current_exception(); }
+                { std::lock_guard<std::mutex> lk(mu); busy = false; }
+                cv.notify_all();
+            }
+        });
+#endif
+    }
+    void drain()                       // every slice handed over so far has been widened
+    {
+#ifndef CAPS_EMUL
+        if (!dispatcher.joinable()) return;
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [this] { return tasks.empty() && !busy; });
+#endif
+    }
+    void stop()
+    {
+#ifndef CAPS_EMUL
+        if (!dispatcher.joinable()) return;
+        { std::lock_guard<std::mutex> lk(mu); closing = true; }
+        cv.notify_all();
+        dispatcher.join();
+#endif
+    }
+    ~HostCopySink() override { stop(); }
+
     void wave_done(Backend& be, uint64_t base, uint64_t cnt) override
     {
         Backend::stream_wait(copy_stream, be.record());
-        Backend::d2h_on(copy_stream, SA + base, dSA + base, cnt * sizeof(idx_t));
-        Backend::d2h_on(copy_stream, LCP + base, dLCP + base, cnt * sizeof(idx_t));
+        if (narrow()) {
+            Backend cb(copy_stream);
+            const uint64_t rounds = (cnt + 256ull * NARROW_PER - 1) / (256ull * NARROW_PER);
+            CAPS_LAUNCH(lcp_narrow_kernel, capped_grid(std::min<uint64_t>(rounds, 4096), 256), 256, cb,
+                        reinterpret_cast<const uint32_t*>(dLCP) + base, cnt, base, d8 + base, dexc_count, exc_cap, dexc);
+            Backend::d2h_on(copy_stream, h8 + base, d8 + base, cnt);
+            const BackendEvent ev = Backend::record_on(copy_stream);
+            Backend::d2h_on(copy_stream, SA + base, dSA + base, cnt * sizeof(idx_t));
+#ifdef CAPS_EMUL
+            widen_slice(base, cnt);
+            (void)ev;
+#else
+            { std::lock_guard<std::mutex> lk(mu); tasks.push_back(Task{ev, base, cnt}); }
+            cv.notify_all();
+#endif
+        } else {
+            Backend::d2h_on(copy_stream, SA + base, dSA + base, cnt * sizeof(idx_t));
+            Backend::d2h_on(copy_stream, LCP + base, dLCP + base, cnt * sizeof(idx_t));
+        }
         copied += cnt;
+    }
+    void reset(Backend&) override
+    {
+        Backend::sync_stream(copy_stream);                  // nothing reads the device arrays any more
+        drain();
+        if (narrow()) { Backend::memset_on(copy_stream, dexc_count, 0, sizeof(uint64_t)); Backend::sync_stream(copy_stream); }
+        copied = 0;
+    }
+    // after the last slice: the values of 255 and more.  false: more of them than the list holds -- the caller copies LCP at full width
+    bool finish_lcp(uint64_t n)
+    {
+        if (!narrow()) { Backend::sync_stream(copy_stream); return true; }        // (the last copies have landed)
+        Backend::d2h_on(copy_stream, hexc + exc_cap, dexc_count, sizeof(uint64_t));
+        Backend::sync_stream(copy_stream);
+        drain();
+        if (failure) std::rethrow_exception(failure);
+        const uint64_t ne = hexc[exc_cap];
+        if (ne > exc_cap) return false;
+        if (ne) {
+            Backend::d2h_on(copy_stream, hexc, dexc, ne * sizeof(uint64_t));
+            Backend::sync_stream(copy_stream);
+            auto patch = [this, n](uint64_t a, uint64_t b) {
+                for (uint64_t i = a; i < b; ++i) {
+                    const uint64_t pos = hexc[i] >> 32;
+                    if (pos < n) LCP[pos] = (idx_t)(hexc[i] & 0xFFFFFFFFull);
+                }
+            };
+#ifdef CAPS_EMUL
+            patch(0, ne);
+#else
+            const uint32_t K = (uint32_t)std::min<uint64_t>(workers, std::max<uint64_t>(1, ne >> 16));
+            if (K <= 1) patch(0, ne);
+            else {                                           // (scattered stores: a few million of them on a repeat-rich genome)
+                std::vector<std::thread> th;
+                for (uint32_t k = 0; k < K; ++k) th.emplace_back(patch, ne * k / K, ne * (k + 1) / K);
+                for (auto& t : th) t.join();
+            }
+#endif
+        }
+        return true;
     }
 };
 #ifndef CAPS_HOST_WAVES
@@ -170,6 +350,8 @@ struct HostPathCache {
     int device = -1;
     char* base = nullptr;
     size_t bytes = 0;
+    char* host = nullptr;              // page-locked staging of the LCP bytes and their exceptions (HostCopySink)
+    size_t host_bytes = 0;
 };
 inline HostPathCache& host_cache()
 {
@@ -183,6 +365,9 @@ inline void release_host_cache_locked(HostPathCache& c)
         Backend be(nullptr);
         be.free(c.base);
     }
+    if (c.host) Backend::host_free(c.host);
+    c.host = nullptr;
+    c.host_bytes = 0;
     c.base = nullptr;
     c.bytes = 0;
     c.device = -1;
@@ -220,12 +405,39 @@ int build_host(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context, 
         // waves cost 14 ms (per-wave host synchronisations, 24 copies instead of 2), at C3 (3e9) they save 31 of 524 ms
         uint32_t waves = n >= (400ull << 20) ? CAPS_HOST_WAVES : 1u;
         if (const char* e = std::getenv("CAPS_SA_HOST_WAVES")) waves = (uint32_t)std::max(1, std::atoi(e));
-        const size_t total = off_ws + need.bytes + 1024 + wave_scratch_bytes<idx_t>(wave_scratch_elems(n, waves));
+        // LCP as bytes: with waves (the builds long enough for the link to matter), 32-bit indices; CAPS_SA_HOST_NARROW_LCP=0 / 1
+        bool narrow = sizeof(idx_t) == 4 && waves > 1;
+        if (const char* e = std::getenv("CAPS_SA_HOST_NARROW_LCP")) narrow = sizeof(idx_t) == 4 && std::atoi(e) != 0;
+        const uint64_t exc_cap = narrow ? std::max<uint64_t>(1024, n / 32) : 0;
+        const size_t narrow_dev = narrow ? up(n) + up((exc_cap + 1) * sizeof(uint64_t)) + 512 : 0;
+        const size_t ws_room = need.bytes + 1024 + wave_scratch_bytes<idx_t>(wave_scratch_elems(n, waves));
+        const size_t total = off_ws + ws_room + narrow_dev;
         if (hc.device != device || hc.bytes < total) {
+            const size_t keep_host = hc.host_bytes;
+            char* keep = hc.host;
+            hc.host = nullptr;                               // (the staging arrays survive a larger device block)
             release_host_cache_locked(hc);
+            hc.host = keep;
+            hc.host_bytes = keep_host;
+            const auto a0 = std::chrono::steady_clock::now();
             hc.base = static_cast<char*>(be.alloc(total));
             hc.bytes = total;
             hc.device = device;
+            if (std::getenv("CAPS_SA_DEBUG_ALLOC"))
+                std::fprintf(stderr, "[alloc] device block of %zu bytes: %.1f ms\n", total,
+                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a0).count());
+        }
+        const size_t host_need = narrow ? up(n) + up((exc_cap + 1) * sizeof(uint64_t)) : 0;
+        if (narrow && hc.host_bytes < host_need) {
+            if (hc.host) Backend::host_free(hc.host);
+            hc.host = nullptr;
+            hc.host_bytes = 0;
+            const auto a0 = std::chrono::steady_clock::now();
+            hc.host = static_cast<char*>(Backend::host_alloc(host_need));
+            hc.host_bytes = host_need;
+            if (std::getenv("CAPS_SA_DEBUG_ALLOC"))
+                std::fprintf(stderr, "[alloc] page-locked staging of %zu bytes: %.1f ms\n", host_need,
+                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a0).count());
         }
         char* base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(hc.base) + 255) & ~uintptr_t(255));
         uint8_t* dT = reinterpret_cast<uint8_t*>(base);
@@ -250,21 +462,42 @@ int build_host(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context, 
         sink.LCP = LCP;
         sink.dSA = dSA;
         sink.dLCP = dLCP;
+        if (narrow) {
+            char* nb = base + off_ws + up(ws_room);
+            sink.d8 = reinterpret_cast<uint8_t*>(nb);
+            sink.dexc = reinterpret_cast<uint64_t*>(nb + up(n));
+            sink.dexc_count = sink.dexc + exc_cap;
+            sink.exc_cap = exc_cap;
+            sink.h8 = reinterpret_cast<uint8_t*>(hc.host);
+            sink.hexc = reinterpret_cast<uint64_t*>(hc.host + up(n));
+            sink.workers = host_worker_threads();
+            be.memset(sink.dexc_count, 0, sizeof(uint64_t));
+            be.sync();
+        }
+        sink.start();
         struct StreamGuard { decltype(Backend::stream) s; ~StreamGuard() { Backend::destroy_stream(s); } } guard{sink.copy_stream};
         bool served = false;
         const auto t0 = std::chrono::steady_clock::now();
-        int rc = build_device<idx_t>(dT, n, p_arg, max_context, dSA, dLCP, base + off_ws, hc.bytes - off_ws - 256, nullptr, &local, waves,
+        int rc = build_device<idx_t>(dT, n, p_arg, max_context, dSA, dLCP, base + off_ws, ws_room - 256, nullptr, &local, waves,
                                      &sink, &served, text_bits);
-        if (rc == CAPS_SA_EALPHABET && text_bits == 2) { Backend::sync_stream(sink.copy_stream); continue; }
-        if (rc) { Backend::sync_stream(sink.copy_stream); return rc; }
+        if (rc == CAPS_SA_EALPHABET && text_bits == 2) { Backend::sync_stream(sink.copy_stream); sink.drain(); sink.stop(); continue; }
+        if (rc) { Backend::sync_stream(sink.copy_stream); sink.drain(); return rc; }
+        bool lcp_as_bytes = sink.narrow();
         if (!served || sink.copied != n) {           // another construction (samplesort path, tiny input): nothing was streamed out
             Backend::sync_stream(sink.copy_stream);
+            sink.drain();
             be.d2h(SA, dSA, n * sizeof(idx_t));
             be.d2h(LCP, dLCP, n * sizeof(idx_t));
             be.sync();
-        } else {
-            Backend::sync_stream(sink.copy_stream);
+            local.result_waves = 1;
+            lcp_as_bytes = false;
+        } else if (!sink.finish_lcp(n)) {            // more values of 255 and more than the list holds: LCP at full width
+            be.d2h(LCP, dLCP, n * sizeof(idx_t));
+            be.sync();
+            lcp_as_bytes = false;
         }
+        sink.stop();
+        local.lcp_bytes_on_link = lcp_as_bytes ? 1u : (uint32_t)sizeof(idx_t);
         local.ms_h2d = be.elapsed_ms(h0, h1);
         // build + result copies, overlapped: host wall clock from the launch of the build to the last byte on the host, minus the build
         const double wall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

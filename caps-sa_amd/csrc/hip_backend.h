@@ -101,6 +101,17 @@ public:
         if (bytes) CAPS_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, s));
     }
     static void sync_stream(hipStream_t s) { CAPS_HIP(hipStreamSynchronize(s)); }
+    // an event of the caller's own on any stream (the host waits for it: build_host's widening of LCP bytes follows the copies)
+    static BackendEvent record_on(hipStream_t s)
+    {
+        hipEvent_t e;
+        CAPS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        CAPS_HIP(hipEventRecord(e, s));
+        return BackendEvent{e};
+    }
+    static void wait_event(BackendEvent e) { CAPS_HIP(hipEventSynchronize(e.ev)); }
+    static void destroy_event(BackendEvent e) { if (e.ev) (void)hipEventDestroy(e.ev); }
+    static void memset_on(hipStream_t s, void* d, int v, size_t bytes) { CAPS_HIP(hipMemsetAsync(d, v, bytes, s)); }
     // the same on any stream of the SOURCE device (build_multi's fan-out of the text: one stream per destination, so the copies
     // to different peers run side by side, each over its own xGMI link)
     static void peer_copy_on(hipStream_t s, void* dst, int dst_dev, const void* src, int src_dev, size_t bytes)

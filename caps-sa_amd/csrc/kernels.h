@@ -4500,4 +4500,53 @@ GLOBAL_FN LAUNCH_BOUNDS(256) verify_kernel(KCTX const int8_t* __restrict__ T, ui
     }
 }
 
+// ---- f2: LCP values leave the device as BYTES (capi_impl.h HostCopySink) -------------------------------------------------------
+// The D2H of SA and LCP is what a host-buffer build waits for (24 GB at C3: 390 of 494 ms), and LCP values are small -- mean 12 on
+// random DNA, a few dozen on a genome.  out8[i] = lcp[i] if it is below 255, else 255 with (base + i) << 32 | lcp[i] appended to the
+// list of exceptions (one atomic per wave; exc_count may run past exc_cap: the host then takes the whole array at full width).  The
+// host widens the bytes into the caller's array while the next slice is on the link.  32-bit indices only (positions fit 32 bits).
+constexpr uint32_t NARROW_PER = 16;            // consecutive values per thread: four 16-byte loads, one 16-byte store
+GLOBAL_FN LAUNCH_BOUNDS(256) lcp_narrow_kernel(KCTX const uint32_t* __restrict__ lcp, uint64_t cnt, uint64_t base, uint8_t* __restrict__ out8,
+                                               uint64_t* __restrict__ exc_count, uint64_t exc_cap, uint64_t* __restrict__ exc)
+{
+    // a workgroup reserves room on the list once per round for all its exceptions (inside a satellite array EVERY value is one: an
+    // atomic per thread on the one counter would serialise millions of them)
+    SHARED_ARRAY(uint32_t, bsum, 1);
+    SHARED_ARRAY(uint64_t, bbase, 1);
+    TL_DECL(uint32_t, v, NARROW_PER);
+    TL_DECL(uint32_t, off, 1);
+    const uint64_t per_round = (uint64_t)K_BLOCK_DIM * NARROW_PER, stride = (uint64_t)K_GRID_DIM * per_round;
+    for (uint64_t r0 = (uint64_t)K_BLOCK_IDX * per_round; r0 < cnt; r0 += stride) {               // block-uniform
+        PAR(tid) { if (tid == 0) bsum[0] = 0; }
+        SYNC();
+        PAR(tid) {
+            const uint64_t i0 = r0 + (uint64_t)tid * NARROW_PER;
+            uint32_t big = 0;
+            UNROLL
+            for (uint32_t k = 0; k < NARROW_PER; ++k) {
+                TL(v, tid, k) = i0 + k < cnt ? lcp[i0 + k] : 0u;
+                big += TL(v, tid, k) >= 255u ? 1u : 0u;
+            }
+            TL(off, tid, 0) = big ? FETCH_ADD_U32(&bsum[0], big) : 0u;
+        }
+        SYNC();
+        PAR(tid) { if (tid == 0 && bsum[0]) bbase[0] = FETCH_ADD_U64(exc_count, (uint64_t)bsum[0]); }
+        SYNC();
+        PAR(tid) {
+            const uint64_t i0 = r0 + (uint64_t)tid * NARROW_PER;
+            uint64_t at = bsum[0] ? bbase[0] + TL(off, tid, 0) : 0;
+            UNROLL
+            for (uint32_t k = 0; k < NARROW_PER; ++k) {
+                const uint32_t x = TL(v, tid, k);
+                if (x >= 255u) {
+                    if (at < exc_cap) exc[at] = ((base + i0 + k) << 32) | x;
+                    ++at;
+                }
+                if (i0 + k < cnt) out8[i0 + k] = (uint8_t)(x < 255u ? x : 255u);
+            }
+        }
+        SYNC();
+    }
+}
+
 }  // namespace caps

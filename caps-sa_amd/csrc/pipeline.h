@@ -1210,6 +1210,9 @@ inline uint64_t test_stream_cap(uint64_t cap, uint64_t n_elems, uint64_t n_strea
 // enqueued on the build's stream.
 struct WaveSink {
     virtual void wave_done(Backend& be, uint64_t base, uint64_t cnt) = 0;
+    // the build starts over (a slot overflowed under 32-bit keys, the deferred ties did not fit): what was handed over so far is
+    // void -- the sink finishes reading the arrays the new attempt is about to rewrite and forgets it
+    virtual void reset(Backend& be) = 0;
     virtual ~WaveSink() {}
 };
 
@@ -1772,13 +1775,19 @@ private:
             set_final(ow, dSA + base, dLCP + base);
             if (elems_w) {
                 SortResult<idx_t> r2 = seg_sort<BITS>(gw, n_tiles_w, max_len_w, W > 1 ? wave_scratch_ : pl_.A, pl_.B, elems_w, ow, true);
-                if (r2.failed) return run_direct<BITS>(dSA, dLCP, PG, K1, e1, false, defer);      // a slot overflowed under 32-bit keys: again with 64
+                if (r2.failed) {                                                                // a slot overflowed under 32-bit keys: again with 64
+                    if (sink_) sink_->reset(be_);
+                    return run_direct<BITS>(dSA, dLCP, PG, K1, e1, false, defer);
+                }
                 passes2_ = std::max(passes2_, r2.passes);
                 run_buckets_ += (uint32_t)r2.run_buckets.size();
                 finalize<idx_t, BITS>(be_, pl_.P, n, r2, dSA + base, dLCP + base);
                 // the deferred groups did not fit the work memory (most of the text in large groups of equal keys): the whole
                 // build again, every tie settled by comparison as before
-                if (r2.msd_failed) return run_direct<BITS>(dSA, dLCP, PG, K1, e1, allow_k32, false);
+                if (r2.msd_failed) {
+                    if (sink_) sink_->reset(be_);
+                    return run_direct<BITS>(dSA, dLCP, PG, K1, e1, allow_k32, false);
+                }
                 tie_groups_ += r2.msd_groups;
                 tie_elems_ += r2.msd_elems;
                 tie_levels_ = std::max(tie_levels_, r2.msd_levels);

@@ -90,7 +90,9 @@ typedef struct caps_sa_stats {
      * re-keying them deeper, level by level, afterwards (csrc/kernels.h "Deferred ties": tandem arrays, repeat families), their
      * members, and the deepest level (each 64 / bits_per_char chars). */
     uint64_t tie_groups_deferred, tie_elems_deferred;
-    uint32_t tie_levels, reserved_;
+    uint32_t tie_levels;
+    uint32_t lcp_bytes_on_link;    /* host-buffer entry points: bytes per LCP value on the PCIe link -- 1 when the values left the device as
+                                      bytes (+ a list of the values of 255 and more) and were widened on the host, else the index width */
     /* the three parts of the last stage, summed over their launches (device time, as the kernel clocks above): gathering SA / LCP
      * with the segment-head LCPs (a11), the letter-run buckets (run_buckets), the deferred ties (tie_groups_deferred) */
     double finish_ms, run_bucket_ms, msd_ms;

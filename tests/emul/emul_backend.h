@@ -58,6 +58,10 @@ public:
     static void stream_wait(void*, BackendEvent) {}
     static void d2h_on(void*, void* h, const void* d, size_t bytes) { std::memcpy(h, d, bytes); }
     static void sync_stream(void*) {}
+    static BackendEvent record_on(void*) { return BackendEvent{}; }
+    static void wait_event(BackendEvent) {}
+    static void destroy_event(BackendEvent) {}
+    static void memset_on(void*, void* d, int v, size_t bytes) { std::memset(d, v, bytes); }
     void peer_copy(void* dst, int, const void* src, int, size_t bytes) { std::memmove(dst, src, bytes); }
     static void peer_copy_on(void*, void* dst, int, const void* src, int, size_t bytes) { std::memmove(dst, src, bytes); }
     static void h2d_on(void*, void* d, const void* h, size_t bytes) { std::memcpy(d, h, bytes); }

@@ -522,6 +522,28 @@ def test_equalised_tile_sort_settles_ties_once(oracle):
         assert int((LCP >= 40).sum()) > n // 100 and int(LCP.max()) >= 2999
 
 
+def test_lcp_leaves_as_bytes_through_the_host_path(oracle, monkeypatch):
+    """The host-buffer entry point's LCP-as-bytes transfer (capi_impl.h HostCopySink, lcp_narrow_kernel) in the emulation: no
+    value above 254, some (single-letter runs), more than the list of exceptions holds (full width again)."""
+    from sa_check import sa_lcp
+    rs = np.random.RandomState(5)
+    E = emul()
+    uni = rs.choice(DNA, size=400_000)
+    runs = rs.choice(DNA, size=400_000)
+    runs[100_000:103_000] = ord("G")
+    runs[300_000:300_900] = ord("A")
+    flood = rs.choice(DNA, size=400_000)
+    flood[100_000:130_000] = ord("G")
+    monkeypatch.setenv("CAPS_SA_HOST_NARROW_LCP", "1")
+    for name, T, want in (("uniform", uni, 1), ("runs", runs, 1), ("flood", flood, 4)):
+        SAo, LCPo = sa_lcp(T, 32)
+        for waves in ("1", "3", "5"):
+            monkeypatch.setenv("CAPS_SA_HOST_WAVES", waves)
+            SA, LCP, st = E.build(T, p=100)
+            assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), (name, waves)
+            assert st["lcp_bytes_on_link"] == want, (name, waves, st["lcp_bytes_on_link"])
+
+
 def test_a_lost_tie_note_sends_the_tile_to_the_comparison_sort(oracle, monkeypatch):
     """a tie note that gets lost must not become a wrong LCP.  CAPS_SA_TEST_DROP_NOTE makes tile_sort_eq_kernel lose
     the notes of its tied pairs; its emit phase then meets equal keys without a note and hands the tile to the comparison sort (the

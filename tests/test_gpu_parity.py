@@ -826,6 +826,38 @@ def test_results_leave_in_waves_host_path(L, oracle, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_lcp_leaves_the_device_as_bytes_host_path(L, oracle, monkeypatch):
+    """on the link the LCP array travels as bytes (capi_impl.h HostCopySink, lcp_narrow_kernel) -- values below
+    255 as they are, the others as (position, value) pairs at the end -- and host threads widen them into the caller's array while
+    the next slice is copied.  Forced here at sizes the oracle checks (it is the default from 400 Mi chars on): no exception at all,
+    a few thousand (single-letter runs), more than the list holds (then the whole array at full width), page-locked and pageable
+    result arrays, several worker counts."""
+    from sa_check import sa_lcp
+    rs = np.random.RandomState(91)
+    uni = rs.choice(DNA, size=5_000_001)
+    runs = rs.choice(DNA, size=6_000_000)
+    runs[1_000_000:1_003_000] = ord("G")
+    runs[4_000_000:4_000_900] = ord("A")
+    flood = rs.choice(DNA, size=6_000_000)
+    flood[2_000_000:2_400_000] = ord("G")                  # 400,000 values above 254: the list holds n / 32
+    L.release_cache()
+    monkeypatch.setenv("CAPS_SA_HOST_NARROW_LCP", "1")
+    for name, T, want_bytes in (("uniform", uni, 1), ("runs", runs, 1), ("flood", flood, 4)):
+        SAo, LCPo = oracle.build_sa_lcp(T, p=1000) if name == "uniform" else sa_lcp(T, 32)
+        for waves, pinned, threads in (("3", True, "1"), ("4", False, "3"), ("6", True, "8")):
+            monkeypatch.setenv("CAPS_SA_HOST_WAVES", waves)
+            monkeypatch.setenv("CAPS_SA_HOST_THREADS", threads)
+            SA, LCP, st = L.build(T, p=1000, pinned=pinned)
+            assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), (name, waves)
+            assert st["path_direct"] == 1 and st["result_waves"] >= 2 and st["lcp_bytes_on_link"] == want_bytes, (name, st["lcp_bytes_on_link"])
+    monkeypatch.setenv("CAPS_SA_HOST_NARROW_LCP", "0")
+    SAo, LCPo = sa_lcp(runs, 32)
+    SA, LCP, st = L.build(runs, p=1000)
+    assert st["lcp_bytes_on_link"] == 4 and np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo)
+    L.release_cache()
+
+
+@pytest.mark.gpu
 def test_a_lost_tie_note_sends_the_tile_to_the_comparison_sort_device(oracle, monkeypatch):
     """tile_sort_eq_kernel's plain build reads the lcp of two neighbours with EQUAL keys from the note the tie
     phases left; if a note were ever lost it would emit the capped key length -- a wrong LCP nothing but the verifier would see.
