@@ -858,12 +858,11 @@ def test_lcp_leaves_the_device_as_bytes_host_path(L, oracle, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_a_lost_tie_note_sends_the_tile_to_the_comparison_sort_device(oracle, monkeypatch):
+def test_a_lost_tie_note_sends_the_tile_to_the_comparison_sort_device(L, oracle, monkeypatch):
     """tile_sort_eq_kernel's plain build reads the lcp of two neighbours with EQUAL keys from the note the tie
     phases left; if a note were ever lost it would emit the capped key length -- a wrong LCP nothing but the verifier would see.
     CAPS_SA_TEST_DROP_NOTE makes it lose the notes of all tied pairs: the emit phase must notice (equal keys, no note), queue the
     tile for the comparison sort, and the arrays must still be THE arrays."""
-    L = _gpu_lib()
     rs = np.random.RandomState(77)
     n = 1_500_000
     T = rs.choice(DNA, size=n, p=[0.4, 0.1, 0.15, 0.35])
