@@ -224,7 +224,11 @@ static __device__ __forceinline__ void caps_lds_barrier()
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
+#ifdef CAPS_FULL_BARRIERS      /* measurement / debugging: every barrier is __syncthreads() */
+#define SYNC_LDS() __syncthreads()
+#else
 #define SYNC_LDS() caps_lds_barrier()
+#endif
 #define SHARED_ARRAY(type, name, count) __shared__ type name[count]
 #define TL_DECL(type, name, cnt) type name##_reg_[cnt]
 #define TL(name, tid, k) name##_reg_[k]

@@ -41,7 +41,13 @@ HD uint64_t window64(const uint32_t* __restrict__ P, uint64_t pos)
     const uint64_t w = pos / CPW;
     const uint32_t sh = (uint32_t)(pos % CPW) * BITS;          // 0..31
     const uint64_t x0 = P[w], x1 = P[w + 1], x2 = P[w + 2];
+#if defined(CAPS_W64_FUNNEL)        /* the same value from 32-bit funnel shifts: with it tools/level_a_repro.hip is exact at -O1 too */
+    const uint32_t a = (uint32_t)x0, b = (uint32_t)x1, c = (uint32_t)x2;
+    const uint32_t hi = sh ? (a << sh) | (b >> (32u - sh)) : a, lo = sh ? (b << sh) | (c >> (32u - sh)) : b;
+    return ((uint64_t)hi << 32) | lo;
+#else
     return (((x0 << 32) | x1) << sh) | ((x2 << sh) >> 32);
+#endif
 }
 
 // ---------------------------------------------------------------------------------
