@@ -385,6 +385,8 @@ public:
     // d_send_keys: u64[send_capacity], d_send_sa: idx[send_capacity]; d_report: u64[n_streams + 2] (stream_report_kernel)
     void scatter(void* d_send_keys, void* d_send_sa, void* d_report) override
     {
+        last_send_keys_ = d_send_keys;
+        last_send_sa_ = d_send_sa;
         if (direct_fb_ != CAPS_SA_FB_NONE) throw std::invalid_argument("this shard's shape does not allow the direct path");
         slot_stats_[0] = slot_stats_[1] = 0;
         level_a_ran_ = false;
@@ -493,7 +495,11 @@ public:
             // scattered itself (no exchange) under 64-bit keys.  Groups that do not fit the work memory, or need more levels than
             // msd_refine allows: level A again -- the sort has used its buffers -- and the sort with every tie compared
             bool retry = false;
-            const bool defer = local_ && key_bits_ == 64 && !std::getenv("CAPS_SA_NO_DEFER");
+            // ties are deferred only when the streams sorted here are the ones THIS shard scattered last (d_recv_* = the send buffers of
+            // scatter()): a failed refinement is repaired by scattering into them again -- buffers of the caller's own are inputs, never
+            // rewritten, and their ties are compared
+            const bool own_streams = d_recv_keys == last_send_keys_ && d_recv_sa == last_send_sa_;
+            const bool defer = local_ && own_streams && key_bits_ == 64 && !std::getenv("CAPS_SA_NO_DEFER");
             bool ok = bits_ == 2 ? sort_owned_bits<2>(d_recv_keys, d_recv_sa, dSA, dLCP, defer, &retry)
                                  : sort_owned_bits<8>(d_recv_keys, d_recv_sa, dSA, dLCP, defer, &retry);
             if (ok && retry) {
@@ -586,6 +592,8 @@ private:
     uint32_t PG_ = 0, K1_ = 0, SUB_ = 1, n_streams_ = 0, my_tiles_ = 0, own_lo_ = 0, own_hi_ = 0;
     uint64_t capA_ = 0, my_elems_ = 0;
     uint32_t key_bits_ = 64;             // width of the keys the last scatter() wrote (32: text.h key32_of)
+    const void* last_send_keys_ = nullptr;      // the buffers scatter() filled last (sort_owned may scatter into them again)
+    const void* last_send_sa_ = nullptr;
     bool force64_ = false;               // set_key_bits(64): after a slot overflow under 32-bit keys
     uint8_t* gshift_ = nullptr;
     uint64_t *gkey_ = nullptr, *dstat_ = nullptr;

@@ -321,24 +321,45 @@ def bench_main(args, rank: int, local_rank: int, world: int):
             # the ranks agree on the failure (errors of this kind -- out of memory, a refused message size -- hit every rank alike)
             # and the mode is left out.  The default mode failing is an error as before.
             s_ = b_ = None
+
+            def agree(e):
+                """Did the step fail on ANY rank?  Called by every rank at the same point, before the next collective."""
+                f = torch.tensor([1.0 if e is not None else 0.0], dtype=torch.float64, device=dev)
+                dist.all_reduce(f, op=dist.ReduceOp.MAX)
+                return float(f.item()) != 0.0
+
+            # (1) allocations: no collective inside, so a rank that fails here (out of memory) still meets the others in agree()
             err = None
             try:
                 s_, b_ = make_shard(m)
-                build_sharded(L, T, args.p, idx_bits, stream, shard=s_, bufs=b_)        # first build: allocations, RCCL connections
-                dist.barrier()
-                torch.cuda.synchronize()
-                t_ = time.perf_counter()
-                build_sharded(L, T, args.p, idx_bits, stream, shard=s_, bufs=b_)
-                dist.barrier()
-                torch.cuda.synchronize()
-                took = time.perf_counter() - t_
             except Exception as e:          # noqa: BLE001
-                if m == "local":
-                    raise
-                err, took = e, 0.0
-            el_ = torch.tensor([took, 1.0 if err is not None else 0.0], dtype=torch.float64, device=dev)
+                err = e
+            failed = agree(err)
+            took = 0.0
+            if not failed:
+                # (2) the builds hold collectives: a rank that raises INSIDE one has left its peers waiting in it -- no agreement is
+                # possible any more, and going on to the next collective would hang until the RCCL time-out (ADVICE r4): fatal
+                try:
+                    build_sharded(L, T, args.p, idx_bits, stream, shard=s_, bufs=b_)    # first build: allocations, RCCL connections
+                    dist.barrier()
+                    torch.cuda.synchronize()
+                    t_ = time.perf_counter()
+                    build_sharded(L, T, args.p, idx_bits, stream, shard=s_, bufs=b_)
+                    dist.barrier()
+                    torch.cuda.synchronize()
+                    took = time.perf_counter() - t_
+                except Exception as e:      # noqa: BLE001
+                    import sys
+                    import traceback
+                    traceback.print_exc()
+                    print(f"rank {rank}: the calibration build of shard mode '{m}' failed inside a collective sequence: {e!r}", file=sys.stderr, flush=True)
+                    os._exit(3)
+            if failed and m == "local":
+                raise SystemExit(f"rank {rank}: the default shard mode could not be set up: {err!r}" if err is not None
+                                 else f"rank {rank}: the default shard mode could not be set up on another rank")
+            el_ = torch.tensor([took], dtype=torch.float64, device=dev)
             dist.all_reduce(el_, op=dist.ReduceOp.MAX)
-            if float(el_[1].item()) != 0.0:
+            if failed:
                 calib_errors[m] = repr(err) if err is not None else "failed on another rank"
             else:
                 calib[m] = 1e3 * float(el_[0].item())

@@ -83,7 +83,9 @@ typedef struct caps_sa_stats {
                                       being sorted (1: one copy after the build) */
     uint32_t n_devices;            /* caps_sa_hip_build_multi_*: devices that built (1 elsewhere) */
     /* caps_sa_hip_build_multi_*: host wall clock of the three stages, the slowest and the fastest device of each (ms) */
-    double ms_upload_max, ms_upload_min;       /* text to the device (page-locked staging, all devices at once) */
+    double ms_upload_max, ms_upload_min;       /* text to the device: ONE chunked upload to the first device, fanned out to the others
+                                                  over xGMI chunk by chunk; a device's figure ends when its last chunk has arrived, so
+                                                  it includes the wait for the devices served before it */
     double ms_device_build_max, ms_device_build_min;   /* level A .. boundary LCPs of the device's slice */
     double ms_download_max, ms_download_min;   /* the device's slice of SA / LCP to the caller's arrays */
     /* Groups of suffixes with one and the same key (64 / bits_per_char chars) that the sort did not settle by comparison but by
@@ -333,7 +335,9 @@ int caps_sa_hip_shard_phase2(caps_sa_shard* s, const void* d_recv_keys, const vo
  * d_report: u64[n_streams + 2], this rank's stream sizes and flags.  shard_plan: all_reports = HOST u64[world][n_streams + 2];
  * returns 0, or a positive CAPS_SA_FB_* code -- the same on every rank -- when the text cannot be split by keys alone: the
  * ranks then run the samplesort sequence above (shard_phase1 ...).  shard_sort: dSA / dLCP: idx[capacity] out, recv_total
- * entries valid.
+ * entries valid.  When d_recv_* ARE the send buffers of the last shard_scatter (exchange = 0), shard_sort may rewrite them: large
+ * groups of equal keys are then re-keyed instead of compared, and if that refinement does not fit its work memory the shard
+ * scatters into the same buffers once more and sorts with every tie compared.  Buffers of the caller's own are read only.
  */
 int caps_sa_hip_shard_scatter(caps_sa_shard* s, void* d_send_keys, void* d_send_sa, void* d_report);
 int caps_sa_hip_shard_plan(caps_sa_shard* s, const uint64_t* all_reports, uint64_t* send_counts, uint64_t* recv_counts);
