@@ -101,6 +101,7 @@ template <typename T> static inline T caps_emul_load(const T* p) { CAPS_RACE_ATO
 template <typename T> static inline void caps_emul_store(T* p, T v) { CAPS_RACE_ATOMIC; *p = v; }
 #define RACY_LOAD_U32(ptr) caps_emul_load<uint32_t>((ptr))
 #define RACY_STORE_U32(ptr, v) caps_emul_store<uint32_t>((ptr), (v))
+#define RACY_STORE_U16(ptr, v) caps_emul_store<uint16_t>((ptr), (v))
 #define ATOMIC_OR_U32(ptr, v) caps_emul_or<uint32_t>((ptr), (v))
 #define ATOMIC_MIN_U32(ptr, v) caps_emul_min<uint32_t>((ptr), (v))
 #define ATOMIC_MAX_U32(ptr, v) caps_emul_max<uint32_t>((ptr), (v))
@@ -235,6 +236,7 @@ static __device__ __forceinline__ void caps_lds_barrier()
 #define UNROLL _Pragma("unroll")
 #define RACY_LOAD_U32(ptr) (*(ptr))                 /* see the emulation side: racing with atomics by design */
 #define RACY_STORE_U32(ptr, v) (*(ptr) = (v))
+#define RACY_STORE_U16(ptr, v) (*(ptr) = (v))
 #define ATOMIC_OR_U32(ptr, v) atomicOr((ptr), (v))
 #define ATOMIC_MIN_U32(ptr, v) atomicMin((ptr), (v))
 #define ATOMIC_MAX_U32(ptr, v) atomicMax((ptr), (v))

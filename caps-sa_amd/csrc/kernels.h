@@ -999,6 +999,9 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
     // this kernel's LDS cycles were bank conflicts).  64-bit indices: no room in LDS (two workgroups per CU) for sbin.
     constexpr bool SLOT_ORDER = sizeof(idx_t) == 4;
     SHARED_ARRAY(uint16_t, sbin, SLOT_ORDER ? TILE_E : 1);
+    // ... and no second placement (as in tile_sort_eq_kernel): the element that knows its final position d notes perm[d] = its slot,
+    // the emit phase reads keys and indices through perm -- one barrier, two LDS writes and a read per element less
+    SHARED_ARRAY(uint16_t, perm, SLOT_ORDER ? TILE_E : 1);
     TL_DECL(KT, rk, TILE_EPT);
     TL_DECL(idx_t, rs, TILE_EPT);
     TL_DECL(uint32_t, rd, TILE_EPT);
@@ -1056,27 +1059,29 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
                 if (e < cnt) {
                     const uint32_t slot = SLOT_ORDER ? e : TL(rd, tid, k), bin = SLOT_ORDER ? (uint32_t)sbin[slot] : TL(rb, tid, k);
                     const uint32_t bs = hist[bin], be = hist[bin + 1];
-                    if (SLOT_ORDER) { TL(rk, tid, k) = skey[slot]; TL(rs, tid, k) = ssa[slot]; }    // mine from here on
-                    const uint64_t key = TL(rk, tid, k);
-                    const uint64_t sa = (uint64_t)TL(rs, tid, k);
+                    const uint64_t key = SLOT_ORDER ? (uint64_t)skey[slot] : (uint64_t)TL(rk, tid, k);
                     uint32_t less = 0;                        // members of my bin that sort before me
                     for (uint32_t j = bs; j < be; ++j) {
                         const uint64_t kj = skey[j];
                         less += kj < key ? 1u : 0u;
                         if (kj == key && j != slot) {                                                               // rare: text
+                            const uint64_t sa = SLOT_ORDER ? (uint64_t)ssa[slot] : (uint64_t)TL(rs, tid, k);
                             const uint32_t c = suffix_less_tie_bounded<BITS>(P, n, (uint64_t)ssa[j], sa, tie_from);
                             if (c == 2u) flag[0] = 1;                                                               // a deep tie: not here
                             less += c & 1u;
                         }
                     }
-                    TL(rd, tid, k) = bs + less;
+                    // (bs + less < be <= cnt whatever the ties did; RACY_STORE: two members of a tie too deep for this kernel get one
+                    // rank and one cell -- the tile has raised its flag by then and nothing reads perm)
+                    if (SLOT_ORDER) RACY_STORE_U16(&perm[bs + less], (uint16_t)slot);
+                    else TL(rd, tid, k) = bs + less;
                 }
             }
         }
         SYNC();
         fast = flag[0] == 0;
         PHASE_MARK(4);                                         // rank inside the bin
-        if (fast) {
+        if (fast && !SLOT_ORDER) {
             TILE_SORT_PLACE_FINAL
             PHASE_MARK(5);                                     // place final
         }
@@ -1089,7 +1094,34 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
         PAR(tid) { if (tid == 0) redo[1 + FETCH_ADD_U32(&redo[0], 1u)] = b; }
         return;
     }
-    TILE_SORT_EMIT
+    if (SLOT_ORDER && cnt > 1) {
+        // sorted order -> HBM through perm (+ LCPs from neighbouring keys, + boundary records)
+        PAR(tid) {
+            UNROLL
+            for (uint32_t k = 0; k < TILE_EPT; ++k) {
+                const uint32_t e = tid + k * TILE_NT;
+                if (e < cnt) {
+                    const uint32_t sl = perm[e];
+                    const KT key = skey[sl];
+                    const idx_t sa = ssa[sl];
+                    uint64_t l = 0;
+                    if (with_lcp && e) { const uint32_t sp = perm[e - 1]; l = TILE_EMIT_LCP_(skey[sp], ssa[sp], key, sa); }
+                    if (direct) {
+                        fin.sa[start + e] = sa;
+                        fin.lcp[start + e] = (idx_t)l;
+                        if (e == 0) { fin.first_key[g] = key; fin.first_sa[g] = sa; }
+                        if (e == cnt - 1) { fin.last_key[g] = key; fin.last_sa[g] = sa; }
+                    } else {
+                        out_key[start + e] = key;
+                        out_sa[start + e] = sa;
+                        if (with_lcp) out_lcp[start + e] = (idx_t)l;
+                    }
+                }
+            }
+        }
+    } else {
+        TILE_SORT_EMIT
+    }
     PHASE_MARK(6);                                             // emit (+ LCPs); the stores themselves drain after the mark
 }
 
