@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cstring>
 #include <exception>
+#include <functional>
 #include <limits>
 #include <memory>
 #include <condition_variable>
@@ -195,8 +196,15 @@ template <typename idx_t> struct HostCopySink : WaveSink {
     uint64_t* dexc = nullptr;          // device: exceptions, (position << 32 | value)
     uint64_t* dexc_count = nullptr;
     uint64_t exc_cap = 0;
-    uint8_t* h8 = nullptr;             // host, page-locked: the bytes
-    uint64_t* hexc = nullptr;          // host, page-locked: the exceptions (hexc[exc_cap] receives the count)
+    // host, page-locked: the bytes land in CHUNKS of chunk_bytes (chunk c = positions [c * chunk_bytes, ...)), allocated one after
+    // the other by a thread of their own while the text is uploaded and the first slices are sorted: page-locking memory costs ~4 ms
+    // per 64 MB -- 240 ms for a C3-sized array, which a first call would otherwise pay up front -- and a slice only needs the chunks
+    // under it (chunk_ready blocks until chunk c exists).  Kept between calls with the device block.
+    std::vector<char*>* chunks = nullptr;
+    uint64_t chunk_bytes = 0;
+    std::function<void(uint64_t)> chunk_ready;
+    std::vector<uint64_t> hexc_store;  // host: the exceptions (pageable: a few MB at the end)
+    uint64_t* hexc = nullptr;
     uint32_t workers = 1;
     struct Task { BackendEvent ev; uint64_t base, cnt; };
     std::mutex mu;
@@ -207,24 +215,36 @@ template <typename idx_t> struct HostCopySink : WaveSink {
     std::exception_ptr failure;
 
     bool narrow() const { return d8 != nullptr; }
+    // f(chunk pointer + offset, position, length) for the pieces of [base, base + cnt) chunk by chunk
+    template <typename F> void for_pieces(uint64_t base, uint64_t cnt, F&& f)
+    {
+        for (uint64_t pos = base; pos < base + cnt;) {
+            const uint64_t c = pos / chunk_bytes, off = pos - c * chunk_bytes;
+            const uint64_t len = std::min<uint64_t>(chunk_bytes - off, base + cnt - pos);
+            f(c, off, pos, len);
+            pos += len;
+        }
+    }
     void widen_slice(uint64_t base, uint64_t cnt)
     {
         if (sizeof(idx_t) != 4) return;
-        uint32_t* out = reinterpret_cast<uint32_t*>(LCP) + base;
-        const uint8_t* in = h8 + base;
+        for_pieces(base, cnt, [this](uint64_t c, uint64_t off, uint64_t pos, uint64_t len) {
+            uint32_t* out = reinterpret_cast<uint32_t*>(LCP) + pos;
+            const uint8_t* in = reinterpret_cast<const uint8_t*>((*chunks)[c]) + off;
 #ifdef CAPS_EMUL
-        widen_bytes(in, out, cnt);
+            widen_bytes(in, out, len);
 #else
-        const uint32_t K = (uint32_t)std::min<uint64_t>(workers, std::max<uint64_t>(1, cnt >> 20));
-        if (K <= 1) { widen_bytes(in, out, cnt); return; }
-        std::vector<std::thread> th;
-        const uint64_t per = ((cnt + K - 1) / K + 63) & ~uint64_t(63);
-        for (uint32_t k = 0; k < K; ++k) {
-            const uint64_t a = std::min<uint64_t>(cnt, (uint64_t)k * per), b = std::min<uint64_t>(cnt, a + per);
-            if (a < b) th.emplace_back([=] { widen_bytes(in + a, out + a, b - a); });
-        }
-        for (auto& t : th) t.join();
+            const uint32_t K = (uint32_t)std::min<uint64_t>(workers, std::max<uint64_t>(1, len >> 20));
+            if (K <= 1) { widen_bytes(in, out, len); return; }
+            std::vector<std::thread> th;
+            const uint64_t per = ((len + K - 1) / K + 63) & ~uint64_t(63);
+            for (uint32_t k = 0; k < K; ++k) {
+                const uint64_t a = std::min<uint64_t>(len, (uint64_t)k * per), b = std::min<uint64_t>(len, a + per);
+                if (a < b) th.emplace_back([=] { widen_bytes(in + a, out + a, b - a); });
+            }
+            for (auto& t : th) t.join();
 #endif
+        });
     }
     void start()
     {
@@ -279,7 +299,10 @@ template <typename idx_t> struct HostCopySink : WaveSink {
             const uint64_t rounds = (cnt + 256ull * NARROW_PER - 1) / (256ull * NARROW_PER);
             CAPS_LAUNCH(lcp_narrow_kernel, capped_grid(std::min<uint64_t>(rounds, 4096), 256), 256, cb,
                         reinterpret_cast<const uint32_t*>(dLCP) + base, cnt, base, d8 + base, dexc_count, exc_cap, dexc);
-            Backend::d2h_on(copy_stream, h8 + base, d8 + base, cnt);
+            for_pieces(base, cnt, [this](uint64_t c, uint64_t off, uint64_t pos, uint64_t len) {
+                chunk_ready(c);
+                Backend::d2h_on(copy_stream, (*chunks)[c] + off, d8 + pos, len);
+            });
             const BackendEvent ev = Backend::record_on(copy_stream);
             Backend::d2h_on(copy_stream, SA + base, dSA + base, cnt * sizeof(idx_t));
 #ifdef CAPS_EMUL
@@ -306,13 +329,15 @@ template <typename idx_t> struct HostCopySink : WaveSink {
     bool finish_lcp(uint64_t n)
     {
         if (!narrow()) { Backend::sync_stream(copy_stream); return true; }        // (the last copies have landed)
-        Backend::d2h_on(copy_stream, hexc + exc_cap, dexc_count, sizeof(uint64_t));
+        uint64_t ne = 0;
+        Backend::d2h_on(copy_stream, &ne, dexc_count, sizeof(uint64_t));
         Backend::sync_stream(copy_stream);
         drain();
         if (failure) std::rethrow_exception(failure);
-        const uint64_t ne = hexc[exc_cap];
         if (ne > exc_cap) return false;
         if (ne) {
+            hexc_store.resize(ne);
+            hexc = hexc_store.data();
             Backend::d2h_on(copy_stream, hexc, dexc, ne * sizeof(uint64_t));
             Backend::sync_stream(copy_stream);
             auto patch = [this, n](uint64_t a, uint64_t b) {
@@ -350,8 +375,9 @@ struct HostPathCache {
     int device = -1;
     char* base = nullptr;
     size_t bytes = 0;
-    char* host = nullptr;              // page-locked staging of the LCP bytes and their exceptions (HostCopySink)
-    size_t host_bytes = 0;
+    std::vector<char*> host_chunks;    // page-locked staging of the LCP bytes (HostCopySink), host_chunk_bytes each
+    size_t host_chunk_bytes = 0;
+    uint64_t calls = 0;                // host-buffer builds of this process so far
 };
 inline HostPathCache& host_cache()
 {
@@ -365,9 +391,9 @@ inline void release_host_cache_locked(HostPathCache& c)
         Backend be(nullptr);
         be.free(c.base);
     }
-    if (c.host) Backend::host_free(c.host);
-    c.host = nullptr;
-    c.host_bytes = 0;
+    for (char* q : c.host_chunks) Backend::host_free(q);
+    c.host_chunks.clear();
+    c.host_chunk_bytes = 0;
     c.base = nullptr;
     c.bytes = 0;
     c.device = -1;
@@ -397,6 +423,7 @@ int build_host(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context, 
                 if (!seen[(uint8_t)T[i]]) { seen[(uint8_t)T[i]] = true; ++sigma; }
             if (sigma <= 4 && !std::getenv("CAPS_SA_FULL_ALPHABET")) text_bits = 2;
         }
+        const uint64_t earlier_calls = hc.calls++;
         for (;; text_bits = 8) {
         const Plan<idx_t> need = make_plan<idx_t>(n, p_arg, nullptr, text_bits);
         const size_t off_sa = up(n ? n : 1), off_lcp = off_sa + up((n ? n : 1) * sizeof(idx_t));
@@ -405,20 +432,23 @@ int build_host(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context, 
         // waves cost 14 ms (per-wave host synchronisations, 24 copies instead of 2), at C3 (3e9) they save 31 of 524 ms
         uint32_t waves = n >= (400ull << 20) ? CAPS_HOST_WAVES : 1u;
         if (const char* e = std::getenv("CAPS_SA_HOST_WAVES")) waves = (uint32_t)std::max(1, std::atoi(e));
-        // LCP as bytes: with waves (the builds long enough for the link to matter), 32-bit indices; CAPS_SA_HOST_NARROW_LCP=0 / 1
-        bool narrow = sizeof(idx_t) == 4 && waves > 1;
+        // LCP as bytes: with waves (the builds long enough for the link to matter), 32-bit indices -- and from the SECOND host build of
+        // a process on: the page-locked staging costs ~240 ms to allocate at C3 (measured: not hidden by allocating it on a thread
+        // beside the upload -- the runtime serialises the two), which a process that builds once (the CLI) would pay for a saving
+        // of 150 ms; one that builds again and again pays it once.  CAPS_SA_HOST_NARROW_LCP=0 / 1: never / from the first build.
+        bool narrow = sizeof(idx_t) == 4 && waves > 1 && earlier_calls > 0;
         if (const char* e = std::getenv("CAPS_SA_HOST_NARROW_LCP")) narrow = sizeof(idx_t) == 4 && std::atoi(e) != 0;
         const uint64_t exc_cap = narrow ? std::max<uint64_t>(1024, n / 32) : 0;
         const size_t narrow_dev = narrow ? up(n) + up((exc_cap + 1) * sizeof(uint64_t)) + 512 : 0;
         const size_t ws_room = need.bytes + 1024 + wave_scratch_bytes<idx_t>(wave_scratch_elems(n, waves));
         const size_t total = off_ws + ws_room + narrow_dev;
         if (hc.device != device || hc.bytes < total) {
-            const size_t keep_host = hc.host_bytes;
-            char* keep = hc.host;
-            hc.host = nullptr;                               // (the staging arrays survive a larger device block)
+            std::vector<char*> keep;
+            keep.swap(hc.host_chunks);                       // (the staging chunks survive a larger device block)
+            const size_t keep_bytes = hc.host_chunk_bytes;
             release_host_cache_locked(hc);
-            hc.host = keep;
-            hc.host_bytes = keep_host;
+            hc.host_chunks.swap(keep);
+            hc.host_chunk_bytes = keep_bytes;
             const auto a0 = std::chrono::steady_clock::now();
             hc.base = static_cast<char*>(be.alloc(total));
             hc.bytes = total;
@@ -427,18 +457,44 @@ int build_host(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context, 
                 std::fprintf(stderr, "[alloc] device block of %zu bytes: %.1f ms\n", total,
                              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a0).count());
         }
-        const size_t host_need = narrow ? up(n) + up((exc_cap + 1) * sizeof(uint64_t)) : 0;
-        if (narrow && hc.host_bytes < host_need) {
-            if (hc.host) Backend::host_free(hc.host);
-            hc.host = nullptr;
-            hc.host_bytes = 0;
-            const auto a0 = std::chrono::steady_clock::now();
-            hc.host = static_cast<char*>(Backend::host_alloc(host_need));
-            hc.host_bytes = host_need;
-            if (std::getenv("CAPS_SA_DEBUG_ALLOC"))
-                std::fprintf(stderr, "[alloc] page-locked staging of %zu bytes: %.1f ms\n", host_need,
-                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a0).count());
+        // the page-locked chunks for the LCP bytes, allocated beside the upload (HostCopySink::chunks)
+        constexpr uint32_t N_CHUNKS = 16;
+        const uint64_t chunk_bytes = narrow ? up((n + N_CHUNKS - 1) / N_CHUNKS) : 0;
+        const size_t chunks_need = narrow ? (size_t)((n + chunk_bytes - 1) / chunk_bytes) : 0;
+        std::thread ring_alloc;
+        std::exception_ptr ring_error;
+        std::mutex chunk_mu;
+        std::condition_variable chunk_cv;
+        size_t chunks_done = hc.host_chunks.size();
+        if (narrow && (hc.host_chunk_bytes != chunk_bytes || hc.host_chunks.size() < chunks_need)) {
+            for (char* q : hc.host_chunks) Backend::host_free(q);
+            hc.host_chunks.assign(chunks_need, nullptr);
+            hc.host_chunk_bytes = chunk_bytes;
+            chunks_done = 0;
+            auto alloc = [&, chunks_need, chunk_bytes, device]() {
+                try {
+                    const auto a0 = std::chrono::steady_clock::now();
+                    if (set_device(device) != CAPS_SA_OK) throw HipError("hipSetDevice failed");
+                    for (size_t c = 0; c < chunks_need; ++c) {
+                        char* q = static_cast<char*>(Backend::host_alloc(chunk_bytes));
+                        { std::lock_guard<std::mutex> lk(chunk_mu); hc.host_chunks[c] = q; chunks_done = c + 1; }
+                        chunk_cv.notify_all();
+                    }
+                    if (std::getenv("CAPS_SA_DEBUG_ALLOC"))
+                        std::fprintf(stderr, "[alloc] %zu page-locked chunks of %llu bytes: %.1f ms (beside the upload and the first slices)\n", chunks_need,
+                                     (unsigned long long)chunk_bytes, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a0).count());
+                } catch (...) {
+                    { std::lock_guard<std::mutex> lk(chunk_mu); ring_error = std::current_exception(); }
+                    chunk_cv.notify_all();
+                }
+            };
+#ifdef CAPS_EMUL
+            alloc();
+#else
+            ring_alloc = std::thread(alloc);
+#endif
         }
+        struct JoinGuard { std::thread& t; ~JoinGuard() { if (t.joinable()) t.join(); } } ring_join{ring_alloc};
         char* base = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(hc.base) + 255) & ~uintptr_t(255));
         uint8_t* dT = reinterpret_cast<uint8_t*>(base);
         idx_t* dSA = reinterpret_cast<idx_t*>(base + off_sa);
@@ -468,8 +524,13 @@ int build_host(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context, 
             sink.dexc = reinterpret_cast<uint64_t*>(nb + up(n));
             sink.dexc_count = sink.dexc + exc_cap;
             sink.exc_cap = exc_cap;
-            sink.h8 = reinterpret_cast<uint8_t*>(hc.host);
-            sink.hexc = reinterpret_cast<uint64_t*>(hc.host + up(n));
+            sink.chunks = &hc.host_chunks;
+            sink.chunk_bytes = chunk_bytes;
+            sink.chunk_ready = [&](uint64_t c) {
+                std::unique_lock<std::mutex> lk(chunk_mu);
+                chunk_cv.wait(lk, [&] { return chunks_done > c || ring_error; });
+                if (ring_error) std::rethrow_exception(ring_error);
+            };
             sink.workers = host_worker_threads();
             be.memset(sink.dexc_count, 0, sizeof(uint64_t));
             be.sync();
