@@ -438,8 +438,11 @@ int build_host(const char* T, uint64_t n, uint64_t p_arg, uint64_t max_context, 
         // of 150 ms; one that builds again and again pays it once.  CAPS_SA_HOST_NARROW_LCP=0 / 1: never / from the first build.
         bool narrow = sizeof(idx_t) == 4 && waves > 1 && earlier_calls > 0;
         if (const char* e = std::getenv("CAPS_SA_HOST_NARROW_LCP")) narrow = sizeof(idx_t) == 4 && std::atoi(e) != 0;
-        const uint64_t exc_cap = narrow ? std::max<uint64_t>(1024, n / 32) : 0;
-        const size_t narrow_dev = narrow ? up(n) + up((exc_cap + 1) * sizeof(uint64_t)) + 512 : 0;
+        // (the device block has room for the bytes from the first build on: growing it by a second build would free and re-allocate
+        // ~130 GB, which takes seconds)
+        const bool narrow_later = sizeof(idx_t) == 4 && waves > 1 && !(std::getenv("CAPS_SA_HOST_NARROW_LCP") && !narrow);
+        const uint64_t exc_cap = narrow || narrow_later ? std::max<uint64_t>(1024, n / 32) : 0;
+        const size_t narrow_dev = narrow || narrow_later ? up(n) + up((exc_cap + 1) * sizeof(uint64_t)) + 512 : 0;
         const size_t ws_room = need.bytes + 1024 + wave_scratch_bytes<idx_t>(wave_scratch_elems(n, waves));
         const size_t total = off_ws + ws_room + narrow_dev;
         if (hc.device != device || hc.bytes < total) {

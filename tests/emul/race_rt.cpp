@@ -213,6 +213,27 @@ void __tsan_unaligned_write8(void* p) { caps_race::on_write((uintptr_t)p, 8); }
 void __tsan_unaligned_write16(void* p) { caps_race::on_write((uintptr_t)p, 16); }
 void __tsan_read_range(void* p, unsigned long n) { for (unsigned long i = 0; i < n; ++i) caps_race::on_read((uintptr_t)p + i, 1); }
 void __tsan_write_range(void* p, unsigned long n) { for (unsigned long i = 0; i < n; ++i) caps_race::on_write((uintptr_t)p + i, 1); }
+// atomics of the instrumented code itself (function-local static guards, std::atomic in host-side helpers): plain builtins -- they
+// never touch LDS arrays
+#define CAPS_TSAN_ATOMICS(BITS, T)                                                                                              \
+    T __tsan_atomic##BITS##_load(const volatile T* a, int) { return __atomic_load_n(a, __ATOMIC_SEQ_CST); }                    \
+    void __tsan_atomic##BITS##_store(volatile T* a, T v, int) { __atomic_store_n(a, v, __ATOMIC_SEQ_CST); }                    \
+    T __tsan_atomic##BITS##_exchange(volatile T* a, T v, int) { return __atomic_exchange_n(a, v, __ATOMIC_SEQ_CST); }          \
+    T __tsan_atomic##BITS##_fetch_add(volatile T* a, T v, int) { return __atomic_fetch_add(a, v, __ATOMIC_SEQ_CST); }          \
+    T __tsan_atomic##BITS##_fetch_sub(volatile T* a, T v, int) { return __atomic_fetch_sub(a, v, __ATOMIC_SEQ_CST); }          \
+    T __tsan_atomic##BITS##_fetch_and(volatile T* a, T v, int) { return __atomic_fetch_and(a, v, __ATOMIC_SEQ_CST); }          \
+    T __tsan_atomic##BITS##_fetch_or(volatile T* a, T v, int) { return __atomic_fetch_or(a, v, __ATOMIC_SEQ_CST); }            \
+    T __tsan_atomic##BITS##_fetch_xor(volatile T* a, T v, int) { return __atomic_fetch_xor(a, v, __ATOMIC_SEQ_CST); }          \
+    int __tsan_atomic##BITS##_compare_exchange_strong(volatile T* a, T* c, T v, int, int)                                        \
+    { return __atomic_compare_exchange_n(a, c, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST); }                                 \
+    int __tsan_atomic##BITS##_compare_exchange_weak(volatile T* a, T* c, T v, int, int)                                          \
+    { return __atomic_compare_exchange_n(a, c, v, true, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST); }
+CAPS_TSAN_ATOMICS(8, unsigned char)
+CAPS_TSAN_ATOMICS(16, unsigned short)
+CAPS_TSAN_ATOMICS(32, unsigned int)
+CAPS_TSAN_ATOMICS(64, unsigned long long)
+void __tsan_atomic_thread_fence(int) { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+void __tsan_atomic_signal_fence(int) { __atomic_signal_fence(__ATOMIC_SEQ_CST); }
 // read by the tests
 unsigned long long caps_sa_emul_races_found(void) { return caps_race::races_found(); }
 void caps_sa_emul_races_reset(void) { caps_race::reset_count(); }

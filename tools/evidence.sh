@@ -16,7 +16,7 @@ cd "$GRAFT_REPO_ROOT" 2>/dev/null || cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 O=gpurun_out
 mkdir -p $O
-T=${TAG:-r05_a}
+T=${TAG:-r05}
 cmd=$1; shift
 summ() { python3 - "$@" <<'PY'
 import json,sys
