@@ -422,6 +422,8 @@ def main():
                    "construction": "direct (pivots from the text, one scatter into groups, per-group sort)" if direct
                                    else f"samplesort (fallback reason {last['path_fallback']})",
                    "groups": last["direct_groups"], "slot_splits": [last["slot_splits"], last["slot_splits_redone"]],
+                   "knot_slot_splits": {"kept": last["knot_slot_splits"], "redone_with_count_pass": last["knot_slot_splits_redone"],
+                                        "elements_on_the_spill_stream": last["spill_entries"]},
                    "merge_passes": [last["merge_passes_phase1"], last["merge_passes_phase2"]],
                    "max_partition": last["max_partition"], "workspace": "preallocated",
                    "workspace_gb": ws_bytes / 1e9, "parallelism": "1 GPU"},

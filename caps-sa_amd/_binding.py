@@ -75,6 +75,9 @@ class Stats(ctypes.Structure):
         ("finish_ms", ctypes.c_double),
         ("run_bucket_ms", ctypes.c_double),
         ("msd_ms", ctypes.c_double),
+        ("knot_slot_splits", ctypes.c_uint32),
+        ("knot_slot_splits_redone", ctypes.c_uint32),
+        ("spill_entries", ctypes.c_uint64),
     ]
 
     def as_dict(self) -> dict:

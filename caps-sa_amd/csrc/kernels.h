@@ -845,6 +845,12 @@ __device__ unsigned int caps_eq_check[64];
 #endif
 #define EQ_CHK(ok, id) ((void)EQ_OK((ok), (id)))
 
+// Where a tile of a sort over slots reads its keys: the slot array, or -- a bucket that outgrew its slot (speculative split by
+// knots: spill_gather_kernel / spill_place_kernel have put it together there) -- its place in the output array, sorted in place.
+// (32-bit keys live in slots only: such a sort gives up when a slot overflows.)
+DEV_INLINE const uint64_t* tile_src(const uint64_t* in, const uint64_t* out, bool from_out) { return from_out ? out : in; }
+DEV_INLINE const uint32_t* tile_src(const uint32_t* in, const uint64_t*, bool) { return in; }
+
 // Shared pieces of the two tile sort kernels (macros: they use the kernels' TL registers).
 #define TILE_SORT_PROLOGUE                                                                                      \
     const uint32_t b = K_BLOCK_IDX;                                                                             \
@@ -859,9 +865,17 @@ __device__ unsigned int caps_eq_check[64];
     /* fin.sa != null: a segment completed here goes straight to the caller's SA / LCP arrays                */ \
     /* (its head LCP is filled in by head_lcp_kernel from the boundary records).                             */ \
     const bool direct = with_lcp && fin.sa != nullptr;                                                          \
-    /* slot_cap != 0: the input of segment (bucket) g sits in its fixed-capacity slot, see bucket_scatter_kernel */ \
+    /* slot_cap != 0: the input of segment (bucket) g sits in its fixed-capacity slot, see bucket_scatter_kernel.  */ \
+    /* (A bucket that outgrew its slot -- speculative split by knots -- was put together at its place in the OUTPUT */ \
+    /* arrays: TILE_OUTGROWN.  The kernels at the head of the queue chain never see such a tile: the tile table    */ \
+    /* they are launched with shows it EMPTY (hot_tiles_kernel), they pass it on as unfinished, and the builds      */ \
+    /* behind them -- launched with the true table -- read it there, tile_src below.  No code for it here: a test   */ \
+    /* in tile_sort_eq_kernel's plain build cost ten more SGPR spills and 5 % of its time.)                         */ \
     const uint64_t in0 = slot_cap ? (uint64_t)g * slot_cap : start;
+#define TILE_OUTGROWN (slot_cap != 0 && t.s1 - t.s0 > (uint64_t)slot_cap)
 
+#define TILE_SRC_KEY in_key
+#define TILE_SRC_SA in_sa
 #define TILE_SORT_LOAD                                                                                          \
     PAR(tid) {                                                                                                  \
         if (tid == 0) { kmm[0] = ~0ull; kmm[1] = 0; flag[0] = 0; }                                              \
@@ -876,11 +890,11 @@ __device__ unsigned int caps_eq_check[64];
                     key = window64<BITS>(P, text_base + start + e);                                             \
                     sa = (idx_t)(text_base + start + e);                                                        \
                 } else if (TILE_KEYS_FROM_TEXT) {   /* 32-bit keys in the slots: the 64-bit key is cut from the text */ \
-                    sa = in_sa[in0 + e];                                                                        \
+                    sa = TILE_SRC_SA[in0 + e];                                                                  \
                     key = window64<BITS>(P, (uint64_t)sa);                                                      \
                 } else {                                                                                        \
-                    key = in_key[in0 + e];                                                                      \
-                    sa = in_sa[in0 + e];                                                                        \
+                    key = TILE_SRC_KEY[in0 + e];                                                                \
+                    sa = TILE_SRC_SA[in0 + e];                                                                  \
                 }                                                                                               \
                 TL(rk, tid, k) = (decltype(TL(rk, tid, k) + 0))key;                                             \
                 TL(rs, tid, k) = sa;                                                                            \
@@ -1125,6 +1139,21 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
     PHASE_MARK(6);                                             // emit (+ LCPs); the stores themselves drain after the mark
 }
 
+// The tile table for the kernels at the head of the queue chain of a sort over slots with outgrown buckets (TILE_SORT_PROLOGUE):
+// a copy in which the tiles of every segment longer than slot_cap are empty.
+GLOBAL_FN LAUNCH_BOUNDS(256) hot_tiles_kernel(KCTX SegDesc sd, uint32_t slot_cap, TileInfo* __restrict__ hot)
+{
+    PAR(tid) {
+        const uint32_t nt = sd.tile_off[sd.G];
+        const uint32_t i = K_BLOCK_IDX * K_BLOCK_DIM + tid;
+        if (i < nt) {
+            TileInfo t = sd.tile_rec[i];
+            if (t.s1 - t.s0 > (uint64_t)slot_cap) { t.s1 = t.s0; t.tl = 0; }
+            hot[i] = t;
+        }
+    }
+}
+
 // Every tile straight into tile_sort_kernel's queue of unfinished tiles (skewed keys, pipeline.h SortOpts::skewed_keys:
 // the linear bin map would crowd nearly every tile -- 97 % of a genome-like text's -- and its attempt is then pure cost).
 GLOBAL_FN LAUNCH_BOUNDS(256) queue_all_tiles_kernel(KCTX SegDesc sd, uint32_t* __restrict__ redo)
@@ -1218,6 +1247,10 @@ DEV_INLINE uint64_t eq_emit_lcp(const uint32_t* __restrict__ P, uint64_t n, uint
 #endif
 #undef TILE_EMIT_LCP_
 #define TILE_EMIT_LCP_(ka, a, kb, b) eq_emit_lcp<BITS, VDEEP>(P, n, ka, a, kb, b, &flag[1], TEST_DROP)
+#undef TILE_SRC_KEY
+#undef TILE_SRC_SA
+#define TILE_SRC_KEY src_key
+#define TILE_SRC_SA src_sa
 #ifndef CAPS_EQ_FULL_SYNC          /* measurement: -DCAPS_EQ_FULL_SYNC keeps __syncthreads() in this kernel */
 #undef TILE_SYNC
 #define TILE_SYNC() SYNC_LDS()
@@ -1321,7 +1354,13 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
     const uint32_t cnt = (uint32_t)(t.s1 - start < TILE_E ? t.s1 - start : TILE_E);
     const bool with_lcp = lcp_mode != 0 && (t.s1 - t.s0) <= TILE_E;
     const bool direct = with_lcp && fin.sa != nullptr;
-    const uint64_t in0 = slot_cap ? (uint64_t)g * slot_cap : start;
+    // a bucket that outgrew its slot (TILE_SORT_PROLOGUE): the plain build sees its tiles empty and passes them on (`fast` below is
+    // false for them, no flag is up: redo_deep); the VDEEP build reads them where they were put together -- at their place in the
+    // output arrays -- and sorts them in place
+    const bool in_slot = !VDEEP || !TILE_OUTGROWN;
+    const uint64_t in0 = slot_cap != 0 && in_slot ? (uint64_t)g * slot_cap : start;
+    const uint64_t* src_key = tile_src(in_key, out_key, !in_slot);
+    const idx_t* src_sa = in_slot ? in_sa : out_sa;
     PHASE_T0();
     TILE_SORT_LOAD
 #if defined(CAPS_EQ_CHECK) && !defined(CAPS_EMUL)
@@ -1862,7 +1901,11 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_general_kernel(
     const uint32_t cnt = (uint32_t)(t.s1 - start < TILE_E ? t.s1 - start : TILE_E);
     const bool with_lcp = lcp_mode != 0 && (t.s1 - t.s0) <= TILE_E;
     const bool direct = with_lcp && fin.sa != nullptr;
-    const uint64_t in0 = slot_cap ? (uint64_t)g * slot_cap : start;
+    // a bucket that outgrew its slot was put together at its place in the output arrays (TILE_SORT_PROLOGUE): sorted in place
+    const bool in_slot = !TILE_OUTGROWN;
+    const uint64_t in0 = slot_cap != 0 && in_slot ? (uint64_t)g * slot_cap : start;
+    const uint64_t* src_key = tile_src(in_key, out_key, !in_slot);
+    const idx_t* src_sa = in_slot ? in_sa : out_sa;
     const uint32_t S = cnt / 4 < TILE_NT - 1 ? cnt / 4 : TILE_NT - 1;      // samples
     PAR(tid) {
         if (tid == 0) flag[0] = 0;
@@ -1877,11 +1920,11 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_general_kernel(
                     key = window64<BITS>(P, text_base + start + e);
                     sa = (idx_t)(text_base + start + e);
                 } else if (keys_from_text) {                      // 32-bit keys in the slots: the 64-bit key is cut from the text
-                    sa = in_sa[in0 + e];
+                    sa = src_sa[in0 + e];
                     key = window64<BITS>(P, (uint64_t)sa);
                 } else {
-                    key = in_key[in0 + e];
-                    sa = in_sa[in0 + e];
+                    key = src_key[in0 + e];
+                    sa = src_sa[in0 + e];
                 }
                 TL(rk, tid, k) = key;
                 TL(rs, tid, k) = sa;
@@ -2858,7 +2901,28 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_count_kernel(KCTX SegDesc sd, const uint
 // that consecutive lanes write consecutive slots (a bucket receives a run of consecutive
 // elements from every tile instead of 64 scattered 8-byte stores per wave instruction).
 // KT = uint32_t (SRC_ARRAYS, MAP_LINEAR only): the elements carry 32-bit keys in and out, the map lives in their space.
-template <typename idx_t, int BITS, int SRC, int MAP, typename KT = uint64_t>
+// SPILL (slots only; the speculative split by knots): what does not fit a slot is not dropped but appended to a stream --
+// every (tile, bucket) run that reaches beyond its slot reserves its length there (one global atomic, only then).  An
+// entry is (key, index, bucket, position inside the bucket): the cursor's values are positions inside the bucket for ALL its
+// elements, so once the sizes are known (the cursors) and scanned, spill_gather_kernel copies the slot's part of every bucket
+// that outgrew its slot to the bucket's place in the compact array and spill_place_kernel adds the stream's entries: no
+// count pass, and no second scatter for a text whose buckets mostly fit (quantile knots: all but 1-2 %, + the repeats).
+template <typename idx_t> struct Spill {
+    uint64_t* count = nullptr;     // entries reserved so far (beyond cap: the caller redoes the split with the count pass)
+    uint64_t cap = 0;
+    uint32_t chunk = 0;            // != 0: tile b of the launch owns entries [b * chunk, (b + 1) * chunk) -- its first runs go there
+                                   //   without a trip to `count` (which then starts behind the chunks; unused entries: bucket ~0)
+    uint64_t base = 0;             // one past the last slot position: an output offset >= base names entry (offset - base)
+    uint64_t* key = nullptr;
+    idx_t* sa = nullptr;
+    uint32_t* bucket = nullptr;    // bucket of the launch (~0: no entry)
+    idx_t* rel = nullptr;          // position inside the bucket
+};
+constexpr uint32_t SPILL_LONG = 64;                   // runs of this length and more: the workgroup writes (bucket, position) together
+constexpr uint32_t SPILL_LONG_CAP = TILE_E / SPILL_LONG;
+constexpr uint32_t SPILL_CHUNK = TILE_E / 128 ? TILE_E / 128 : 1;   // a tile of a genome-like text puts 7 elements on the stream, mean
+
+template <typename idx_t, int BITS, int SRC, int MAP, typename KT = uint64_t, bool SPILL = false>
 GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const uint32_t* __restrict__ P, uint64_t n_words,
                                                        uint64_t text_base, const KT* __restrict__ in_key,
                                                        const idx_t* __restrict__ in_sa, RunSrc<idx_t> rsrc,
@@ -2869,7 +2933,7 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
                                                        const BucketParams* __restrict__ fbps, const uint32_t* __restrict__ gfirst,
                                                        const uint64_t* __restrict__ split, const uint16_t* __restrict__ split_lut,
                                                        const uint32_t* __restrict__ split_span, uint32_t sub, uint32_t split_stride,
-                                                       uint32_t in_sub, const uint16_t* __restrict__ bid)
+                                                       uint32_t in_sub, const uint16_t* __restrict__ bid, Spill<idx_t> spill)
 {
     // sub > 1 (slots only; level A of the direct path): bucket i owns `sub` slots, one per sub-stream; the tiles of a
     // launch are dealt to the sub-streams round-robin by block index, i.e. (observed dispatch order, MI355X_MICROARCH
@@ -2909,6 +2973,13 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
     SHARED_ARRAY(KT, skey, TILE_E);
     SHARED_ARRAY(idx_t, ssa, TILE_E);
     SHARED_ARRAY(uint16_t, sbk, TILE_E);
+    // SPILL: the long runs of the tile that went to the stream (at, cursor value, length, bucket)
+    SHARED_ARRAY(uint64_t, lr_at, SPILL ? SPILL_LONG_CAP : 1);
+    SHARED_ARRAY(idx_t, lr_old, SPILL ? SPILL_LONG_CAP : 1);
+    SHARED_ARRAY(uint32_t, lr_c, SPILL ? SPILL_LONG_CAP : 1);
+    SHARED_ARRAY(uint32_t, lr_b, SPILL ? SPILL_LONG_CAP : 1);
+    SHARED_ARRAY(uint32_t, nlong, 2);     // [1]: entries of the tile's own chunk taken so far
+    static_assert(!SPILL || (MAP == MAP_SPLIT && sizeof(KT) == 8), "the spill stream: splits by knots, 64-bit keys");
     TL_DECL(KT, rk, TILE_EPT);
     TL_DECL(idx_t, rs, TILE_EPT);
     TL_DECL(uint32_t, rb, TILE_EPT);      // bucket
@@ -2937,6 +3008,7 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
     if (lds || FROM_TEXT || FROM_RUNS) {
         PAR(tid) {
             if (lds) for (uint32_t i = tid; i <= TILE_BINS; i += K_BLOCK_DIM) hist[i] = 0;
+            if (SPILL && tid < 2) nlong[tid] = 0;
             if (MAP == MAP_SPLIT && lds && !bid) {
                 for (uint32_t i = tid; i < n_split; i += K_BLOCK_DIM) stab[lds_swz(i)] = tab[i];
                 if (split_lut) for (uint32_t i = tid; i <= SPLIT_LUT_CELLS; i += K_BLOCK_DIM) slut[i] = split_lut[i];
@@ -3097,7 +3169,32 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
                 if (c) {
                     const uint64_t ci = spec ? (b0 + i) * sub + sx : b0 + i;
                     if (!spec) ob = (idx_t)(sub_start[b0 + i] + old);
-                    else ob = (uint64_t)old + c <= slot_cap ? (idx_t)(ci * slot_cap + old) : NO_SLOT;
+                    else if ((uint64_t)old + c <= slot_cap) ob = (idx_t)(ci * slot_cap + old);
+                    else if (SPILL && spill.count) {
+                        // the run reaches beyond the slot: all of it goes to the stream (what sits in the slot stays a prefix
+                        // of the bucket: the cursor only grows, so every later run of this bucket comes here too)
+                        // (room in the tile's own chunk first: the trip to the global counter would sit on every tile's critical
+                        // path -- measured at 3e9 genome-like: 20.8 ms with it against 19.4 for the same scatter without a stream)
+                        uint64_t at = ~0ull;
+                        if (spill.chunk) {
+                            const uint32_t lo = FETCH_ADD_U32(&nlong[1], c);
+                            if ((uint64_t)lo + c <= spill.chunk) at = (uint64_t)b * spill.chunk + lo;
+                        }
+                        if (at == ~0ull) at = FETCH_ADD_U64(spill.count, (uint64_t)c);
+                        ob = NO_SLOT;
+                        if (at + c <= spill.cap) {
+                            ob = (idx_t)(spill.base + at);
+                            if (c < SPILL_LONG) {
+                                for (uint32_t j = 0; j < c; ++j) { spill.bucket[at + j] = (uint32_t)(b0 + i); spill.rel[at + j] = (idx_t)(old + j); }
+                            } else {
+                                const uint32_t q = FETCH_ADD_U32(&nlong[0], 1u);      // (< SPILL_LONG_CAP: the runs of a tile add up to TILE_E)
+                                lr_at[q] = at;
+                                lr_old[q] = old;
+                                lr_c[q] = c;
+                                lr_b[q] = (uint32_t)(b0 + i);
+                            }
+                        }
+                    } else ob = NO_SLOT;
                 }
                 obase[i] = ob;
             }
@@ -3111,12 +3208,64 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
             if (q < cnt) {
                 const uint32_t bk = sbk[q];
                 const idx_t ob = obase[bk];
-                if (ob != NO_SLOT) {
+                if (SPILL && ob != NO_SLOT && (uint64_t)ob >= spill.base) {
+                    const uint64_t dst = (uint64_t)ob - spill.base + (q - hist[bk]);
+                    spill.key[dst] = skey[q];
+                    spill.sa[dst] = ssa[q];
+                } else if (ob != NO_SLOT) {
                     const uint64_t dst = (uint64_t)ob + (q - hist[bk]);
                     out_key[dst] = skey[q];
                     out_sa[dst] = ssa[q];
                 }
             }
+        }
+        if (SPILL) {
+            const uint32_t nl = nlong[0];
+            for (uint32_t r = 0; r < nl && r < SPILL_LONG_CAP; ++r) {
+                const uint64_t at = lr_at[r];
+                const idx_t old = lr_old[r];
+                const uint32_t c = lr_c[r], bb = lr_b[r];
+                for (uint32_t j = tid; j < c; j += K_BLOCK_DIM) { spill.bucket[at + j] = bb; spill.rel[at + j] = (idx_t)(old + j); }
+            }
+        }
+    }
+}
+
+// After a scatter with a spill stream: bucket b of the launch has seg_start[b + 1] - seg_start[b] elements (its cursor); where
+// that is more than the slot holds -- or the bucket sits out the tile sort (skip: the letter-run buckets, sorted later from the
+// compact array) -- the slot's part goes to the bucket's place in the compact array.  The tail of the slot's part of a bucket
+// that outgrew the slot may be positions of runs that went to the stream (never written): spill_place_kernel, next on the
+// stream, overwrites exactly those.
+template <typename idx_t>
+GLOBAL_FN LAUNCH_BOUNDS(256) spill_gather_kernel(KCTX const uint64_t* __restrict__ seg_start, uint32_t NB, uint64_t slot_cap,
+                                                 const uint8_t* __restrict__ skip, const uint64_t* __restrict__ slot_key,
+                                                 const idx_t* __restrict__ slot_sa, uint64_t* __restrict__ dst_key,
+                                                 idx_t* __restrict__ dst_sa)
+{
+    for (uint32_t b = K_BLOCK_IDX; b < NB; b += K_GRID_DIM) {
+        const uint64_t s0 = seg_start[b], len = seg_start[b + 1] - s0;
+        if (len <= slot_cap && !(skip && skip[b])) continue;
+        const uint64_t m = len < slot_cap ? len : slot_cap;
+        PAR(tid) {
+            for (uint64_t i = tid; i < m; i += K_BLOCK_DIM) {
+                dst_key[s0 + i] = slot_key[(uint64_t)b * slot_cap + i];
+                dst_sa[s0 + i] = slot_sa[(uint64_t)b * slot_cap + i];
+            }
+        }
+    }
+}
+
+template <typename idx_t>
+GLOBAL_FN LAUNCH_BOUNDS(256) spill_place_kernel(KCTX Spill<idx_t> sp, uint64_t cnt, const uint64_t* __restrict__ seg_start,
+                                                uint64_t* __restrict__ dst_key, idx_t* __restrict__ dst_sa)
+{
+    PAR(tid) {
+        for (uint64_t i = (uint64_t)K_BLOCK_IDX * K_BLOCK_DIM + tid; i < cnt; i += (uint64_t)K_GRID_DIM * K_BLOCK_DIM) {
+            const uint32_t b = sp.bucket[i];
+            if (b == ~0u) continue;
+            const uint64_t d = seg_start[b] + (uint64_t)sp.rel[i];
+            dst_key[d] = sp.key[i];
+            dst_sa[d] = sp.sa[i];
         }
     }
 }

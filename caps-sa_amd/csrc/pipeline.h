@@ -470,6 +470,11 @@ struct SortOpts {
     const uint64_t* knots = nullptr;    // non-null (quantile mode): parent q's buckets are (knots[q * KPG + i - 1], knots[q * KPG + i]],
     uint32_t knots_per_parent = 0;      //   i < KPG = knots_per_parent -- count pass + exact scatter, no slots, no equalising
     bool knots_have_prev = false;       // knots[-1] exists: the slice of a shard that does not own the first group
+    bool spill_slots = false;           // split by knots WITHOUT the count pass (needs final_sa / final_lcp: the spill stream borrows
+                                        //   them until the tile sort writes results there): slots over `oth`, what does not fit a
+                                        //   slot on the stream, the buckets that outgrew their slots put together in `cur`
+    TileInfo* hot_tile_rec = nullptr;   //   room for a second tile table (as many records as the bucket tables' tile capacity)
+    uint64_t* spill_stats = nullptr;    // [3] host counters: splits by knots done with slots / redone with the count pass, stream entries
     uint64_t in_extent = 0;             // one past the largest element index of in_key / in_sa (0: unknown).  Quantile splits then
                                         //   keep every element's bucket id between the count pass and the scatter (u16 per element, in
                                         //   the idle LCP array of the scatter's destination) instead of searching the knots twice
@@ -569,7 +574,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
             CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, SRC_, MAP_>), n_tiles, TILE_NT, be, psd, P, n_words, tbase, ikey, isa, rsrc, \
                         (const BucketParams*)bk.params, (const uint64_t*)bk.bstart, sub_start, (uint64_t)cap, static_cast<idx_t*>(bk.cursor),       \
                         okey, osa, fbps, gfirst, o.knots, (const uint16_t*)nullptr, (const uint32_t*)nullptr, 1u, o.knots_per_parent, o.sub, \
-                        (const uint16_t*)bid)
+                        (const uint16_t*)bid, Spill<idx_t>())
             const uint64_t* nokey = nullptr;
             const idx_t* nosa = nullptr;
             if (from_text) { if (grouped) CAPS_SCATTER_LAUNCH(SRC_TEXT, MAP_GROUPED, nokey, nosa); else CAPS_SCATTER_LAUNCH(SRC_TEXT, MAP_LINEAR, nokey, nosa); }
@@ -646,7 +651,8 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
                             (uint64_t)0, reinterpret_cast<const uint32_t*>(o.in_key), src_sa, rsrc, (const BucketParams*)bk.params,
                             (const uint64_t*)bk.bstart, (const uint64_t*)nullptr, (uint64_t)TILE_E, static_cast<idx_t*>(bk.cursor),
                             reinterpret_cast<uint32_t*>(slot_key), slot_sa, (const BucketParams*)nullptr, (const uint32_t*)nullptr,
-                            (const uint64_t*)nullptr, (const uint16_t*)nullptr, (const uint32_t*)nullptr, 1u, 0u, 1u, (const uint16_t*)nullptr);
+                            (const uint64_t*)nullptr, (const uint16_t*)nullptr, (const uint32_t*)nullptr, 1u, 0u, 1u, (const uint16_t*)nullptr,
+                            Spill<idx_t>());
                 BackendEvent s1 = be.record();
                 if (o.scatter_clock) { o.scatter_clock->spans.push_back({s0, s1}); o.scatter_clock->elems.push_back(n_elems); }
             } else
@@ -659,6 +665,92 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
             if (o.slot_stats) ++o.slot_stats[slots ? 0 : 1];
             if (o.k32 && !slots) { r.failed = true; return r; }
             if (dbg) std::fprintf(stderr, "[sort] slot split: largest bucket %llu -> %s\n", (unsigned long long)out2[1], slots ? "kept" : "redone");
+        }
+        // ---- speculative split by knots (quantile mode, level B of the direct path): slots + a spill stream, no count pass.
+        // Quantile buckets average BUCKET_Q = 3/4 of a tile with ~14 % spread: all but a percent or two fit a slot of nearly
+        // TILE_E; the rest (and the buckets of repeats, any size) outgrow it, and what they do not get into the slot goes to
+        // the stream (bucket_scatter_kernel SPILL).  Afterwards the cursors are the exact sizes as after a count pass, the
+        // outgrown buckets are put together at their places in `cur` (spill_gather_kernel, spill_place_kernel) and the tile
+        // sort reads a bucket from its slot or, outgrown, from `cur` in place (kernels.h tile_src).  The stream lives in the
+        // caller's SA / LCP slice of this sort, idle until the tile sort emits.  A stream that runs full (a text that is
+        // mostly repeats): the count split below, as before.
+        if (by_knots && o.spill_slots && o.hot_tile_rec && !from_text && !runs && o.final_sa && o.final_lcp && o.need_lcp &&
+            !std::getenv("CAPS_SA_NO_SPILL_SLOTS")) {
+            const uint64_t NB = (uint64_t)(s.G / o.sub) * o.knots_per_parent;
+            const uint64_t idx_max = (uint64_t)std::numeric_limits<idx_t>::max() - TILE_E - 1;
+            // the stream: keys in the LCP slice, (index, bucket, position) in the SA slice
+            char* lcp_lo = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(o.final_lcp) + 15) & ~uintptr_t(15));
+            char* lcp_hi = reinterpret_cast<char*>(static_cast<idx_t*>(o.final_lcp) + n_elems);
+            char* sa_lo = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(o.final_sa) + 15) & ~uintptr_t(15));
+            char* sa_hi = reinterpret_cast<char*>(static_cast<idx_t*>(o.final_sa) + n_elems);
+            uint64_t scap = 0;
+            if (lcp_hi > lcp_lo + 64 && sa_hi > sa_lo + 64)
+                scap = std::min<uint64_t>((uint64_t)(lcp_hi - lcp_lo) / sizeof(uint64_t), (uint64_t)(sa_hi - sa_lo - 32) / (2 * sizeof(idx_t) + sizeof(uint32_t)));
+            const char* cap_env = std::getenv("CAPS_SA_TEST_SPILL_CAP");          // tests: a stream that runs full
+            if (cap_env) scap = std::min<uint64_t>(scap, std::strtoull(cap_env, nullptr, 10));
+            // slot capacity: a tile, unless `oth` or the index type has less room (then a little less: still well above the mean)
+            uint64_t cap_s = TILE_E;
+            if (NB) cap_s = std::min<uint64_t>(cap_s, oth.region_bytes / (sizeof(uint64_t) + sizeof(idx_t)) / NB);
+            const uint64_t want_stream = std::min<uint64_t>(scap, n_elems / 8 + 1024);
+            if (NB && idx_max > want_stream) cap_s = std::min<uint64_t>(cap_s, (idx_max - want_stream) / NB);
+            cap_s &= ~uint64_t(31);
+            const char* slot_env = std::getenv("CAPS_SA_TEST_SPILL_SLOT");        // tests: tiny slots (everything outgrows them)
+            if (slot_env) cap_s = std::min<uint64_t>(cap_s, std::strtoull(slot_env, nullptr, 10));
+            const uint64_t slot_total = NB * cap_s;
+            if (slot_total < idx_max) scap = std::min<uint64_t>(scap, idx_max - slot_total);
+            const bool fits = NB != 0 && NB <= bk.nb_cap && o.knots_per_parent <= BUCKET_LDS && (cap_env ? scap >= 1 : scap >= 1024) && slot_total < idx_max &&
+                              (slot_env || cap_s >= (BUCKET_Q / 6) * 7) &&
+                              oth.region_bytes >= slot_total * (sizeof(uint64_t) + sizeof(idx_t)) && bk.run_list;
+            if (fits) {
+                slot_key = oth.key;
+                slot_sa = reinterpret_cast<idx_t*>(reinterpret_cast<char*>(oth.key) + slot_total * sizeof(uint64_t));
+                Spill<idx_t> sp;
+                sp.count = bk.run_list;                  // (the list of letter-run buckets is made after the stream's count has been read)
+                sp.cap = scap;
+                sp.base = slot_total;
+                sp.key = reinterpret_cast<uint64_t*>(lcp_lo);
+                sp.sa = reinterpret_cast<idx_t*>(sa_lo);
+                sp.rel = sp.sa + scap;
+                sp.bucket = reinterpret_cast<uint32_t*>(sp.rel + scap);
+                // every tile's own chunk at the head of the stream (kernels.h Spill::chunk), the counter behind them
+                const uint64_t fixed = (uint64_t)n_tiles * SPILL_CHUNK <= scap / 4 && !std::getenv("CAPS_SA_NO_SPILL_CHUNKS") ? (uint64_t)n_tiles * SPILL_CHUNK : 0;
+                sp.chunk = fixed ? SPILL_CHUNK : 0u;
+                be.memset(bk.cursor, 0, (size_t)bk.nb_cap * sizeof(idx_t));
+                be.h2d(sp.count, &fixed, sizeof(uint64_t));
+                if (fixed) be.memset(sp.bucket, 0xFF, (size_t)fixed * sizeof(uint32_t));
+                BackendEvent s0 = be.record();
+                CAPS_LAUNCH((bucket_scatter_kernel<idx_t, BITS, SRC_ARRAYS, MAP_SPLIT, uint64_t, true>), n_tiles, TILE_NT, be, psd, P, (uint64_t)0,
+                            (uint64_t)0, src_key, src_sa, rsrc, (const BucketParams*)bk.params, (const uint64_t*)bk.bstart,
+                            (const uint64_t*)nullptr, cap_s, static_cast<idx_t*>(bk.cursor), slot_key, slot_sa,
+                            (const BucketParams*)nullptr, (const uint32_t*)nullptr, o.knots, (const uint16_t*)nullptr,
+                            (const uint32_t*)nullptr, 1u, o.knots_per_parent, o.sub, (const uint16_t*)nullptr, sp);
+                uint64_t spilled = 0;
+                be.d2h(&spilled, sp.count, sizeof spilled);
+                CAPS_LAUNCH((widen_kernel<idx_t>), (bk.nb_cap + 255) / 256, 256, be, (const idx_t*)static_cast<idx_t*>(bk.cursor),
+                            (uint64_t)bk.nb_cap, bk.count);
+                adopt_buckets();
+                bucket_tiles();                          // (syncs: `spilled` is here)
+                slots = spilled <= scap;
+                if (o.spill_stats) { ++o.spill_stats[slots ? 0 : 1]; o.spill_stats[2] += spilled; }
+                if (dbg) std::fprintf(stderr, "[sort] split by knots with slots of %llu: %llu on the stream (room for %llu), largest bucket %llu -> %s\n",
+                                      (unsigned long long)cap_s, (unsigned long long)spilled, (unsigned long long)scap, (unsigned long long)out2[1],
+                                      slots ? "kept" : "redone");
+                if (slots) {
+                    const uint32_t ggrid_ = (uint32_t)std::min<uint64_t>(NB, 65536);
+                    CAPS_LAUNCH((spill_gather_kernel<idx_t>), ggrid_, 256, be, (const uint64_t*)bk.sub.seg_start, (uint32_t)NB, cap_s,
+                                run_buckets ? (const uint8_t*)bk.skip : (const uint8_t*)nullptr, (const uint64_t*)slot_key, (const idx_t*)slot_sa,
+                                cur.key, cur.sa);
+                    if (spilled)
+                        CAPS_LAUNCH((spill_place_kernel<idx_t>), (uint32_t)std::min<uint64_t>((spilled + 255) / 256, 16384), 256, be, sp, spilled,
+                                    (const uint64_t*)bk.sub.seg_start, cur.key, cur.sa);
+                    BackendEvent s1 = be.record();
+                    if (o.scatter_clock) { o.scatter_clock->spans.push_back({s0, s1}); o.scatter_clock->elems.push_back(n_elems); }
+                    slot_cap = (uint32_t)cap_s;
+                } else {
+                    BackendEvent s1 = be.record();
+                    if (o.scatter_clock) { o.scatter_clock->spans.push_back({s0, s1}); o.scatter_clock->elems.push_back(n_elems); }
+                }
+            }
         }
         if (!slots) {
             // Count split.  Equalised (bk.fcount): the count pass fills EQ_FINE times finer buckets, bucket_group_kernel
@@ -711,7 +803,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
                 r.buf[1] = oth;
             }
             bucket_tiles();
-        } else {
+        } else if (!slot_cap) {
             slot_cap = TILE_E;                           // the tile sort reads the slots, writes `cur`
         }
         mark("bucket scatter");
@@ -725,6 +817,15 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
         r.n_tiles = n_tiles;
     }
     const SegDesc sd = segs.desc();
+    // the kernels at the head of the queue chain (tile_sort_kernel, the plain builds of tile_sort_eq_kernel) get a tile table in which
+    // the tiles of outgrown buckets are empty (kernels.h hot_tiles_kernel): they pass those on, the rest of the chain has `sd`
+    SegDesc sd_hot = sd;
+    if (slot_cap && max_len > slot_cap && o.hot_tile_rec) {
+        CAPS_LAUNCH(hot_tiles_kernel, (n_tiles + 255) / 256, 256, be, sd, slot_cap, o.hot_tile_rec);
+        sd_hot.tile_rec = o.hot_tile_rec;
+    } else if (slot_cap && max_len > slot_cap) {
+        throw std::invalid_argument("slots with outgrown buckets need room for the second tile table");
+    }
     const uint32_t lcp_mode = o.need_lcp ? 1u : 0u;
     FinalOut<idx_t> fin;
     if (o.need_lcp && o.final_sa) {
@@ -803,11 +904,11 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
                         in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo3, 0u, bflag);
         } else {
         if (all_queued && !per_tile) CAPS_LAUNCH(queue_all_tiles_kernel, (n_tiles + 255) / 256, 256, be, sd, redo);
-        else if (!all_queued) CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
+        else if (!all_queued) CAPS_LAUNCH((tile_sort_kernel<idx_t, BITS, false>), n_tiles, TILE_NT, be, sd_hot, P, n, (uint64_t)0, lcp_mode, slot_cap,
                     in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, redo, no_shift);
         if (per_tile) {
             // (no queue: workgroup b takes tile b)
-            CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false, false, false>), n_tiles, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
+            CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false, false, false>), n_tiles, TILE_NT, be, sd_hot, P, n, (uint64_t)0, lcp_mode, slot_cap,
                         in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)nullptr, redo3, 0u | drop, redo2);
             // what is left goes on with exact grids, one workgroup per entry: the lengths of the two queues come back to the
             // host (a round trip of ~20 us; a grid over all tiles for a queue that is mostly empty costs 0.8 ms at 3e9, and the
@@ -832,7 +933,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
                 CAPS_LAUNCH((tile_sort_general_kernel<idx_t, BITS, false, false, false>), ng, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
                             in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, (const uint32_t*)redo3, 0u, bflag);
         } else {
-            if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false>), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
+            if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false>), ggrid, TILE_NT, be, sd_hot, P, n, (uint64_t)0, lcp_mode, slot_cap,
                         in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo, redo3, 0u | drop, redo2);
             if (eq_tiles) CAPS_LAUNCH((tile_sort_eq_kernel<idx_t, BITS, false, true>), ggrid, TILE_NT, be, sd, P, n, (uint64_t)0, lcp_mode, slot_cap,
                         in_key, in_sa, cur.key, cur.sa, cur.lcp, fin, seg_map, (const uint32_t*)redo2, redo3, 0u, (uint32_t*)nullptr);
@@ -1289,6 +1390,7 @@ private:
     KernelClock finish_clock_, runb_clock_, msd_clock_;      // finalize(): gather + head LCPs, letter-run buckets, deferred ties
     uint32_t pass_base_ = 0;
     uint32_t slot_stats_[2] = {0, 0};
+    uint64_t spill_stats_[3] = {0, 0, 0};
     // per-build results of the phase sequences below
     uint32_t passes1_ = 0, passes2_ = 0, passesS_ = 0;
     BackendEvent e2_, e3_, e4_, e5_, e6_, e7_, la0_, la1_;
@@ -1673,7 +1775,8 @@ private:
                             packed_words(n, BITS), (uint64_t)0, (const uint64_t*)nullptr, (const idx_t*)nullptr, RunSrc<idx_t>(),
                             (const BucketParams*)pl_.bk.params, (const uint64_t*)pl_.bk.bstart, (const uint64_t*)nullptr, capA,
                             pl_.dcur, a_key, a_sa, (const BucketParams*)nullptr, (const uint32_t*)nullptr,
-                            (const uint64_t*)pl_.gkey, (const uint16_t*)pl_.glut, (const uint32_t*)(dflag + 1), SUB, 0u, 1u, (const uint16_t*)nullptr);
+                            (const uint64_t*)pl_.gkey, (const uint16_t*)pl_.glut, (const uint32_t*)(dflag + 1), SUB, 0u, 1u, (const uint16_t*)nullptr,
+                            Spill<idx_t>());
             BackendEvent s1 = be_.record();
             scatter_clock_.spans.push_back({s0, s1});
             scatter_clock_.elems.push_back(n);
@@ -1714,7 +1817,15 @@ private:
         o2.part_total = K1;
         o2.sub = SUB;
         o2.seg_ends = true;
-        if (quantile) { o2.knots = pl_.knots; o2.knots_per_parent = KPG; o2.in_extent = (uint64_t)n_streams * capA; }
+        if (quantile) {
+            o2.knots = pl_.knots;
+            o2.knots_per_parent = KPG;
+            o2.in_extent = (uint64_t)n_streams * capA;
+            // no count pass (segmented_sort "speculative split by knots") -- unless a wave of this build already had to redo its split
+            o2.spill_slots = spill_stats_[1] == 0;
+            o2.spill_stats = spill_stats_;
+            o2.hot_tile_rec = pl_.seg1.tile_rec;     // (level A's one-segment tables: idle until finalize() sorts the letter-run buckets)
+        }
         o2.skewed_keys = quantile && probe[2] != 0 && !std::getenv("CAPS_SA_TRY_LINEAR_TILES");   // (the variable: measurement)
         if (k32) { o2.k32 = true; o2.range_mode = 2; o2.gshift = pl_.gshift; }
         o2.in_key = a_key;
@@ -1892,6 +2003,9 @@ private:
             st->level_a_ms = direct_groups_ ? be_.elapsed_ms(la0_, la1_) : 0.0;
             st->slot_splits = slot_stats_[0];
             st->slot_splits_redone = slot_stats_[1];
+            st->knot_slot_splits = (uint32_t)spill_stats_[0];
+            st->knot_slot_splits_redone = (uint32_t)spill_stats_[1];
+            st->spill_entries = spill_stats_[2];
             st->merge_pass_elems = 0;                      // elements the timed passes really merged
             for (uint32_t i = 0; i < pass_base_ && i < kMaxPasses; ++i) st->merge_pass_elems += pass_elems[i];
         }

@@ -98,6 +98,10 @@ typedef struct caps_sa_stats {
     /* the three parts of the last stage, summed over their launches (device time, as the kernel clocks above): gathering SA / LCP
      * with the segment-head LCPs (a11), the letter-run buckets (run_buckets), the deferred ties (tie_groups_deferred) */
     double finish_ms, run_bucket_ms, msd_ms;
+    /* direct path, quantile mode: level-B splits by knots done WITHOUT the count pass (slots + a stream for what outgrows them) /
+     * redone with it (the stream ran full), and the elements that took the stream */
+    uint32_t knot_slot_splits, knot_slot_splits_redone;
+    uint64_t spill_entries;
 } caps_sa_stats;
 
 /* sizeof(caps_sa_stats) / sizeof(caps_sa_shard_info) of THIS library.  Both structs grow at their end from release to release and

@@ -439,6 +439,69 @@ def test_direct_path_modes_and_fallbacks(oracle, monkeypatch):
     assert run(T5)["bits_per_char"] == 8
 
 
+def test_quantile_split_without_a_count_pass(oracle, monkeypatch):
+    """Level B in quantile mode (pipeline.h "speculative split by knots"): no count pass -- every bucket gets a slot, the runs that
+    do not fit go to a stream (bucket_scatter_kernel SPILL) that borrows the caller's SA / LCP slice, the buckets that outgrew
+    their slots are put together in the compact array (spill_gather_kernel, spill_place_kernel) and the tile sort reads a bucket
+    from its slot or from there.  Skewed keys, N-block stand-ins (letter-run buckets: always from the compact array; runs of a
+    tile long enough for the cooperative write), repeats with deferred ties, 64-bit indices, waves; slots made tiny (most of
+    every bucket takes the stream) and a stream that runs full (the count split takes over).  256-element-tile build."""
+    from emul_util import emul_small
+    E = emul_small()
+    rs = np.random.RandomState(5)
+    keys = ("CAPS_SA_DIRECT_MODE", "CAPS_SA_DIRECT_SUB", "CAPS_SA_TEST_SPILL_SLOT", "CAPS_SA_TEST_SPILL_CAP", "CAPS_SA_NO_SPILL_SLOTS",
+            "CAPS_SA_HOST_WAVES")
+
+    def run(T, bits=32, **env):
+        for k in keys:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv("CAPS_SA_" + k, v)
+        SA, LCP, st = E.build(T, p=0, idx_bits=bits)
+        SAo, LCPo = oracle.build_sa_lcp(T, p=64, idx_bits=bits)
+        assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo), env
+        return st
+
+    skew = _markov(rs, 200_000)
+    st = run(skew)
+    assert st["direct_quantile"] == 1 and st["knot_slot_splits"] == 1 and st["knot_slot_splits_redone"] == 0
+    assert 0 < st["spill_entries"] < skew.size // 8 and st["bucket_count_ms"] == 0.0
+    base = st["spill_entries"]
+    st = run(skew, NO_SPILL_SLOTS="1")
+    assert st["knot_slot_splits"] == 0 and st["spill_entries"] == 0
+    st = run(skew, TEST_SPILL_SLOT="160")                                   # slots below the mean bucket (192): most buckets outgrow them
+    assert st["knot_slot_splits"] == 1 and st["spill_entries"] > 4 * base
+    st = run(skew, TEST_SPILL_SLOT="32")                                    # ... so far below that the stream runs full
+    assert st["knot_slot_splits"] == 0 and st["knot_slot_splits_redone"] == 1
+    st = run(skew, TEST_SPILL_CAP="100")
+    assert st["knot_slot_splits"] == 0 and st["knot_slot_splits_redone"] == 1
+    st = run(skew[:120_001], bits=64)
+    assert st["knot_slot_splits"] == 1 and st["spill_entries"] > 0
+    st = run(skew[:120_001], bits=64, TEST_SPILL_SLOT="160")
+    assert st["knot_slot_splits"] == 1
+    for waves in ("2", "5"):
+        st = run(skew, HOST_WAVES=waves)
+        assert st["result_waves"] >= 2 and st["knot_slot_splits"] == st["result_waves"], st
+        st = run(skew, HOST_WAVES=waves, TEST_SPILL_SLOT="160")
+        assert st["knot_slot_splits"] == st["result_waves"]
+    runs = rs.choice(DNA, size=300_000)
+    runs[50_000:53_000] = ord("G")
+    runs[200_000:200_700] = ord("G")
+    st = run(runs, DIRECT_SUB="1")
+    assert st["direct_quantile"] == 1 and st["long_runs"] == 1 and st["run_buckets"] >= 1 and st["knot_slot_splits"] == 1
+    assert st["spill_entries"] > 2_500                                       # the G-block: one bucket, far beyond its slot
+    st = run(runs, DIRECT_SUB="1", HOST_WAVES="3")
+    assert st["knot_slot_splits"] >= 2
+    rep = _repeat_rich(rs, 260_000)
+    st = run(rep, DIRECT_MODE="quantile")
+    assert st["knot_slot_splits"] == 1 and st["tie_groups_deferred"] > 0
+    st = run(rep, DIRECT_MODE="quantile", TEST_SPILL_SLOT="160")
+    assert st["knot_slot_splits"] == 1
+    T8 = rs.choice(np.frombuffer(b"abcdefgh", dtype=np.uint8), size=150_000, p=[.5, .2, .1, .1, .05, .03, .01, .01])
+    st = run(T8, DIRECT_MODE="quantile")
+    assert st["bits_per_char"] == 8 and (st["path_direct"] == 0 or st["knot_slot_splits"] == 1)
+
+
 def test_forced_substreams_on_a_nine_tile_text(oracle, monkeypatch):
     """Found by tools/stress_gpu.py on the GPU (and replayed here): quantile mode with 8 sub-streams forced on a text of nine
     level-A tiles -- the token room per stream exceeded the budget per stream, the regions overran the buffer, SA was not a

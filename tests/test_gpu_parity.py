@@ -826,6 +826,80 @@ def test_results_leave_in_waves_host_path(L, oracle, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_quantile_split_without_a_count_pass_device(L, oracle, monkeypatch):
+    """VERDICT r4 item 1 (quantile level B): the split by knots runs without its count pass -- slots, a spill stream in the
+    caller's SA / LCP slice for what outgrows them, the outgrown buckets put together in the compact array (pipeline.h
+    "speculative split by knots"; kernels.h Spill).  Against the oracle: skewed keys, N-block stand-ins (letter-run buckets and
+    long runs on the stream), repeats (deferred ties), 64-bit indices, waves, slots made small (most buckets outgrow them),
+    a stream that runs full (the count split takes over), and the count split itself -- the same arrays every way."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    from genome_like import markov_dna
+    keys = ("CAPS_SA_DIRECT_MODE", "CAPS_SA_DIRECT_SUB", "CAPS_SA_TEST_SPILL_SLOT", "CAPS_SA_TEST_SPILL_CAP", "CAPS_SA_NO_SPILL_SLOTS",
+            "CAPS_SA_HOST_WAVES")
+
+    def run(T, want, bits=32, direct=True, **env):
+        for k in keys:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv("CAPS_SA_" + k, v)
+        SA, LCP, st = L.build(T, p=1000, idx_bits=bits)
+        assert np.array_equal(SA, want[0]) and np.array_equal(LCP, want[1]), env
+        assert not direct or (st["path_direct"] == 1 and st["direct_quantile"] == 1), env
+        return st
+
+    rs = np.random.RandomState(91)
+    skew = markov_dna(5_000_000, seed=23).cpu().numpy()
+    want = oracle.build_sa_lcp(skew, p=1000)
+    st = run(skew, want)
+    assert st["knot_slot_splits"] == 1 and st["knot_slot_splits_redone"] == 0 and st["bucket_count_ms"] == 0.0, st
+    assert 0 < st["spill_entries"] < skew.size // 8
+    base = st["spill_entries"]
+    st = run(skew, want, NO_SPILL_SLOTS="1")
+    assert st["knot_slot_splits"] == 0 and st["bucket_count_ms"] > 0.0
+    st = run(skew, want, TEST_SPILL_SLOT="2816")                            # slots below the mean bucket (3072)
+    assert st["knot_slot_splits"] == 1 and st["spill_entries"] > 4 * base
+    st = run(skew, want, TEST_SPILL_SLOT="512")                             # ... and so small that the stream runs full
+    assert st["knot_slot_splits"] == 0 and st["knot_slot_splits_redone"] == 1
+    st = run(skew, want, TEST_SPILL_CAP="1000")
+    assert st["knot_slot_splits"] == 0 and st["knot_slot_splits_redone"] == 1
+    for waves in ("2", "5"):
+        st = run(skew, want, HOST_WAVES=waves)
+        assert st["result_waves"] >= 2 and st["knot_slot_splits"] == st["result_waves"]
+        st = run(skew, want, HOST_WAVES=waves, TEST_SPILL_SLOT="2816")
+        assert st["knot_slot_splits"] == st["result_waves"]
+    want64 = oracle.build_sa_lcp(skew[:3_000_001], p=1000, idx_bits=64)
+    st = run(skew[:3_000_001], want64, bits=64)
+    assert st["knot_slot_splits"] == 1
+    run(skew[:3_000_001], want64, bits=64, TEST_SPILL_SLOT="2816")
+    runs = rs.choice(DNA, size=8_000_000)
+    runs[1_000_000:1_060_000] = ord("G")
+    runs[5_000_000:5_009_000] = ord("G")
+    want = oracle.build_sa_lcp(runs, p=1000)
+    run(runs, want, direct=False)               # (8 sub-streams at this size: the 60,000-char run may overload some -> the samplesort path)
+    st = run(runs, want, DIRECT_SUB="1")        # one stream per group: the fat group's region holds the run
+    assert st["long_runs"] == 1 and st["run_buckets"] >= 1 and st["knot_slot_splits"] == 1 and st["spill_entries"] > 50_000
+    st = run(runs, want, DIRECT_SUB="1", HOST_WAVES="3")
+    assert st["knot_slot_splits"] >= 2
+    run(runs, want, DIRECT_SUB="1", TEST_SPILL_SLOT="2816")
+    rep = markov_dna(6_000_000, seed=29).cpu().numpy()
+    unit = rep[1000:1171].copy()
+    for k in range(3000):                                                   # a tandem array with a mutation here and there
+        rep[2_000_000 + 171 * k:2_000_000 + 171 * (k + 1)] = unit
+    mut = rs.randint(2_000_000, 2_000_000 + 171 * 3000, size=4000)
+    rep[mut] = rs.choice(DNA, size=mut.size)
+    rep[5_000_000:5_040_000] = rep[100_000:140_000]                         # an exact 40-kb duplicate
+    want = oracle.build_sa_lcp(rep, p=1000)
+    st = run(rep, want)
+    assert st["knot_slot_splits"] == 1
+    run(rep, want, TEST_SPILL_SLOT="2816")
+    run(rep, want, NO_SPILL_SLOTS="1")
+    L.release_cache()
+
+
+@pytest.mark.gpu
 def test_lcp_leaves_the_device_as_bytes_host_path(L, oracle, monkeypatch):
     """on the link the LCP array travels as bytes (capi_impl.h HostCopySink, lcp_narrow_kernel) -- values below
     255 as they are, the others as (position, value) pairs at the end -- and host threads widen them into the caller's array while
