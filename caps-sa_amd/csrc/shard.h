@@ -155,6 +155,7 @@ public:
             partial_ = get<uint64_t>((size_t)PART_CHUNKS * p_);
             lstart_ = get<uint64_t>((size_t)p_ + 1);
             bk_ = buckets(cap_, gseg);
+            hot_rec_ = quantile_ok_ ? get<TileInfo>(bk_.tile_cap + 1) : nullptr;      // (segmented_sort: speculative split by knots)
             const uint64_t a = bk_.tile_cap + 3, b = m_total_ / TILE_E + 3;
             tdesc_ = get<TileDesc>(a > b ? a : b);
             desc_ = get<uint64_t>((size_t)3 * world * p_ + 3);
@@ -588,6 +589,8 @@ private:
     uint32_t KPG_ = 0;
     uint64_t NB_ = 0, m2_ = 0;
     uint64_t *knots_ = nullptr, *rcap_ = nullptr, *rstart_ = nullptr;
+    TileInfo* hot_rec_ = nullptr;
+    uint64_t spill_stats_[3] = {0, 0, 0};
     std::vector<uint64_t> h_rstart_, h_rcap_;       // regions of the owned streams (host copy for shard_plan)
     uint32_t PG_ = 0, K1_ = 0, SUB_ = 1, n_streams_ = 0, my_tiles_ = 0, own_lo_ = 0, own_hi_ = 0;
     uint64_t capA_ = 0, my_elems_ = 0;
@@ -719,6 +722,9 @@ private:
             o.knots_have_prev = jlo_ > 0;                 // bucket 0 of the slice starts above the previous group's last knot
             o.in_extent = ((uint64_t)K1_ + world_ - 1) / world_ * SUB_ * capA_;   // the owned streams' regions fit this (scatter_bits)
             o.skewed_keys = skewed_ && !std::getenv("CAPS_SA_TRY_LINEAR_TILES");
+            o.spill_slots = hot_rec_ != nullptr;      // no count pass (as Builder::run_direct)
+            o.hot_tile_rec = hot_rec_;
+            o.spill_stats = spill_stats_;
         }
         KernelClock tile_clock, scatter_clock, count_clock, merge_clock;
         o.tile_clock = &tile_clock;
