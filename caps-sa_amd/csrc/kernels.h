@@ -3242,16 +3242,34 @@ GLOBAL_FN LAUNCH_BOUNDS(256) spill_gather_kernel(KCTX const uint64_t* __restrict
                                                  const idx_t* __restrict__ slot_sa, uint64_t* __restrict__ dst_key,
                                                  idx_t* __restrict__ dst_sa)
 {
-    for (uint32_t b = K_BLOCK_IDX; b < NB; b += K_GRID_DIM) {
-        const uint64_t s0 = seg_start[b], len = seg_start[b + 1] - s0;
-        if (len <= slot_cap && !(skip && skip[b])) continue;
-        const uint64_t m = len < slot_cap ? len : slot_cap;
+    // a workgroup looks at 256 consecutive buckets at once (one bucket per thread: a walk bucket by bucket was one memory latency
+    // per bucket for the 98 % that have nothing to copy -- 0.6 ms at 977,000 buckets), lists the few that do, copies those together
+    SHARED_ARRAY(uint32_t, lst, 256);
+    SHARED_ARRAY(uint32_t, ln, 1);
+    for (uint64_t base = (uint64_t)K_BLOCK_IDX * 256u; base < NB; base += (uint64_t)K_GRID_DIM * 256u) {
+        PAR(tid) { if (tid == 0) ln[0] = 0; }
+        SYNC();
         PAR(tid) {
-            for (uint64_t i = tid; i < m; i += K_BLOCK_DIM) {
-                dst_key[s0 + i] = slot_key[(uint64_t)b * slot_cap + i];
-                dst_sa[s0 + i] = slot_sa[(uint64_t)b * slot_cap + i];
+            const uint64_t b = base + tid;
+            if (b < NB) {
+                const uint64_t len = seg_start[b + 1] - seg_start[b];
+                if (len > slot_cap || (len && skip && skip[b])) lst[FETCH_ADD_U32(&ln[0], 1u)] = (uint32_t)b;
             }
         }
+        SYNC();
+        const uint32_t m = ln[0];                                           // block-uniform
+        for (uint32_t q = 0; q < m; ++q) {
+            const uint32_t b = lst[q];
+            const uint64_t s0 = seg_start[b], len = seg_start[b + 1] - s0;
+            const uint64_t cnt = len < slot_cap ? len : slot_cap;
+            PAR(tid) {
+                for (uint64_t i = tid; i < cnt; i += K_BLOCK_DIM) {
+                    dst_key[s0 + i] = slot_key[(uint64_t)b * slot_cap + i];
+                    dst_sa[s0 + i] = slot_sa[(uint64_t)b * slot_cap + i];
+                }
+            }
+        }
+        SYNC();
     }
 }
 

@@ -736,7 +736,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
                                       (unsigned long long)cap_s, (unsigned long long)spilled, (unsigned long long)scap, (unsigned long long)out2[1],
                                       slots ? "kept" : "redone");
                 if (slots) {
-                    const uint32_t ggrid_ = (uint32_t)std::min<uint64_t>(NB, 65536);
+                    const uint32_t ggrid_ = (uint32_t)std::min<uint64_t>((NB + 255) / 256, 16384);
                     CAPS_LAUNCH((spill_gather_kernel<idx_t>), ggrid_, 256, be, (const uint64_t*)bk.sub.seg_start, (uint32_t)NB, cap_s,
                                 run_buckets ? (const uint8_t*)bk.skip : (const uint8_t*)nullptr, (const uint64_t*)slot_key, (const idx_t*)slot_sa,
                                 cur.key, cur.sa);

@@ -500,6 +500,13 @@ def test_quantile_split_without_a_count_pass(oracle, monkeypatch):
     T8 = rs.choice(np.frombuffer(b"abcdefgh", dtype=np.uint8), size=150_000, p=[.5, .2, .1, .1, .05, .03, .01, .01])
     st = run(T8, DIRECT_MODE="quantile")
     assert st["bits_per_char"] == 8 and (st["path_direct"] == 0 or st["knot_slot_splits"] == 1)
+    # uniform keys in quantile mode: the queue chain starts at tile_sort_kernel (linear bins), which sees the tiles of outgrown
+    # buckets empty and passes them on like the plain equalised build behind it
+    uni = rs.choice(DNA, size=150_000)
+    st = run(uni, DIRECT_MODE="quantile")
+    assert st["direct_quantile"] == 1 and st["knot_slot_splits"] == 1
+    st = run(uni, DIRECT_MODE="quantile", TEST_SPILL_SLOT="160")
+    assert st["knot_slot_splits"] == 1 and st["spill_entries"] > 10_000
 
 
 def test_forced_substreams_on_a_nine_tile_text(oracle, monkeypatch):

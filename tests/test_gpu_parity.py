@@ -896,6 +896,13 @@ def test_quantile_split_without_a_count_pass_device(L, oracle, monkeypatch):
     assert st["knot_slot_splits"] == 1
     run(rep, want, TEST_SPILL_SLOT="2816")
     run(rep, want, NO_SPILL_SLOTS="1")
+    # uniform keys in quantile mode: the queue chain starts at tile_sort_kernel, which sees the tiles of outgrown buckets empty
+    uni = rs.choice(DNA, size=5_000_001)
+    want = oracle.build_sa_lcp(uni, p=1000)
+    st = run(uni, want, DIRECT_MODE="quantile")
+    assert st["knot_slot_splits"] == 1
+    st = run(uni, want, DIRECT_MODE="quantile", TEST_SPILL_SLOT="2816")
+    assert st["knot_slot_splits"] == 1 and st["spill_entries"] > 200_000
     L.release_cache()
 
 

@@ -16,6 +16,7 @@ from bench import kernel_sources_sha256  # noqa: E402
 
 # kernel name prefix -> family of bench.py's roofline (first match wins)
 FAMILY = [("group_scatter_kernel", "level_a_scatter"), ("bucket_scatter_kernel", "level_b_scatter"), ("bucket_count_kernel", "level_b_count"),
+          ("spill_gather_kernel", "level_b_scatter"), ("spill_place_kernel", "level_b_scatter"),
           ("tile_sort_eq_kernel", "tile_sort_kernel"), ("tile_sort_kernel", "tile_sort_kernel"), ("tile_sort_general_kernel", "tile_sort_kernel"),
           ("merge_pass_kernel", "merge_pass_kernel"), ("merge_partition_kernel", "merge_pass_kernel"),
           ("pack_kernel", "pack"), ("alphabet_kernel", "pack"), ("run_blocks_kernel", "pack"), ("run_chunk_heads_kernel", "pack"),

@@ -65,7 +65,8 @@ kinds = ["uniform", "skew", "two", "bytes", "periodic", "planted", "runs", "stre
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from sa_check import sa_lcp                 # independent prefix-doubling construction: not quadratic on stretches
 t0 = time.time(); done = 0; oom = 0; last_note = t0
-stats = {"slot_splits": 0, "slot_splits_redone": 0, "long_runs": 0, "path_direct": 0, "direct_quantile": 0}
+stats = {"slot_splits": 0, "slot_splits_redone": 0, "long_runs": 0, "path_direct": 0, "direct_quantile": 0, "knot_slot_splits": 0,
+         "knot_slot_splits_redone": 0}
 fallbacks = {}
 while time.time() - t0 < budget:
     kind = kinds[rs.randint(len(kinds))]
@@ -91,6 +92,9 @@ while time.time() - t0 < budget:
     else: os.environ["CAPS_SA_DIRECT_MODE"] = mode
     if rs.rand() < 0.3: os.environ["CAPS_SA_DIRECT_SUB"] = str(rs.choice([1, 2, 8]))
     else: os.environ.pop("CAPS_SA_DIRECT_SUB", None)
+    # quantile level B without its count pass: slots smaller than they would be (more buckets outgrow them, more of the stream)
+    if rs.rand() < 0.35: os.environ["CAPS_SA_TEST_SPILL_SLOT"] = str(rs.choice([3584, 2816, 1024] if not os.environ.get("STRESS_EMUL") else [224, 160, 64]))
+    else: os.environ.pop("CAPS_SA_TEST_SPILL_SLOT", None)
     if os.environ.get("STRESS_ONLY_N") and n != int(os.environ["STRESS_ONLY_N"]):
         continue                                 # replaying one case of a sequence: same random draws, nothing built
     if os.environ.get("STRESS_TRACE"):           # the parameters of every build, before it runs (finding the one that faults)
@@ -117,7 +121,7 @@ while time.time() - t0 < budget:
         np.save(os.environ.get("STRESS_DUMP", "/tmp/stress_fail_T.npy"), T)
         print(json.dumps({"FAIL": True, "kind": kind, "n": n, "p": p, "bits": bits, "path": os.environ.get("CAPS_SA_PATH"),
                           "mode": os.environ.get("CAPS_SA_DIRECT_MODE"), "sub": os.environ.get("CAPS_SA_DIRECT_SUB"),
-                          "multi": os.environ.get("STRESS_MULTI"), "exchange": os.environ.get("CAPS_SA_SHARD_EXCHANGE"),
+                          "spill_slot": os.environ.get("CAPS_SA_TEST_SPILL_SLOT"), "multi": os.environ.get("STRESS_MULTI"), "exchange": os.environ.get("CAPS_SA_SHARD_EXCHANGE"),
                           "stats": {k: st[k] for k in ("path_direct", "path_fallback", "direct_quantile", "direct_groups")}}))
         sys.exit(1)
     for k in stats: stats[k] += st[k]
