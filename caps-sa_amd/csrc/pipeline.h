@@ -76,8 +76,14 @@ constexpr uint32_t kMaxPasses = 96;
 constexpr uint32_t DIRECT_SUB = CAPS_DIRECT_SUB;
 // Quantile mode of the direct path (skewed keys): mean bucket size (sampling noise on top: sigma = 1 / sqrt(QUANTILE_SPB)) and
 // samples drawn per bucket.
-constexpr uint32_t BUCKET_Q = (TILE_E * 3) / 4;
-constexpr uint32_t QUANTILE_SPB = 48;
+#ifndef CAPS_BUCKET_Q_32NDS
+#define CAPS_BUCKET_Q_32NDS 24     /* measured at 3e9 genome-like, count-free split: 22 / 24 / 26 thirty-seconds of a tile */
+#endif
+#ifndef CAPS_QUANTILE_SPB
+#define CAPS_QUANTILE_SPB 64       /* ... and 32 / 48 / 64 samples per bucket: 89.4 / 83.6 / 82.1 ms (a bucket above a tile costs a merge pass and more) */
+#endif
+constexpr uint32_t BUCKET_Q = (TILE_E * CAPS_BUCKET_Q_32NDS) / 32;
+constexpr uint32_t QUANTILE_SPB = CAPS_QUANTILE_SPB;
 
 // Fine buckets per bucket slot of the equalised split (bucket_group_kernel), as far as the LDS histograms hold them.
 #ifndef CAPS_EQ_FINE
@@ -667,7 +673,7 @@ SortResult<idx_t> segmented_sort(Backend& be, const uint32_t* P, uint64_t n, Til
             if (dbg) std::fprintf(stderr, "[sort] slot split: largest bucket %llu -> %s\n", (unsigned long long)out2[1], slots ? "kept" : "redone");
         }
         // ---- speculative split by knots (quantile mode, level B of the direct path): slots + a spill stream, no count pass.
-        // Quantile buckets average BUCKET_Q = 3/4 of a tile with ~14 % spread: all but a percent or two fit a slot of nearly
+        // Quantile buckets average BUCKET_Q = 3/4 of a tile with ~12 % spread: all but a percent fit a slot of nearly
         // TILE_E; the rest (and the buckets of repeats, any size) outgrow it, and what they do not get into the slot goes to
         // the stream (bucket_scatter_kernel SPILL).  Afterwards the cursors are the exact sizes as after a count pass, the
         // outgrown buckets are put together at their places in `cur` (spill_gather_kernel, spill_place_kernel) and the tile
