@@ -241,7 +241,7 @@ def test_small_tiles_random_dna(oracle, sa_path, n, p):
     assert np.array_equal(SA, SAo) and np.array_equal(LCP, LCPo)
 
 
-@pytest.mark.parametrize("n,p", [(20000, 5), (50000, 64), (120000, 300), (90000, 1200)])
+@pytest.mark.parametrize("n,p", [(20000, 5), (50000, 64), (70000, 300), (60000, 1200)])
 def test_small_tiles_skewed_and_repetitive(oracle, sa_path, n, p):
     from emul_util import emul_small
     rs = np.random.RandomState(n % 89 + p)
