@@ -35,6 +35,9 @@ namespace caps { struct EmulCtx { uint32_t block_idx, grid_dim, block_dim; }; }
 #define KCTX const caps::EmulCtx& kctx_,
 #define KCTX_PASS kctx_,
 #define K_BLOCK_IDX (kctx_.block_idx)
+#define STREAM_LOAD(p) (*(p))                   /* a load of data read once (GPU: nontemporal, see below) */
+#define STREAM_STORE(p, v) (*(p) = (v))
+#define STREAM_STORE2(p, v) (*(p) = (v))
 #define K_GRID_DIM (kctx_.grid_dim)
 #define K_BLOCK_DIM (kctx_.block_dim)
 // CAPS_EMUL_RACE (tests/emul/race_rt.h): the barrier-race detector -- every PAR iteration announces its thread, every barrier
@@ -133,6 +136,24 @@ static inline uint32_t caps_bswap32(uint32_t x) { return __builtin_bswap32(x); }
 #define KCTX
 #define KCTX_PASS
 #define K_BLOCK_IDX (blockIdx.x)
+// Cache hints for data that passes once (round 5; measured at C3 on one box, 6 builds each, twice):
+//   STREAM_LOAD   the streams between the passes, read by the scatters and the tile sorts: nontemporal -- level B 16.85 -> 16.62 ms;
+//   STREAM_STORE  the results (SA, LCP), written once and never read again by the build: nontemporal -- tile sort 14.63 -> 14.37 ms;
+//   STREAM_STORE2 the scatters' own stores must NOT be: they are short runs that complete each other's cache lines in L2, and with
+//                 nontemporal stores level A took 35 ms instead of 13.6 and level B 54 instead of 16.6 (-DCAPS_STREAM_STORES2 repeats it).
+// -DCAPS_NO_STREAM_HINTS: plain loads and stores everywhere (the builds before this).
+#ifndef CAPS_NO_STREAM_HINTS
+#define STREAM_LOAD(p) __builtin_nontemporal_load(p)
+#define STREAM_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define STREAM_LOAD(p) (*(p))
+#define STREAM_STORE(p, v) (*(p) = (v))
+#endif
+#ifdef CAPS_STREAM_STORES2
+#define STREAM_STORE2(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define STREAM_STORE2(p, v) (*(p) = (v))
+#endif
 #define K_GRID_DIM (gridDim.x)
 #define K_BLOCK_DIM (blockDim.x)
 #define PAR(tid) for (uint32_t tid = threadIdx.x, par_once_ = 1; par_once_; par_once_ = 0)

@@ -890,11 +890,11 @@ DEV_INLINE const uint32_t* tile_src(const uint32_t* in, const uint64_t*, bool) {
                     key = window64<BITS>(P, text_base + start + e);                                             \
                     sa = (idx_t)(text_base + start + e);                                                        \
                 } else if (TILE_KEYS_FROM_TEXT) {   /* 32-bit keys in the slots: the 64-bit key is cut from the text */ \
-                    sa = TILE_SRC_SA[in0 + e];                                                                  \
+                    sa = STREAM_LOAD(&TILE_SRC_SA[in0 + e]);                                                    \
                     key = window64<BITS>(P, (uint64_t)sa);                                                      \
                 } else {                                                                                        \
-                    key = TILE_SRC_KEY[in0 + e];                                                                \
-                    sa = TILE_SRC_SA[in0 + e];                                                                  \
+                    key = STREAM_LOAD(&TILE_SRC_KEY[in0 + e]);                                                  \
+                    sa = STREAM_LOAD(&TILE_SRC_SA[in0 + e]);                                                    \
                 }                                                                                               \
                 TL(rk, tid, k) = (decltype(TL(rk, tid, k) + 0))key;                                             \
                 TL(rs, tid, k) = sa;                                                                            \
@@ -963,8 +963,8 @@ DEV_INLINE const uint32_t* tile_src(const uint32_t* in, const uint64_t*, bool) {
                     l = ov_ ? ov_ : TILE_EMIT_LCP_(skey[e - 1], ssa[e - 1], skey[e], sa);                          \
                 }                                                                                               \
                 if (direct) {                                                                                   \
-                    fin.sa[start + e] = sa;                                                                     \
-                    fin.lcp[start + e] = (idx_t)l;                                                              \
+                    STREAM_STORE(&fin.sa[start + e], sa);                                                       \
+                    STREAM_STORE(&fin.lcp[start + e], (idx_t)l);                                                \
                     if (e == 0) { fin.first_key[g] = key; fin.first_sa[g] = sa; }                               \
                     if (e == cnt - 1) { fin.last_key[g] = key; fin.last_sa[g] = sa; }                           \
                 } else {                                                                                        \
@@ -1121,8 +1121,8 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) tile_sort_kernel(KCTX Seg
                     uint64_t l = 0;
                     if (with_lcp && e) { const uint32_t sp = perm[e - 1]; l = TILE_EMIT_LCP_(skey[sp], ssa[sp], key, sa); }
                     if (direct) {
-                        fin.sa[start + e] = sa;
-                        fin.lcp[start + e] = (idx_t)l;
+                        STREAM_STORE(&fin.sa[start + e], sa);
+                        STREAM_STORE(&fin.lcp[start + e], (idx_t)l);
                         if (e == 0) { fin.first_key[g] = key; fin.first_sa[g] = sa; }
                         if (e == cnt - 1) { fin.last_key[g] = key; fin.last_sa[g] = sa; }
                     } else {
@@ -1817,8 +1817,8 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, CAPS_EQ_WAVES) tile_sort_eq_kernel(KCTX SegDes
                         else { const uint32_t sp = perm[e - 1]; l = TILE_EMIT_LCP_(skey[sp], ssa[sp], key, sa); }
                     }
                     if (direct) {
-                        fin.sa[start + e] = sa;
-                        fin.lcp[start + e] = (idx_t)l;
+                        STREAM_STORE(&fin.sa[start + e], sa);
+                        STREAM_STORE(&fin.lcp[start + e], (idx_t)l);
                         if (e == 0) { fin.first_key[g] = key; fin.first_sa[g] = sa; }
                         if (e == cnt - 1) { fin.last_key[g] = key; fin.last_sa[g] = sa; }
                     } else {
@@ -3052,8 +3052,8 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
                 uint64_t key = 0;
                 idx_t sa = 0;
                 if (e < cnt) {
-                    key = FROM_TEXT ? window64<BITS>(twin, text_base + start + e - w0 * TextTraits<BITS>::CPW) : in_key[src];
-                    sa = FROM_TEXT ? (idx_t)(text_base + start + e) : in_sa[src];
+                    key = FROM_TEXT ? window64<BITS>(twin, text_base + start + e - w0 * TextTraits<BITS>::CPW) : STREAM_LOAD(&in_key[src]);
+                    sa = FROM_TEXT ? (idx_t)(text_base + start + e) : STREAM_LOAD(&in_sa[src]);
                 }
                 const uint32_t cell = (uint32_t)(key >> (64 - SPLIT_LUT_BITS));
                 TL(rk, tid, k) = key;
@@ -3085,8 +3085,8 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
                                                                    run_b, run_x0 + e)
                                                : start + e;
                 const uint64_t key = FROM_TEXT ? window64<BITS>(twin, text_base + start + e - w0 * TextTraits<BITS>::CPW)
-                                               : in_key[src];
-                const idx_t sa = FROM_TEXT ? (idx_t)(text_base + start + e) : in_sa[src];
+                                               : (uint64_t)STREAM_LOAD(&in_key[src]);
+                const idx_t sa = FROM_TEXT ? (idx_t)(text_base + start + e) : STREAM_LOAD(&in_sa[src]);
                 uint32_t bk = 0;
                 idx_t r;
                 if (bp.B == 1) r = e;                                        // identity: the segment is its own bucket
@@ -3214,8 +3214,8 @@ GLOBAL_FN LAUNCH_BOUNDS(TILE_NT) bucket_scatter_kernel(KCTX SegDesc sd, const ui
                     spill.sa[dst] = ssa[q];
                 } else if (ob != NO_SLOT) {
                     const uint64_t dst = (uint64_t)ob + (q - hist[bk]);
-                    out_key[dst] = skey[q];
-                    out_sa[dst] = ssa[q];
+                    STREAM_STORE2(&out_key[dst], skey[q]);
+                    STREAM_STORE2(&out_sa[dst], ssa[q]);
                 }
             }
         }
@@ -3462,8 +3462,8 @@ GLOBAL_FN LAUNCH_BOUNDS2(TILE_NT, TILE_WAVES_PER_SIMD) group_scatter_kernel(KCTX
                     if (ob != NO_SLOT) {
                         const uint64_t dst = (uint64_t)ob + (q - hist[g]);
                         const uint64_t key = window64<BITS>(twin, pos0 + e - w0 * CPW);
-                        out_key[dst] = K32 ? (KT)key32_of(key, scs[g]) : (KT)key;
-                        out_sa[dst] = (idx_t)(pos0 + e);
+                        STREAM_STORE2(&out_key[dst], K32 ? (KT)key32_of(key, scs[g]) : (KT)key);
+                        STREAM_STORE2(&out_sa[dst], (idx_t)(pos0 + e));
                     }
                 }
             }
