@@ -1,3 +1,5 @@
+"""One line per bench log (gpurun_out/<name>.json.log): ms per build, the kernel families' times, the count-free split's statistics and the
+verifier's verdict -- the A/B runs behind DESIGN 5.3.  usage (on the GPU box): python3 tools/bench_compare.py <name> [<name> ...]"""
 import json,sys
 for f in sys.argv[1:]:
     d=None
